@@ -1,0 +1,252 @@
+"""ctypes binding of the CPU oracle (oracle/libtgr_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (tensegrity_rl_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NQ, NV, NU, NTEN, NBAR, MAXCON, RING, INFO_K = 21, 18, 6, 9, 3, 32, 32, 16
+
+ENV_TENSEGRITY, ENV_TR = 0, 1
+ACT_STRAIGHT, ACT_TURN, ACT_AIMING, ACT_TRACKING, ACT_VEL_TRACK = range(5)
+ACTIONS = {"straight": 0, "turn": 1, "aiming": 2, "tracking": 3, "vel_track": 4}
+INFO_KEYS = ["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
+             "distance_from_origin", "x_velocity", "y_velocity", "forward_reward", "waypt_x", "waypt_y",
+             "ori_x", "ori_y", "ep_return", "ep_length"]
+
+d = C.c_double
+
+
+class Model(C.Structure):
+    _fields_ = [("timestep", d), ("gravity", d), ("cap_radius", d), ("bar_half", d), ("rcyl_radius", d),
+                ("bcyl_radius", d), ("bcyl_lo", d), ("bcyl_hi", d), ("site_off", d), ("site_z", d), ("mass", d),
+                ("inertia", d * 3), ("invweight_tran", d), ("ten_stiffness", d * NTEN), ("ten_damping", d * NTEN),
+                ("ten_springlen", d * NTEN), ("gain", d), ("bias0", d), ("bias1", d), ("bias2", d), ("force_lo", d),
+                ("force_hi", d), ("ctrl_lo", d), ("ctrl_hi", d), ("solref", d * 2), ("solimp", d * 5),
+                ("friction", d * 5), ("impratio", d), ("actuator_deriv_skip_clamped", C.c_int),
+                ("newton_maxiter", C.c_int), ("qpos0", d * NQ)]
+
+
+class Contact(C.Structure):
+    _fields_ = [("pos", d * 3), ("frame", d * 9), ("dist", d), ("body1", C.c_int), ("body2", C.c_int),
+                ("geom1", C.c_int), ("geom2", C.c_int), ("J", (d * NV) * 6), ("aref", d * 6), ("R", d * 6),
+                ("D", d * 6), ("mu", d), ("force", d * 6), ("zone", C.c_int)]
+
+
+class Data(C.Structure):
+    _fields_ = [("qpos", d * NQ), ("qvel", d * NV), ("ctrl", d * NU), ("qacc_warmstart", d * NV), ("time", d),
+                ("xpos", (d * 3) * NBAR), ("xmat", (d * 9) * NBAR), ("site_xpos", ((d * 3) * 6) * NBAR),
+                ("cap_xpos", (d * 3) * 6), ("ten_length", d * NTEN), ("ten_velocity", d * NTEN),
+                ("ten_J", (d * NV) * NTEN), ("actuator_force", d * NU), ("qfrc_passive", d * NV),
+                ("qfrc_actuator", d * NV), ("qfrc_bias", d * NV), ("qfrc_smooth", d * NV), ("qacc_smooth", d * NV),
+                ("qfrc_constraint", d * NV), ("qacc", d * NV), ("ncon", C.c_int), ("con", Contact * MAXCON),
+                ("cfrc_ext", (d * 6) * 4), ("solver_iter", C.c_int), ("flags", C.c_int)]
+
+
+class EnvCfg(C.Structure):
+    _fields_ = [("env_kind", C.c_int), ("desired_action", C.c_int), ("desired_direction", d),
+                ("terminate_when_unhealthy", C.c_int), ("use_contact_forces", C.c_int), ("use_cap_velocity", C.c_int),
+                ("is_test", C.c_int), ("ctrl_cost_weight", d), ("contact_cost_weight", d), ("healthy_reward", d),
+                ("contact_force_lo", d), ("contact_force_hi", d), ("min_reset_heading", d), ("max_reset_heading", d),
+                ("tendon_reset_mean", d), ("tendon_reset_stdev", d), ("tendon_max_length", d),
+                ("tendon_min_length", d), ("reward_delay_steps", C.c_int), ("waypt_range", d * 2),
+                ("waypt_angle_range", d * 2), ("ditch_reward_max", d), ("ditch_reward_stdev", d),
+                ("waypt_reward_amplitude", d), ("waypt_reward_stdev", d), ("yaw_reward_weight", d),
+                ("frame_skip", C.c_int), ("max_episode_steps", C.c_int)]
+
+
+class Env(C.Structure):
+    _fields_ = [("cfg", EnvCfg), ("model", Model), ("data", Data), ("x_velocity", d), ("y_velocity", d),
+                ("reset_psi", d), ("ring", d * RING), ("ring_len", C.c_int), ("ring_head", C.c_int),
+                ("step_num", C.c_int), ("elapsed", C.c_int), ("waypt", d * 2), ("oripoint", d * 2),
+                ("lin_vel_cmd", d * 2), ("ang_vel_cmd", d), ("ep_return", d), ("obs_dim", C.c_int)]
+
+
+_lib = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libtgr_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("tgr_physics.c", "tgr_env.c", "tgr_batch.c", "tgr_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "libtgr_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = os.path.join(_HERE, "libtgr_oracle.so")
+    if not os.path.exists(so):
+        build()
+    L = C.CDLL(so)
+    L.tgo_sizeof_env.restype = C.c_int
+    assert L.tgo_sizeof_env() == C.sizeof(Env), (L.tgo_sizeof_env(), C.sizeof(Env))
+    assert L.tgo_sizeof_data() == C.sizeof(Data)
+    assert L.tgo_sizeof_model() == C.sizeof(Model)
+    assert L.tgo_sizeof_cfg() == C.sizeof(EnvCfg)
+    P = C.POINTER
+    L.tgo_default_model.argtypes = [P(Model)]
+    L.tgo_reset_data.argtypes = [P(Model), P(Data)]
+    L.tgo_forward.argtypes = [P(Model), P(Data)]
+    L.tgo_step.argtypes = [P(Model), P(Data), C.c_int]
+    L.tgo_env_default_cfg.argtypes = [P(EnvCfg), C.c_int, C.c_int]
+    L.tgo_env_init.argtypes = [P(Env), P(EnvCfg)]
+    L.tgo_env_obs_dim.argtypes = [P(EnvCfg)]
+    L.tgo_env_obs_dim.restype = C.c_int
+    L.tgo_env_reset.argtypes = [P(Env), C.c_int, d, P(d), P(d), P(d)]
+    L.tgo_env_step.argtypes = [P(Env), P(C.c_float), P(d), P(d), P(C.c_int), P(C.c_int), P(d)]
+    L.tgo_env_get_obs.argtypes = [P(Env), P(d)]
+    L.tgo_env_reset_seeded.argtypes = [P(Env), C.c_uint64, C.c_uint64, C.c_uint64, P(d)]
+    L.tgo_rng_draws.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, d, d, d, d, d, d, P(C.c_int), P(d), P(d), P(d)]
+    L.tgo_yaw_pose.argtypes = [P(d), d, P(d)]
+    L.tgo_philox4x32.argtypes = [P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
+    L.tgo_batch_create.argtypes = [P(EnvCfg), C.c_int, C.c_uint64, C.c_uint64]
+    L.tgo_batch_create.restype = C.c_void_p
+    L.tgo_batch_destroy.argtypes = [C.c_void_p]
+    L.tgo_batch_env.argtypes = [C.c_void_p, C.c_int]
+    L.tgo_batch_env.restype = P(Env)
+    L.tgo_batch_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.tgo_batch_step.argtypes = [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int, C.c_int]
+    _lib = L
+    return L
+
+
+def arr(x):
+    return np.ctypeslib.as_array(x)
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(d))
+
+
+def default_model():
+    m = Model()
+    lib().tgo_default_model(C.byref(m))
+    return m
+
+
+def new_data(m):
+    dd = Data()
+    lib().tgo_reset_data(C.byref(m), C.byref(dd))
+    return dd
+
+
+def rolling_qpos():
+    return np.array((d * NQ * 6).in_dll(lib(), "tgo_rolling_qpos")).reshape(6, NQ)
+
+
+def make_cfg(env_kind="tensegrity_env", desired_action="straight", **kw):
+    c = EnvCfg()
+    kind = ENV_TENSEGRITY if env_kind in ("tensegrity_env", 0) else ENV_TR
+    lib().tgo_env_default_cfg(C.byref(c), kind, ACTIONS[desired_action] if isinstance(desired_action, str) else desired_action)
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise KeyError(k)
+        setattr(c, k, v)
+    return c
+
+
+class OracleEnv:
+    """Scalar oracle env (one instance of the reference's Env semantics)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.e = Env()
+        lib().tgo_env_init(C.byref(self.e), C.byref(cfg))
+        self.obs_dim = self.e.obs_dim
+
+    @property
+    def data(self):
+        return self.e.data
+
+    def reset(self, pose_idx, theta, tendons, u_way=(0.5, 0.5)):
+        t = np.ascontiguousarray(tendons, dtype=np.float64)
+        u = np.ascontiguousarray(u_way, dtype=np.float64)
+        obs = np.zeros(self.obs_dim)
+        lib().tgo_env_reset(C.byref(self.e), int(pose_idx), float(theta), dptr(t), dptr(u), dptr(obs))
+        return obs
+
+    def reset_seeded(self, seed, env_id, episode):
+        obs = np.zeros(self.obs_dim)
+        lib().tgo_env_reset_seeded(C.byref(self.e), seed, env_id, episode, dptr(obs))
+        return obs
+
+    def get_obs(self):
+        obs = np.zeros(self.obs_dim)
+        lib().tgo_env_get_obs(C.byref(self.e), dptr(obs))
+        return obs
+
+    def step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        obs = np.zeros(self.obs_dim)
+        rew = d(0)
+        term, trunc = C.c_int(0), C.c_int(0)
+        info = np.zeros(INFO_K)
+        lib().tgo_env_step(C.byref(self.e), a.ctypes.data_as(C.POINTER(C.c_float)), dptr(obs), C.byref(rew),
+                           C.byref(term), C.byref(trunc), dptr(info))
+        return obs, rew.value, bool(term.value), bool(trunc.value), dict(zip(INFO_KEYS, info))
+
+
+class OracleBatch:
+    """N oracle envs with VecEnv auto-reset semantics, OpenMP over envs."""
+
+    def __init__(self, cfg, n, seed=1234, first_env_id=0, threads=None):
+        self.n = n
+        self.cfg = cfg
+        self.threads = threads or os.cpu_count()
+        self.h = lib().tgo_batch_create(C.byref(cfg), n, seed, first_env_id)
+        self.obs_dim = lib().tgo_env_obs_dim(C.byref(cfg))
+
+    def env(self, i):
+        return lib().tgo_batch_env(self.h, i).contents
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.n, self.obs_dim))
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().tgo_batch_reset(self.h, None if m is None else m.ctypes.data, obs.ctypes.data, self.threads)
+        return obs
+
+    def step(self, actions, auto_reset=True):
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, 6)
+        obs = np.zeros((self.n, self.obs_dim))
+        tobs = np.zeros((self.n, self.obs_dim))
+        rew = np.zeros(self.n)
+        term = np.zeros(self.n, dtype=np.uint8)
+        trunc = np.zeros(self.n, dtype=np.uint8)
+        info = np.zeros((self.n, INFO_K))
+        lib().tgo_batch_step(self.h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
+                             trunc.ctypes.data, tobs.ctypes.data, info.ctypes.data, int(auto_reset), self.threads)
+        return obs, rew, term.astype(bool), trunc.astype(bool), tobs, info
+
+    def get_state(self):
+        """qpos[N,21], qvel[N,18], ctrl[N,6], warm[N,18], aux dict of arrays (what the HIP path keeps per env)."""
+        n = self.n
+        qpos = np.zeros((n, NQ)); qvel = np.zeros((n, NV)); ctrl = np.zeros((n, NU)); warm = np.zeros((n, NV))
+        aux = {k: np.zeros(n) for k in ("xy_lag_x", "xy_lag_y", "psi_lag", "reset_psi", "step_num", "elapsed", "ep_return")}
+        for i in range(n):
+            e = self.env(i)
+            qpos[i] = arr(e.data.qpos); qvel[i] = arr(e.data.qvel); ctrl[i] = arr(e.data.ctrl)
+            warm[i] = arr(e.data.qacc_warmstart)
+            xp = arr(e.data.xpos)
+            aux["xy_lag_x"][i] = xp[:, 0].mean(); aux["xy_lag_y"][i] = xp[:, 1].mean()
+            aux["reset_psi"][i] = e.reset_psi; aux["step_num"][i] = e.step_num; aux["elapsed"][i] = e.elapsed
+            aux["ep_return"][i] = e.ep_return
+        return qpos, qvel, ctrl, warm, aux
+
+    def close(self):
+        if self.h:
+            lib().tgo_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

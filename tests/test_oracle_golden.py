@@ -1,0 +1,72 @@
+"""The C restatement of the Python env layer (oracle/tgr_env.c) against fixtures produced by the
+reference env classes themselves (oracle/gen_golden.py, reference tensegrity_env.py:291-512, tr_env.py:327-872).
+
+Same physics feeds both, so agreement is expected to rounding (1e-9), which pins reward / obs /
+termination / reset-pose maths of the oracle before the oracle is used to check the HIP path."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+INFO = ["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
+        "distance_from_origin", "x_velocity", "y_velocity", "forward_reward"]
+
+
+def qpos_close(a, b, atol):
+    """qpos comparison up to the sign of each free-joint quaternion (q and -q are the same rotation;
+    the reference's reset goes through scipy euler angles, which fixes an arbitrary sign)."""
+    a = np.asarray(a, dtype=np.float64).reshape(3, 7).copy()
+    b = np.asarray(b, dtype=np.float64).reshape(3, 7)
+    for i in range(3):
+        if np.dot(a[i, 3:], b[i, 3:]) < 0:
+            a[i, 3:] *= -1
+    np.testing.assert_allclose(a, b, rtol=0, atol=atol)
+
+
+def load_cases(golden_dir):
+    return sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "helpers" not in f)
+
+
+def cfg_from_fixture(O, g):
+    kw = {k: v for k, v in zip(g["kwargs_keys"], g["kwargs_vals"])}
+    kw = {k: (int(v) if k in ("terminate_when_unhealthy", "use_contact_forces", "use_cap_velocity") else float(v)) for k, v in kw.items()}
+    return O.make_cfg(str(g["kind"]), str(g["action"]), desired_direction=float(g["direction"]), **kw)
+
+
+def test_fixtures_present(golden_dir):
+    assert len(load_cases(golden_dir)) >= 10
+
+
+@pytest.mark.parametrize("idx", range(10))
+def test_oracle_env_matches_reference_classes(oracle, golden_dir, idx):
+    O = oracle
+    path = load_cases(golden_dir)[idx]
+    g = np.load(path)
+    env = O.OracleEnv(cfg_from_fixture(O, g))
+    T = int(g["steps_per_episode"])
+    k = 0
+    for ep in range(len(g["reset_theta"])):
+        obs0 = env.reset(int(g["reset_pose"][ep]), float(g["reset_theta"][ep]), g["reset_tendons"][ep], g["reset_u_way"][ep])
+        qpos_close(O.arr(env.data.qpos), g["reset_qpos"][ep], 1e-9)
+        np.testing.assert_allclose(O.arr(env.data.qvel), g["reset_qvel"][ep], rtol=0, atol=1e-8)
+        assert abs(env.e.reset_psi - g["reset_reset_psi"][ep]) < 1e-9
+        np.testing.assert_allclose(obs0, g["reset_obs"][ep], rtol=0, atol=1e-8)
+        for t in range(T):
+            obs, r, term, trunc, info = env.step(g["actions"][k])
+            qpos_close(O.arr(env.data.qpos), g["qpos"][k], 1e-8)
+            np.testing.assert_allclose(obs, g["obs"][k], rtol=0, atol=1e-7, err_msg=f"{path} step {k}")
+            assert abs(r - g["reward"][k]) < 1e-7, (path, k, r, g["reward"][k])
+            assert term == bool(g["terminated"][k])
+            for name in INFO:
+                assert abs(info[name] - g[name][k]) < 1e-7, (path, k, name)
+            k += 1
+
+
+def test_helper_known_answers(oracle, golden_dir):
+    """tr_env.py:648-683 helper outputs recorded from the reference class; also SURVEY.md 8c probes."""
+    g = np.load(os.path.join(golden_dir, "tr_env_helpers.npz"))
+    assert abs(g["ditch"][0] - 80.0737402916808) < 1e-9
+    assert abs(g["vel_track"][0] - 1.396163535868496) < 1e-12
+    assert abs(g["ang"][0] - (-2.2831853071795862)) < 1e-12
+    np.testing.assert_allclose(g["filt"], 0.002, atol=1e-15)
