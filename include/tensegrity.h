@@ -1,0 +1,146 @@
+/*
+ * tensegrity.h -- C-ABI of the MI355X batched tensegrity simulator (libtensegrity.so).
+ *
+ * Drop-in boundary for the reference's hot path.  Each entry point names the reference
+ * interface it replaces (paths relative to drsteinkauz/tensegrity-RL):
+ *
+ *   tgr_create      gym.make('tensegrity_env-v0' | 'tr_env-v0', **kwargs) -> env.__init__
+ *                   (tensegrity_env/tensegrity_env/envs/tensegrity_env.py:160-243,
+ *                    tr_env/tr_env/envs/tr_env.py:137-278, run.py:413-418) which loads the model
+ *                   through gym MujocoEnv.__init__ -> mujoco.MjModel.from_xml_path / MjData.
+ *   tgr_reset       Env.reset() -> MujocoEnv.reset -> mj_resetData + reset_model()
+ *                   (tensegrity_env.py:433-512, tr_env.py:709-872).
+ *   tgr_step[_f64]  Env.step(action) (tensegrity_env.py:291-410, tr_env.py:327-527) =
+ *                   MujocoEnv.do_simulation -> mujoco.mj_step(nstep=20) + mj_rnePostConstraint,
+ *                   then _get_obs / reward / termination; batched over N envs with SB3 VecEnv
+ *                   auto-reset semantics (DummyVecEnv.step_wait: terminal_observation, reset obs).
+ *   tgr_get_state / tgr_set_state
+ *                   env.data.qpos/qvel/ctrl/qacc_warmstart reads and MujocoEnv.set_state
+ *                   (tensegrity_env.py:448,484) -- used for "identical (state, action)" parity.
+ *
+ * Conventions: plain C types only.  All array arguments of tgr_reset/tgr_step are DEVICE
+ * pointers owned by the caller (e.g. torch tensors), valid for the duration of the call's
+ * stream work; get/set_state take HOST pointers and synchronise.  Every function returns 0 on
+ * success and a negative code on failure; tgr_last_error() gives the message.  One caller
+ * thread per handle.  Kernels are enqueued on the HIP stream passed in (NULL = default stream).
+ */
+#ifndef TENSEGRITY_H
+#define TENSEGRITY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGR_OK 0
+#define TGR_ERR_INVALID (-1)
+#define TGR_ERR_HIP (-2)
+#define TGR_ERR_UNSUPPORTED (-3)
+
+#define TGR_ENV_TENSEGRITY 0 /* id 'tensegrity_env-v0' */
+#define TGR_ENV_TR 1         /* id 'tr_env-v0' */
+
+#define TGR_ACT_STRAIGHT 0
+#define TGR_ACT_TURN 1
+#define TGR_ACT_AIMING 2
+#define TGR_ACT_TRACKING 3
+#define TGR_ACT_VEL_TRACK 4
+
+#define TGR_PRECISION_F32 0
+#define TGR_PRECISION_F64 1
+
+#define TGR_NQ 21
+#define TGR_NV 18
+#define TGR_NU 6
+#define TGR_INFO_K 16
+/* info row layout (float/double [N][TGR_INFO_K]); the first ten are the reference's info dict
+ * (tensegrity_env.py:388-400), then tr_env's waypt/oripoint, then Monitor-style episode stats */
+enum {
+  TGR_INFO_REWARD_FORWARD = 0, TGR_INFO_REWARD_CTRL, TGR_INFO_REWARD_SURVIVE, TGR_INFO_X_POSITION,
+  TGR_INFO_Y_POSITION, TGR_INFO_PSI, TGR_INFO_DISTANCE, TGR_INFO_X_VELOCITY, TGR_INFO_Y_VELOCITY,
+  TGR_INFO_FORWARD_REWARD, TGR_INFO_WAYPT_X, TGR_INFO_WAYPT_Y, TGR_INFO_ORI_X, TGR_INFO_ORI_Y,
+  TGR_INFO_EP_RETURN, TGR_INFO_EP_LENGTH
+};
+
+typedef struct tgr_config {
+  /* --- env semantics: same names / defaults as the reference constructors */
+  int32_t env_kind;       /* TGR_ENV_* */
+  int32_t desired_action; /* TGR_ACT_* */
+  double desired_direction;
+  int32_t terminate_when_unhealthy;
+  int32_t use_contact_forces;
+  int32_t use_cap_velocity; /* tr_env */
+  int32_t is_test;          /* tr_env */
+  double ctrl_cost_weight, contact_cost_weight, healthy_reward;
+  double contact_force_lo, contact_force_hi;
+  double min_reset_heading, max_reset_heading;
+  double tendon_reset_mean, tendon_reset_stdev, tendon_max_length, tendon_min_length;
+  int32_t reward_delay_steps;
+  int32_t frame_skip;        /* 20 */
+  int32_t max_episode_steps; /* 5000, gym TimeLimit of the registration */
+  /* --- model (3prism_jonathan_steady_side.xml) */
+  double timestep, gravity, cap_radius;
+  double solref[2], solimp[5], friction[3], impratio;
+  double gain, bias[3], force_range[2], ctrl_range[2];
+  double ten_stiffness[9], ten_damping[9], ten_springlength[9];
+  int32_t actuator_deriv_skip_clamped;
+  /* --- execution */
+  int32_t precision;    /* TGR_PRECISION_* */
+  int32_t auto_reset;   /* 1 = VecEnv semantics, 0 = plain Gym Env semantics */
+  int32_t async_reset;  /* 1 = pre-settle the next episode of every env on a side stream */
+  uint64_t seed;        /* reset RNG: philox4x32-10 keyed (seed, first_env_id + i, episode) */
+  uint64_t first_env_id;
+  double solver_tolerance; /* <=0: default for the precision */
+  int32_t solver_iterations;
+} tgr_config;
+
+typedef struct tgr_handle tgr_handle;
+
+/* fills *cfg with the reference defaults of the given env class / desired_action */
+int tgr_default_config(tgr_config* cfg, int env_kind, int desired_action);
+int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_handle** out);
+int tgr_destroy(tgr_handle* h);
+int tgr_num_envs(const tgr_handle* h);
+int tgr_obs_dim(const tgr_handle* h);
+int tgr_precision(const tgr_handle* h);
+
+/* reset envs with mask[i] != 0 (mask: HOST uint8[N] or NULL = all); obs: DEVICE [N][obs_dim]
+ * of the handle's precision (float or double), rows of reset envs are written; may be NULL */
+int tgr_reset(tgr_handle* h, const uint8_t* mask_host, void* obs_dev, void* hip_stream);
+
+/* one control period for all envs (fp32 handle) */
+int tgr_step(tgr_handle* h, const float* actions /*[N][6]*/, float* obs /*[N][D]*/, float* reward /*[N]*/,
+             uint8_t* terminated /*[N]*/, uint8_t* truncated /*[N]*/, float* terminal_obs /*[N][D] or NULL*/,
+             float* info /*[N][TGR_INFO_K] or NULL*/, void* hip_stream);
+/* same for an fp64 handle (parity checking) */
+int tgr_step_f64(tgr_handle* h, const float* actions, double* obs, double* reward, uint8_t* terminated,
+                 uint8_t* truncated, double* terminal_obs, double* info, void* hip_stream);
+
+/* HOST arrays, any may be NULL: qpos[N][21], qvel[N][18] (MuJoCo convention: world linear,
+ * body-frame angular), ctrl[N][6], qacc_warmstart[N][18], aux[N][TGR_AUX_K] */
+#define TGR_AUX_K 16
+enum {
+  TGR_AUX_XY_LAG_X = 0, TGR_AUX_XY_LAG_Y, TGR_AUX_PSI_LAG, TGR_AUX_RESET_PSI, TGR_AUX_EP_RETURN,
+  TGR_AUX_STEP_NUM, TGR_AUX_ELAPSED, TGR_AUX_EPISODE, TGR_AUX_RING_LEN, TGR_AUX_WAYPT_X, TGR_AUX_WAYPT_Y,
+  TGR_AUX_ORI_X, TGR_AUX_ORI_Y, TGR_AUX_VCMD_X, TGR_AUX_VCMD_Y, TGR_AUX_VCMD_W
+};
+int tgr_get_state(tgr_handle* h, double* qpos, double* qvel, double* ctrl, double* qacc_warmstart, double* aux);
+/* set_state: like MujocoEnv.set_state it also recomputes the derived (lagged) kinematics from qpos;
+ * aux (if given) then overrides the stored aux fields */
+int tgr_set_state(tgr_handle* h, const double* qpos, const double* qvel, const double* ctrl,
+                  const double* qacc_warmstart, const double* aux);
+
+/* counters since creation: [0] dropped bar-bar contacts (slot overflow), [1] envs reset synchronously,
+ * [2] envs reset from a pre-settled state, [3] settle launches on the side stream */
+int tgr_stats(tgr_handle* h, uint64_t out[4]);
+/* re-key the reset RNG (Env.reset(seed=...)); takes effect for subsequent resets */
+int tgr_set_seed(tgr_handle* h, uint64_t seed);
+int tgr_synchronize(tgr_handle* h);
+const char* tgr_last_error(const tgr_handle* h);
+const char* tgr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -605,6 +605,9 @@ static void line_eval(const tgo_model* m, tgo_data* d, const double* qacc, const
   *d1 = g1; *d2 = g2;
 }
 
+double tgo_debug_ls_tol = 1e-13; /* test hook: relative line-search tolerance */
+int tgo_debug_trace = 0;
+#include <stdio.h>
 static void newton_solve(const tgo_model* m, tgo_data* d) {
   double qacc[TGO_NV], grad[TGO_NV], p[TGO_NV], H[TGO_NV * TGO_NV];
   d->solver_iter = 0;
@@ -642,7 +645,7 @@ static void newton_solve(const tgo_model* m, tgo_data* d) {
     int ok = 0;
     for (int ls = 0; ls < 100; ls++) {
       line_eval(m, d, qacc, p, alpha, &d1, &d2);
-      if (fabs(d1) <= 1e-13 * fabs(d0)) { ok = 1; break; }
+      if (fabs(d1) <= tgo_debug_ls_tol * fabs(d0)) { ok = 1; break; }
       if (d1 < 0) lo = alpha; else hi = alpha;
       double na = d2 > 0 ? alpha - d1 / d2 : -1;
       if (hi < 0) { if (na <= lo || na > 10 * (lo + 1)) na = 2 * alpha + 1e-3; }
@@ -651,6 +654,7 @@ static void newton_solve(const tgo_model* m, tgo_data* d) {
       alpha = na;
     }
     (void)ok;
+    if (tgo_debug_trace) { int z[8]={0}; for (int ci=0;ci<d->ncon&&ci<8;ci++) z[ci]=d->con[ci].zone; printf("it %d gn %.3e d0 %.3e alpha %.6f zones %d%d%d%d qacc0 %.5f\n", it, gn, d0, alpha, z[0],z[1],z[2],z[3], qacc[0]); }
     double step = 0, mag = 0;
     for (int k = 0; k < TGO_NV; k++) { qacc[k] += alpha * p[k]; step += fabs(alpha * p[k]); mag += fabs(qacc[k]); }
     if (step <= 1e-15 * (1.0 + mag)) break; /* converged to rounding */

@@ -1,0 +1,844 @@
+// tgr_sim.hip -- kernels + C-ABI of the batched tensegrity simulator for MI355X (gfx950).
+//
+// Layout in HBM: structure-of-arrays, field-major:  st[field][env]  so that the 64 lanes of a
+// wave (64 consecutive envs) read/write 256 contiguous bytes per field.  One env-step = ONE
+// kernel launch: state is read once, all 20 sub-steps run out of registers/LDS, state + outputs
+// are written once.  Observations leave through an LDS transpose so the [N][D] row-major
+// buffer SB3 wants is still written with coalesced stores.
+//
+// Reference behaviour reproduced: tensegrity_env.py:291-512 and tr_env.py:327-872 on top of
+// mujoco 2.3.7 mj_step (see include/tensegrity.h for the entry-point mapping).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/tensegrity.h"
+#include "tgr_device.h"
+
+namespace tgr {
+
+// ------------------------------------------------------------------ state layout
+enum : int {
+  F_QPOS = 0, F_QVEL = 21, F_WARM = 39, F_CTRL = 57, F_XYLAG = 63, F_PSILAG = 65, F_RESETPSI = 66,
+  F_EPRET = 67, F_WAYPT = 68, F_ORI = 70, F_VCMD = 72, NF = 75
+};
+enum : int { I_STEPNUM = 0, I_ELAPSED, I_RINGLEN, I_RINGHEAD, I_EPISODE, NI };
+constexpr int RING = 32;
+constexpr int LDS_SLOTS = 92 + 171;
+constexpr double PI = 3.14159265358979323846;
+
+template <typename T> struct EnvCfg {
+  int env_kind, action, terminate_when_unhealthy, use_contact_forces, use_cap_velocity, is_test;
+  int reward_delay_steps, frame_skip, max_episode_steps, obs_dim;
+  T direction, ctrl_cost_weight, contact_cost_weight, healthy_reward, contact_lo, contact_hi, dt;
+  double min_heading, max_heading, ten_mean, ten_std, ten_max, ten_min;
+  unsigned long long seed, first_env_id;
+};
+
+template <typename T> struct KArgs {
+  Params<T> P;
+  EnvCfg<T> E;
+  int n;
+  T* st; int* ist; T* ring;
+  const float* actions;
+  T* obs; T* reward; uint8_t* terminated; uint8_t* truncated; T* terminal_obs; T* info;
+  int* list_count; int* list;  // envs to (re)settle
+  unsigned long long* counters;
+  int auto_reset;
+  T* obs_reset;  // where the settle kernel writes reset observations ([N][D]) or null
+};
+
+__constant__ double c_qpos0[21] = {0.08369179, -0.28792231, 0.24830847, -0.49145555, 0.7539914, -0.27511722, -0.33805166,
+                                   0.14497616, -0.19291743, 0.35052097, -0.84766041, 0.27950622, 0.45085889, 0.00862359,
+                                   0.04557825, -0.29876206, 0.39531985, -0.35798606, -0.47531391, 0.72471075, 0.34744352};
+// tr_env.py:723-728
+__constant__ double c_rolling[6][21] = {
+    {0.07900689, -0.32670045, 0.23079722, 0.49365198, -0.74001353, 0.26668361, 0.37090101, 0.13713385, -0.24342633, 0.32722167, 0.82936968, -0.31256817, -0.46189217, -0.03320677, 0.04903377, -0.3421725, 0.36675097, 0.33407281, 0.43794432, -0.72515863, -0.41321313},
+    {0.15521685, -0.20651043, 0.38922255, 0.85639289, -0.26723449, -0.44110818, -0.02450564, 0.02999107, -0.33576412, 0.43868814, 0.33839518, 0.48544838, -0.73094128, -0.33993149, 0.08083394, -0.31942006, 0.25783949, 0.51726058, -0.74281033, 0.29432583, 0.30667022},
+    {0.02985312, -0.33588999, 0.43866597, 0.33840617, 0.48522953, -0.73107566, -0.33994403, 0.08072907, -0.31942136, 0.25766037, 0.51740763, -0.74276722, 0.29421311, 0.30663471, 0.15537661, -0.20664637, 0.38923648, 0.85640002, -0.26722239, -0.44110397, -0.02446392},
+    {0.24191878, 0.30939576, 0.25838614, 0.04211683, -0.66689235, -0.44050762, 0.59952798, 0.1105878, 0.33967509, 0.38925944, 0.50825334, 0.20884794, -0.4715363, 0.68972067, 0.27475478, 0.2682452, 0.4387596, 0.47235593, 0.87732918, -0.01675131, 0.08302277},
+    {0.1105878, 0.33967509, 0.38925944, 0.50825334, 0.20884794, -0.4715363, 0.68972067, 0.27475478, 0.2682452, 0.4387596, 0.47235593, 0.87732918, -0.01675131, 0.08302277, 0.24191878, 0.30939576, 0.25838614, 0.04211683, -0.66689235, -0.44050762, 0.59952798},
+    {0.27475478, 0.2682452, 0.4387596, 0.47235593, 0.87732918, -0.01675131, 0.08302277, 0.24191878, 0.30939576, 0.25838614, 0.04211683, -0.66689235, -0.44050762, 0.59952798, 0.1105878, 0.33967509, 0.38925944, 0.50825334, 0.20884794, -0.4715363, 0.68972067}};
+
+// ------------------------------------------------------------------ counter-based RNG (philox4x32-10)
+__device__ inline void philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* o) {
+  for (int r = 0; r < 10; r++) {
+    unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ inline double u53(unsigned a, unsigned b) { return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0; }
+
+struct Draws { int pose; double theta; double tendons[6]; double u_way[2]; };
+template <typename T> __device__ inline Draws reset_draws(const EnvCfg<T>& E, unsigned long long env_id, unsigned long long episode) {
+  Draws d;
+  unsigned k0 = (unsigned)E.seed, k1 = (unsigned)(E.seed >> 32);
+  unsigned c0 = (unsigned)env_id, c1 = (unsigned)(env_id >> 32), c2 = (unsigned)episode;
+  unsigned o[4];
+  philox(c0, c1, c2, 0, k0, k1, o);
+  d.pose = (int)(o[0] % 6u);
+  d.theta = E.min_heading + u53(o[1], o[2]) * (E.max_heading - E.min_heading);
+  for (int k = 0; k < 3; k++) {
+    philox(c0, c1, c2, 1 + k, k0, k1, o);
+    double u1 = 1.0 - u53(o[0], o[1]), u2 = u53(o[2], o[3]);
+    double r = sqrt(-2.0 * log(u1));
+    double z0 = r * cos(2 * PI * u2), z1 = r * sin(2 * PI * u2);
+    double t0 = z0 * E.ten_std + E.ten_mean, t1 = z1 * E.ten_std + E.ten_mean;
+    d.tendons[2 * k] = t0 > E.ten_max ? E.ten_max : (t0 < E.ten_min ? E.ten_min : t0);
+    d.tendons[2 * k + 1] = t1 > E.ten_max ? E.ten_max : (t1 < E.ten_min ? E.ten_min : t1);
+  }
+  philox(c0, c1, c2, 4, k0, k1, o);
+  d.u_way[0] = u53(o[0], o[1]);
+  d.u_way[1] = u53(o[2], o[3]);
+  return d;
+}
+
+// ------------------------------------------------------------------ state <-> registers
+template <typename T> TGR_DEV void load_sim(const T* st, int n, int e, Sim<T>& S) {
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    S.x[b] = mk(st[(F_QPOS + 7 * b + 0) * n + e], st[(F_QPOS + 7 * b + 1) * n + e], st[(F_QPOS + 7 * b + 2) * n + e]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) S.q[b][i] = st[(F_QPOS + 7 * b + 3 + i) * n + e];
+    normalize_quat(S.q[b]);
+    Rot<T> R = quat_rot(S.q[b]);
+    S.v[b] = mk(st[(F_QVEL + 6 * b + 0) * n + e], st[(F_QVEL + 6 * b + 1) * n + e], st[(F_QVEL + 6 * b + 2) * n + e]);
+    V3<T> wb = mk(st[(F_QVEL + 6 * b + 3) * n + e], st[(F_QVEL + 6 * b + 4) * n + e], st[(F_QVEL + 6 * b + 5) * n + e]);
+    S.w[b] = rot_apply(R, wb);
+    S.al[b] = mk(st[(F_WARM + 6 * b + 0) * n + e], st[(F_WARM + 6 * b + 1) * n + e], st[(F_WARM + 6 * b + 2) * n + e]);
+    V3<T> ab = mk(st[(F_WARM + 6 * b + 3) * n + e], st[(F_WARM + 6 * b + 4) * n + e], st[(F_WARM + 6 * b + 5) * n + e]);
+    S.aa[b] = rot_apply(R, ab);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) S.ctrl[i] = st[(F_CTRL + i) * n + e];
+}
+// wb_out: body-frame angular velocity (what qvel stores), needed by the tr_env observation
+template <typename T> TGR_DEV void store_sim(T* st, int n, int e, Sim<T>& S, const Lag<T>& lag, V3<T>* wb_out) {
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    normalize_quat(S.q[b]);
+    Rot<T> R = quat_rot(S.q[b]);
+    st[(F_QPOS + 7 * b + 0) * n + e] = S.x[b].x; st[(F_QPOS + 7 * b + 1) * n + e] = S.x[b].y; st[(F_QPOS + 7 * b + 2) * n + e] = S.x[b].z;
+#pragma unroll
+    for (int i = 0; i < 4; i++) st[(F_QPOS + 7 * b + 3 + i) * n + e] = S.q[b][i];
+    V3<T> wb = rot_applyT(R, S.w[b]);
+    wb_out[b] = wb;
+    st[(F_QVEL + 6 * b + 0) * n + e] = S.v[b].x; st[(F_QVEL + 6 * b + 1) * n + e] = S.v[b].y; st[(F_QVEL + 6 * b + 2) * n + e] = S.v[b].z;
+    st[(F_QVEL + 6 * b + 3) * n + e] = wb.x; st[(F_QVEL + 6 * b + 4) * n + e] = wb.y; st[(F_QVEL + 6 * b + 5) * n + e] = wb.z;
+    // warm start is kept the way mujoco keeps it: body-frame angular part of the last forward pass
+    Rot<T> Rl = quat_rot(lag.q[b]);
+    V3<T> ab = rot_applyT(Rl, S.aa[b]);
+    st[(F_WARM + 6 * b + 0) * n + e] = S.al[b].x; st[(F_WARM + 6 * b + 1) * n + e] = S.al[b].y; st[(F_WARM + 6 * b + 2) * n + e] = S.al[b].z;
+    st[(F_WARM + 6 * b + 3) * n + e] = ab.x; st[(F_WARM + 6 * b + 4) * n + e] = ab.y; st[(F_WARM + 6 * b + 5) * n + e] = ab.z;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) st[(F_CTRL + i) * n + e] = S.ctrl[i];
+}
+
+template <typename T> TGR_DEV T atan2_(T y, T x) { return sizeof(T) == 4 ? T(atan2f(float(y), float(x))) : T(atan2(double(y), double(x))); }
+template <typename T> TGR_DEV T cos_(T x) { return sizeof(T) == 4 ? T(cosf(float(x))) : T(cos(double(x))); }
+
+template <typename T> TGR_DEV void caps_of(const Params<T>& P, const Lag<T>& lag, V3<T>* cap) {
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    cap[2 * b] = lag.x[b] + P.bar_half * lag.z[b];
+    cap[2 * b + 1] = lag.x[b] - P.bar_half * lag.z[b];
+  }
+}
+template <typename T> TGR_DEV void left_right(const V3<T>* cap, V3<T>& l, V3<T>& r) {
+  T third = T(1.0 / 3.0);
+  l = third * (cap[0] + cap[2] + cap[4]);
+  r = third * (cap[1] + cap[3] + cap[5]);
+}
+
+// observation of the env into o[0..D)
+template <typename T>
+TGR_DEV void make_obs(const Params<T>& P, const EnvCfg<T>& E, const Sim<T>& S, const Lag<T>& lag, const V3<T>* wb, T* o) {
+  if (E.env_kind == TGR_ENV_TENSEGRITY) {
+    // tensegrity_env.py:412-430: scipy quaternion (x,y,z,w) of the r-cylinder geom frame = body * quat(0,0,0,1)
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      T w = lag.q[b][0], x = lag.q[b][1], y = lag.q[b][2], z = lag.q[b][3];
+      T g[4] = {y, -x, w, -z};
+      T m = g[0] * g[0]; T sg = g[0];
+#pragma unroll
+      for (int i = 1; i < 4; i++) { T a = g[i] * g[i]; bool big = a > m; m = big ? a : m; sg = big ? g[i] : sg; }
+      T s = sg < T(0) ? T(-1) : T(1);
+#pragma unroll
+      for (int i = 0; i < 4; i++) o[4 * b + i] = s * g[i];
+      o[12 + 6 * b + 0] = S.v[b].x; o[12 + 6 * b + 1] = S.v[b].y; o[12 + 6 * b + 2] = S.v[b].z;
+      o[12 + 6 * b + 3] = wb[b].x; o[12 + 6 * b + 4] = wb[b].y; o[12 + 6 * b + 5] = wb[b].z;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) o[30 + t] = lag.tenL[t];
+    return;
+  }
+  // tr_env.py:529-646
+  V3<T> cap[6];
+  caps_of(P, lag, cap);
+  V3<T> c = T(1.0 / 6.0) * (((cap[0] + cap[1]) + (cap[2] + cap[3])) + (cap[4] + cap[5]));
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { V3<T> r = cap[i] - c; o[k++] = r.x; o[k++] = r.y; o[k++] = r.z; }
+  if (E.use_cap_velocity) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const int b = i / 2;
+      V3<T> r = cap[i] - lag.x[b];
+      V3<T> vv = S.v[b] + cross(wb[b], r);  // body-frame w used as if world (tr_env.py:596-601)
+      o[k++] = vv.x; o[k++] = vv.y; o[k++] = vv.z;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; t++) o[k++] = lag.tenL[t];
+}
+
+template <typename T> struct StepOut { T reward; bool terminated; T info[10]; T psi_straight; T xy[2]; };
+
+// ring buffer of headings (collections.deque that is never cleared: tensegrity_env.py:243)
+template <typename T> struct RingRef { T* ring; int n, e; int len, head; };
+template <typename T> TGR_DEV void ring_push(RingRef<T>& r, T v) { r.ring[((r.head + r.len) % RING) * r.n + r.e] = v; r.len++; }
+template <typename T> TGR_DEV T ring_pop(RingRef<T>& r) { T v = r.ring[r.head * r.n + r.e]; r.head = (r.head + 1) % RING; r.len--; return v; }
+
+// reward / termination of one env step (tensegrity_env.py:291-410, tr_env.py:327-527; straight and turn)
+template <typename T>
+TGR_DEV StepOut<T> env_epilogue(const Params<T>& P, const EnvCfg<T>& E, const Sim<T>& S, const Lag<T>& lag, const V3<T>* wb,
+                                const T* action, T xy_bx, T xy_by, T reset_psi, RingRef<T>& ring) {
+  StepOut<T> o;
+  T third = T(1.0 / 3.0);
+  T xa = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x), ya = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
+  T idt = rcp_(E.dt);
+  T xv = (xa - xy_bx) * idt, yv = (ya - xy_by) * idt;
+  V3<T> cap[6], l, r;
+  caps_of(P, lag, cap);
+  left_right(cap, l, r);
+  T psi_s = atan2_(-(l.x - r.x), l.y - r.y);
+  T psi = psi_s;
+  if (E.env_kind == TGR_ENV_TENSEGRITY && E.action == TGR_ACT_TURN) psi = atan2_(r.y - l.y, r.x - l.x);
+  T cc = T(0);
+  if (E.env_kind == TGR_ENV_TENSEGRITY) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) cc += action[i] * action[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; i++) { T v = action[i] + T(0.5) - lag.tenL[i]; cc += v * v; }
+  }
+  cc *= E.ctrl_cost_weight;
+  bool finite = true;
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    finite = finite && isfinite(S.x[b].x + S.x[b].y + S.x[b].z + S.q[b][0] + S.q[b][1] + S.q[b][2] + S.q[b][3]);
+    finite = finite && isfinite(S.v[b].x + S.v[b].y + S.v[b].z + wb[b].x + wb[b].y + wb[b].z);
+  }
+  bool healthy;
+  if (E.action == TGR_ACT_TURN) {
+    bool any = false;
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+      any = any || abs_(S.v[b].x) > T(0.1) || abs_(S.v[b].y) > T(0.1) || abs_(S.v[b].z) > T(0.1) || abs_(wb[b].x) > T(0.1) ||
+            abs_(wb[b].y) > T(0.1) || abs_(wb[b].z) > T(0.1);
+    healthy = finite && any;
+  } else {
+    T mv = T(0.0001);
+    healthy = finite && ((xv > mv || xv < -mv) || (yv > mv || yv < -mv));
+  }
+  T fwd = T(0), ctrl_cost = T(0);
+  if (E.action == TGR_ACT_TURN) {
+    ring_push(ring, psi);
+    if (ring.len > E.reward_delay_steps) {
+      T old = ring_pop(ring);
+      T hp = T(PI / 2);
+      if (psi < -hp && old > hp) psi = T(2 * PI) + psi;
+      else if (psi > hp && old < -hp) psi = T(-2 * PI) + psi;
+      T delta = (psi - old) * rcp_(E.dt * T(E.reward_delay_steps));
+      fwd = delta * E.direction;
+      ctrl_cost = cc;
+    }
+  } else {
+    T dx = xa - xy_bx, dy = ya - xy_by;
+    T pm = atan2_(dy, dx);
+    T pd = abs_(pm - reset_psi);
+    fwd = E.direction * (sqrt_(dx * dx + dy * dy) * cos_(pd) * idt);
+    ctrl_cost = cc;
+  }
+  T hr = E.terminate_when_unhealthy ? ((healthy || E.terminate_when_unhealthy) ? E.healthy_reward : T(0)) : T(0);
+  bool term = E.terminate_when_unhealthy ? !healthy : false;
+  if (lag.cfrc_absmax > T(1500)) term = true;
+  if (!finite) term = true;  // a non-finite lane never survives the step
+  T costs = ctrl_cost;
+  o.info[TGR_INFO_REWARD_FORWARD] = fwd;
+  o.info[TGR_INFO_REWARD_CTRL] = -ctrl_cost;
+  o.info[TGR_INFO_REWARD_SURVIVE] = hr;
+  o.info[TGR_INFO_X_POSITION] = xa;
+  o.info[TGR_INFO_Y_POSITION] = ya;
+  o.info[TGR_INFO_PSI] = psi;
+  o.info[TGR_INFO_DISTANCE] = sqrt_(xa * xa + ya * ya);
+  o.info[TGR_INFO_X_VELOCITY] = xv;
+  o.info[TGR_INFO_Y_VELOCITY] = yv;
+  o.info[TGR_INFO_FORWARD_REWARD] = fwd;
+  o.reward = fwd + hr - costs;
+  o.terminated = term;
+  o.psi_straight = psi_s;
+  o.xy[0] = xa; o.xy[1] = ya;
+  return o;
+}
+
+// ------------------------------------------------------------------ step kernel
+template <typename T> __global__ __launch_bounds__(64) void step_kernel(KArgs<T> k) {
+  __shared__ T lds[LDS_SLOTS * 64];
+  const int lane = threadIdx.x;
+  const int gid = blockIdx.x * 64 + lane;
+  const bool valid = gid < k.n;
+  const int e = valid ? gid : k.n - 1;
+  const int n = k.n;
+  const Params<T>& P = k.P;
+  const EnvCfg<T>& E = k.E;
+
+  Sim<T> S;
+  load_sim(k.st, n, e, S);
+  T action[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) action[i] = T(k.actions[e * 6 + i]);
+  if (E.env_kind == TGR_ENV_TR) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) S.ctrl[i] = S.ctrl[i] + (action[i] - S.ctrl[i]) * E.dt;  // _action_filter, k_FILTER = 1
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; i++) S.ctrl[i] = action[i];
+  }
+  T xy_bx = k.st[(F_XYLAG + 0) * n + e], xy_by = k.st[(F_XYLAG + 1) * n + e];
+  T reset_psi = k.st[F_RESETPSI * n + e];
+  T ep_ret = k.st[F_EPRET * n + e];
+  int step_num = k.ist[I_STEPNUM * n + e], elapsed = k.ist[I_ELAPSED * n + e];
+  RingRef<T> ring; ring.ring = k.ring; ring.n = n; ring.e = e;
+  ring.len = k.ist[I_RINGLEN * n + e]; ring.head = k.ist[I_RINGHEAD * n + e];
+
+  Lag<T> lag;
+  lag.cfrc_absmax = T(0); lag.overflow = 0;
+#pragma unroll 1
+  for (int s = 0; s < E.frame_skip; s++) substep(P, S, lds, lane, s == E.frame_skip - 1, lag);
+
+  V3<T> wb[3];
+  if (valid) store_sim(k.st, n, e, S, lag, wb);
+  else {
+#pragma unroll
+    for (int b = 0; b < 3; b++) wb[b] = mk(T(0), T(0), T(0));
+  }
+  StepOut<T> out = env_epilogue(P, E, S, lag, wb, action, xy_bx, xy_by, reset_psi, ring);
+  if (E.env_kind == TGR_ENV_TR) step_num += 1;
+  elapsed += 1;
+  bool truncated = elapsed >= E.max_episode_steps;
+  ep_ret += out.reward;
+  bool done = out.terminated || truncated;
+
+  T ob[48];
+  make_obs(P, E, S, lag, wb, ob);
+  const int D = E.obs_dim;
+  if (valid) {
+    k.st[(F_XYLAG + 0) * n + e] = out.xy[0]; k.st[(F_XYLAG + 1) * n + e] = out.xy[1];
+    k.st[F_PSILAG * n + e] = out.psi_straight;
+    k.st[F_EPRET * n + e] = ep_ret;
+    k.ist[I_STEPNUM * n + e] = step_num; k.ist[I_ELAPSED * n + e] = elapsed;
+    k.ist[I_RINGLEN * n + e] = ring.len; k.ist[I_RINGHEAD * n + e] = ring.head;
+    k.reward[e] = out.reward;
+    k.terminated[e] = out.terminated ? 1 : 0;
+    k.truncated[e] = truncated ? 1 : 0;
+    if (k.info) {
+      T* ip = k.info + (size_t)e * TGR_INFO_K;
+#pragma unroll
+      for (int i = 0; i < 10; i++) ip[i] = out.info[i];
+      ip[TGR_INFO_WAYPT_X] = k.st[(F_WAYPT + 0) * n + e]; ip[TGR_INFO_WAYPT_Y] = k.st[(F_WAYPT + 1) * n + e];
+      ip[TGR_INFO_ORI_X] = k.st[(F_ORI + 0) * n + e]; ip[TGR_INFO_ORI_Y] = k.st[(F_ORI + 1) * n + e];
+      ip[TGR_INFO_EP_RETURN] = ep_ret; ip[TGR_INFO_EP_LENGTH] = T(elapsed);
+    }
+    if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
+    if (done && k.terminal_obs) {
+      T* tp = k.terminal_obs + (size_t)e * D;
+      for (int i = 0; i < D; i++) tp[i] = ob[i];
+    }
+    if (done && k.auto_reset) {
+      int slot = atomicAdd(k.list_count, 1);
+      k.list[slot] = e;
+    }
+  }
+  // observations: transpose through LDS so the [N][D] buffer is written with coalesced stores
+  __syncthreads();
+  {
+    const int Dp = (D & 1) ? D : D + 1;  // odd row pitch: conflict-free
+#pragma unroll
+    for (int i = 0; i < 48; i++)
+      if (i < D) lds[lane * Dp + i] = ob[i];
+    __syncthreads();
+    const int base = blockIdx.x * 64;
+    const int rows = min(64, n - base);
+    for (int f = lane; f < rows * D; f += 64) {
+      int r = f / D, c = f - r * D;
+      k.obs[(size_t)base * D + f] = lds[r * Dp + c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ settle kernel: reset_model()
+// one lane per entry of list[]; reproduces tensegrity_env.py:433-512 / tr_env.py:709-872:
+// yaw-randomised start pose, random tendon targets, 50 control periods of settling.
+template <typename T> __global__ __launch_bounds__(64) void settle_kernel(KArgs<T> k) {
+  __shared__ T lds[LDS_SLOTS * 64];
+  const int lane = threadIdx.x;
+  const int count = *k.list_count;
+  if (blockIdx.x * 64 >= count) return;
+  const int li = blockIdx.x * 64 + lane;
+  const bool valid = li < count;
+  const int e = k.list[valid ? li : count - 1];
+  const int n = k.n;
+  const Params<T>& P = k.P;
+  const EnvCfg<T>& E = k.E;
+
+  unsigned long long episode = (unsigned long long)(unsigned)k.ist[I_EPISODE * n + e];
+  Draws dr = reset_draws(E, E.first_env_id + (unsigned long long)e, episode);
+  Sim<T> S;
+  {
+    double c = cos(dr.theta), s = sin(dr.theta), ch = cos(0.5 * dr.theta), sh = sin(0.5 * dr.theta);
+    const double* q0 = E.env_kind == TGR_ENV_TR ? c_rolling[dr.pose] : c_qpos0;
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      const double* q = q0 + 7 * b;
+      S.x[b] = mk(T(c * q[0] - s * q[1]), T(s * q[0] + c * q[1]), T(q[2]));
+      double w = q[3], x = q[4], y = q[5], z = q[6];
+      S.q[b][0] = T(ch * w - sh * z); S.q[b][1] = T(ch * x - sh * y); S.q[b][2] = T(ch * y + sh * x); S.q[b][3] = T(ch * z + sh * w);
+      S.v[b] = mk(T(0), T(0), T(0)); S.w[b] = S.v[b]; S.al[b] = S.v[b]; S.aa[b] = S.v[b];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) S.ctrl[i] = T(dr.tendons[i]);
+  }
+  RingRef<T> ring; ring.ring = k.ring; ring.n = n; ring.e = e;
+  ring.len = k.ist[I_RINGLEN * n + e]; ring.head = k.ist[I_RINGHEAD * n + e];
+  int step_num = 0;
+  const bool turn = E.action == TGR_ACT_TURN;
+  // tr_env turn: reward_delay_steps extra full env steps after the settle (tr_env.py:864-866)
+  const int extra = (E.env_kind == TGR_ENV_TR && turn) ? E.reward_delay_steps : 0;
+  Lag<T> lag;
+  lag.cfrc_absmax = T(0); lag.overflow = 0;
+  T reset_psi = T(0);
+#pragma unroll 1
+  for (int st = 0; st < 50 + extra; st++) {
+#pragma unroll 1
+    for (int s = 0; s < E.frame_skip; s++) substep(P, S, lds, lane, s == E.frame_skip - 1, lag);
+    V3<T> cap[6], l, r;
+    caps_of(P, lag, cap);
+    left_right(cap, l, r);
+    if (st == 49) reset_psi = atan2_(-(l.x - r.x), l.y - r.y);
+    bool env_step = (E.env_kind == TGR_ENV_TENSEGRITY) || st >= 50;  // settling through self.step() vs do_simulation()
+    if (env_step && turn && valid) {
+      T psi = E.env_kind == TGR_ENV_TENSEGRITY ? atan2_(r.y - l.y, r.x - l.x) : atan2_(-(l.x - r.x), l.y - r.y);
+      ring_push(ring, psi);
+      if (ring.len > E.reward_delay_steps) (void)ring_pop(ring);
+    }
+    if (st >= 50) step_num += 1;
+  }
+  V3<T> wb[3];
+  if (!valid) return;
+  store_sim(k.st, n, e, S, lag, wb);
+  T third = T(1.0 / 3.0);
+  k.st[(F_XYLAG + 0) * n + e] = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x);
+  k.st[(F_XYLAG + 1) * n + e] = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
+  {
+    V3<T> cap[6], l, r;
+    caps_of(P, lag, cap);
+    left_right(cap, l, r);
+    k.st[F_PSILAG * n + e] = atan2_(-(l.x - r.x), l.y - r.y);
+  }
+  k.st[F_RESETPSI * n + e] = reset_psi;
+  k.st[F_EPRET * n + e] = T(0);
+  k.ist[I_STEPNUM * n + e] = step_num;
+  k.ist[I_ELAPSED * n + e] = 0;
+  k.ist[I_RINGLEN * n + e] = ring.len; k.ist[I_RINGHEAD * n + e] = ring.head;
+  k.ist[I_EPISODE * n + e] = (int)(episode + 1);
+  atomicAdd(&k.counters[1], 1ull);
+  if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
+  if (k.obs_reset) {
+    T ob[48];
+    make_obs(P, E, S, lag, wb, ob);
+    T* op = k.obs_reset + (size_t)e * E.obs_dim;
+    for (int i = 0; i < E.obs_dim; i++) op[i] = ob[i];
+  }
+}
+
+// set_state: recompute the derived (lagged) fields from qpos the way mj_forward would
+template <typename T> __global__ void refresh_lag_kernel(KArgs<T> k) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= k.n) return;
+  const int n = k.n;
+  Sim<T> S;
+  load_sim(k.st, n, e, S);
+  Lag<T> lag;
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    lag.x[b] = S.x[b];
+    lag.z[b] = quat_rot(S.q[b]).ez;
+  }
+  T third = T(1.0 / 3.0);
+  k.st[(F_XYLAG + 0) * n + e] = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x);
+  k.st[(F_XYLAG + 1) * n + e] = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
+  V3<T> cap[6], l, r;
+  caps_of(k.P, lag, cap);
+  left_right(cap, l, r);
+  k.st[F_PSILAG * n + e] = atan2_(-(l.x - r.x), l.y - r.y);
+}
+
+}  // namespace tgr
+
+// =================================================================== host side / C-ABI
+using namespace tgr;
+
+struct tgr_handle {
+  tgr_config cfg;
+  int n = 0, device = 0, obs_dim = 0;
+  void* st = nullptr;   // T[NF][n]
+  int* ist = nullptr;   // int[NI][n]
+  void* ring = nullptr; // T[RING][n]
+  int* list_count = nullptr;
+  int* list = nullptr;
+  unsigned long long* counters = nullptr;
+  std::string err;
+};
+
+static thread_local std::string g_err;
+
+#define HIP_TRY(h, expr)                                                                         \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                              \
+      return TGR_ERR_HIP;                                                                        \
+    }                                                                                            \
+  } while (0)
+
+extern "C" const char* tgr_version(void) { return "tensegrity-mi355x 0.1 (gfx950)"; }
+
+extern "C" int tgr_default_config(tgr_config* c, int env_kind, int desired_action) {
+  if (!c) return TGR_ERR_INVALID;
+  std::memset(c, 0, sizeof(*c));
+  c->env_kind = env_kind;
+  c->desired_action = desired_action;
+  c->desired_direction = 1;
+  c->terminate_when_unhealthy = 1;
+  c->use_contact_forces = 0;
+  c->use_cap_velocity = 1;
+  c->is_test = 0;
+  c->contact_cost_weight = 5e-4;
+  c->healthy_reward = 0.1;
+  c->contact_force_lo = -1.0; c->contact_force_hi = 1.0;
+  if (desired_action == TGR_ACT_TURN) { c->contact_force_lo = -1000.0; c->contact_force_hi = 1000.0; }
+  c->min_reset_heading = 0.0; c->max_reset_heading = 2 * PI;
+  c->tendon_min_length = -0.45;
+  c->frame_skip = 20;
+  c->max_episode_steps = 5000;
+  c->timestep = 0.001;
+  double dt = c->timestep * c->frame_skip;
+  if (env_kind == TGR_ENV_TENSEGRITY) {  // tensegrity_env.py:160-181
+    c->ctrl_cost_weight = 0.001;
+    c->tendon_reset_mean = -0.15; c->tendon_reset_stdev = 0.1; c->tendon_max_length = -0.15;
+    c->reward_delay_steps = (int)(0.5 / dt);
+  } else {  // tr_env.py:137-173
+    c->ctrl_cost_weight = 0.01;
+    c->tendon_reset_mean = 0.15; c->tendon_reset_stdev = 0.2; c->tendon_max_length = 0.15;
+    c->reward_delay_steps = (int)(0.02 / dt);
+  }
+  c->gravity = 9.81;
+  c->cap_radius = 0.0675;
+  c->solref[0] = -5000; c->solref[1] = -500;
+  c->solimp[0] = 0.9; c->solimp[1] = 0.95; c->solimp[2] = 0.001; c->solimp[3] = 0.5; c->solimp[4] = 2;
+  c->friction[0] = 1; c->friction[1] = 0.005; c->friction[2] = 0.0001;
+  c->impratio = 1;
+  c->gain = 6667; c->bias[0] = 3290; c->bias[1] = -6666; c->bias[2] = -133;
+  c->force_range[0] = -267; c->force_range[1] = 0;
+  c->ctrl_range[0] = -0.45; c->ctrl_range[1] = 0.15;
+  for (int t = 0; t < 9; t++) {
+    c->ten_stiffness[t] = t >= 6 ? 700.0 : 0.0;
+    c->ten_damping[t] = t >= 6 ? 100.0 : 0.0;
+    c->ten_springlength[t] = 0.8;
+  }
+  c->actuator_deriv_skip_clamped = 0;
+  c->precision = TGR_PRECISION_F32;
+  c->auto_reset = 1;
+  c->async_reset = 0;
+  c->seed = 1234;
+  c->first_env_id = 0;
+  c->solver_tolerance = 0;
+  c->solver_iterations = 0;
+  return TGR_OK;
+}
+
+static int obs_dim_of(const tgr_config& c) {
+  if (c.env_kind == TGR_ENV_TENSEGRITY) return 39;
+  int d = 27;
+  if (c.use_cap_velocity) d += 18;
+  if (c.desired_action == TGR_ACT_TRACKING || c.desired_action == TGR_ACT_AIMING || c.desired_action == TGR_ACT_VEL_TRACK) d += 3;
+  return d;
+}
+
+template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
+  const tgr_config& c = h->cfg;
+  Params<T>& P = k.P;
+  P.h = T(c.timestep); P.grav = T(c.gravity);
+  // inertiafromgeom with explicit geom masses (xml:72-78): cylinder 1.0, two spheres 0.5, two cylinders 1.0
+  const double half = 0.688, rr = 0.0381, rs = 0.0675, rb = 0.035, blo = 0.238, bhi = 0.688;
+  double L = 2 * half;
+  double Ixx = 1.0 * (3 * rr * rr + L * L) / 12.0, Izz = 1.0 * rr * rr / 2.0;
+  double Is = 0.4 * 0.5 * rs * rs;
+  Ixx += 2 * (Is + 0.5 * half * half); Izz += 2 * Is;
+  double Lb = bhi - blo, cb = 0.5 * (bhi + blo);
+  Ixx += 2 * (1.0 * (3 * rb * rb + Lb * Lb) / 12.0 + 1.0 * cb * cb); Izz += 2 * (1.0 * rb * rb / 2.0);
+  P.mass = T(4.0); P.Ixx = T(Ixx); P.Izz = T(Izz);
+  P.cap_r = T(c.cap_radius); P.bar_half = T(half); P.rcyl_r = T(rr); P.bcyl_r = T(rb); P.bcyl_lo = T(blo); P.bcyl_hi = T(bhi);
+  P.site_off = T(0.0675); P.site_z = T(0.668);
+  for (int t = 0; t < 9; t++) { P.ten_k[t] = T(c.ten_stiffness[t]); P.ten_b[t] = T(c.ten_damping[t]); P.ten_L0[t] = T(c.ten_springlength[t]); }
+  P.gain = T(c.gain); P.bias0 = T(c.bias[0]); P.bias1 = T(c.bias[1]); P.bias2 = T(c.bias[2]);
+  P.force_lo = T(c.force_range[0]); P.force_hi = T(c.force_range[1]); P.ctrl_lo = T(c.ctrl_range[0]); P.ctrl_hi = T(c.ctrl_range[1]);
+  double dmax = c.solimp[1];
+  P.K = T(-c.solref[0] / (dmax * dmax)); P.B = T(-c.solref[1] / dmax);  // direct (negative) solref
+  P.imp0 = T(c.solimp[0]); P.imp1 = T(c.solimp[1]); P.imp_width = T(c.solimp[2]); P.imp_mid = T(c.solimp[3]);
+  P.f0 = T(c.friction[0]); P.f1sq = T(c.friction[0] * c.friction[0]); P.f3sq = T(c.friction[1] * c.friction[1]);
+  P.f4sq = T(c.friction[2] * c.friction[2]); P.impratio = T(c.impratio);
+  P.invweight = T(0.25);
+  double tol = c.solver_tolerance > 0 ? c.solver_tolerance : (sizeof(T) == 4 ? 1e-6 : 1e-11);
+  P.tol = T(tol); P.ls_tol = T(0.01);
+  P.max_iter = c.solver_iterations > 0 ? c.solver_iterations : (sizeof(T) == 4 ? 12 : 40);
+  P.ls_iter = sizeof(T) == 4 ? 12 : 50;
+  P.skip_clamped = c.actuator_deriv_skip_clamped;
+  EnvCfg<T>& E = k.E;
+  E.env_kind = c.env_kind; E.action = c.desired_action; E.terminate_when_unhealthy = c.terminate_when_unhealthy;
+  E.use_contact_forces = c.use_contact_forces; E.use_cap_velocity = c.use_cap_velocity; E.is_test = c.is_test;
+  E.reward_delay_steps = c.reward_delay_steps; E.frame_skip = c.frame_skip; E.max_episode_steps = c.max_episode_steps;
+  E.obs_dim = h->obs_dim;
+  E.direction = T(c.desired_direction); E.ctrl_cost_weight = T(c.ctrl_cost_weight); E.contact_cost_weight = T(c.contact_cost_weight);
+  E.healthy_reward = T(c.healthy_reward); E.contact_lo = T(c.contact_force_lo); E.contact_hi = T(c.contact_force_hi);
+  E.dt = T(c.timestep * c.frame_skip);
+  E.min_heading = c.min_reset_heading; E.max_heading = c.max_reset_heading;
+  E.ten_mean = c.tendon_reset_mean; E.ten_std = c.tendon_reset_stdev; E.ten_max = c.tendon_max_length; E.ten_min = c.tendon_min_length;
+  E.seed = c.seed; E.first_env_id = c.first_env_id;
+  k.n = h->n;
+  k.st = (T*)h->st; k.ist = h->ist; k.ring = (T*)h->ring;
+  k.list_count = h->list_count; k.list = h->list; k.counters = h->counters;
+  k.auto_reset = c.auto_reset;
+  k.actions = nullptr; k.obs = nullptr; k.reward = nullptr; k.terminated = nullptr; k.truncated = nullptr;
+  k.terminal_obs = nullptr; k.info = nullptr; k.obs_reset = nullptr;
+}
+
+extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_handle** out) {
+  if (!cfg || !out || n_envs <= 0) { g_err = "tgr_create: bad arguments"; return TGR_ERR_INVALID; }
+  if (cfg->desired_action != TGR_ACT_STRAIGHT && cfg->desired_action != TGR_ACT_TURN) {
+    g_err = "tgr_create: desired_action must be straight or turn (aiming/tracking/vel_track: not built yet)";
+    return TGR_ERR_UNSUPPORTED;
+  }
+  if (cfg->use_contact_forces) { g_err = "tgr_create: use_contact_forces not built yet"; return TGR_ERR_UNSUPPORTED; }
+  if (cfg->solimp[4] != 2.0 || cfg->solref[0] >= 0) { g_err = "tgr_create: only direct solref and power-2 solimp"; return TGR_ERR_UNSUPPORTED; }
+  if (cfg->reward_delay_steps >= RING - 1 || cfg->reward_delay_steps < 0) { g_err = "tgr_create: reward_delay_steps too large"; return TGR_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "tgr_create: no HIP device (the HIP path is required; there is no CPU fallback)"; return TGR_ERR_HIP; }
+  if (device < 0 || device >= ndev) { g_err = "tgr_create: bad device index"; return TGR_ERR_INVALID; }
+  tgr_handle* h = new (std::nothrow) tgr_handle();
+  if (!h) return TGR_ERR_INVALID;
+  h->cfg = *cfg; h->n = n_envs; h->device = device; h->obs_dim = obs_dim_of(*cfg);
+  *out = h;
+  HIP_TRY(h, hipSetDevice(device));
+  size_t ts = cfg->precision == TGR_PRECISION_F64 ? 8 : 4;
+  HIP_TRY(h, hipMalloc(&h->st, ts * NF * (size_t)n_envs));
+  HIP_TRY(h, hipMemset(h->st, 0, ts * NF * (size_t)n_envs));
+  HIP_TRY(h, hipMalloc((void**)&h->ist, sizeof(int) * NI * (size_t)n_envs));
+  HIP_TRY(h, hipMemset(h->ist, 0, sizeof(int) * NI * (size_t)n_envs));
+  HIP_TRY(h, hipMalloc(&h->ring, ts * RING * (size_t)n_envs));
+  HIP_TRY(h, hipMemset(h->ring, 0, ts * RING * (size_t)n_envs));
+  HIP_TRY(h, hipMalloc((void**)&h->list_count, sizeof(int)));
+  HIP_TRY(h, hipMalloc((void**)&h->list, sizeof(int) * (size_t)n_envs));
+  HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 4));
+  HIP_TRY(h, hipMemset(h->counters, 0, sizeof(unsigned long long) * 4));
+  return TGR_OK;
+}
+
+extern "C" int tgr_destroy(tgr_handle* h) {
+  if (!h) return TGR_OK;
+  hipSetDevice(h->device);
+  hipDeviceSynchronize();
+  hipFree(h->st); hipFree(h->ist); hipFree(h->ring); hipFree(h->list_count); hipFree(h->list); hipFree(h->counters);
+  delete h;
+  return TGR_OK;
+}
+extern "C" int tgr_num_envs(const tgr_handle* h) { return h ? h->n : 0; }
+extern "C" int tgr_obs_dim(const tgr_handle* h) { return h ? h->obs_dim : 0; }
+extern "C" int tgr_precision(const tgr_handle* h) { return h ? h->cfg.precision : 0; }
+extern "C" const char* tgr_last_error(const tgr_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+extern "C" int tgr_synchronize(tgr_handle* h) {
+  if (!h) return TGR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipDeviceSynchronize());
+  return TGR_OK;
+}
+extern "C" int tgr_set_seed(tgr_handle* h, uint64_t seed) {
+  if (!h) return TGR_ERR_INVALID;
+  h->cfg.seed = seed;
+  return TGR_OK;
+}
+extern "C" int tgr_stats(tgr_handle* h, uint64_t out[4]) {
+  if (!h || !out) return TGR_ERR_INVALID;
+  unsigned long long tmp[4];
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemcpy(tmp, h->counters, sizeof(tmp), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 4; i++) out[i] = tmp[i];
+  return TGR_OK;
+}
+
+template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, void* obs, hipStream_t s) {
+  std::vector<int> idx;
+  idx.reserve(h->n);
+  for (int i = 0; i < h->n; i++)
+    if (!mask || mask[i]) idx.push_back(i);
+  int cnt = (int)idx.size();
+  if (cnt == 0) return TGR_OK;
+  HIP_TRY(h, hipMemcpyAsync(h->list, idx.data(), sizeof(int) * cnt, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(h->list_count, &cnt, sizeof(int), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipStreamSynchronize(s));  // idx / cnt are stack/heap temporaries
+  KArgs<T> k;
+  fill_args<T>(h, k);
+  k.obs_reset = (T*)obs;
+  int blocks = (cnt + 63) / 64;
+  hipLaunchKernelGGL(settle_kernel<T>, dim3(blocks), dim3(64), 0, s, k);
+  HIP_TRY(h, hipGetLastError());
+  return TGR_OK;
+}
+
+extern "C" int tgr_reset(tgr_handle* h, const uint8_t* mask_host, void* obs_dev, void* hip_stream) {
+  if (!h) return TGR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  return h->cfg.precision == TGR_PRECISION_F64 ? reset_impl<double>(h, mask_host, obs_dev, s) : reset_impl<float>(h, mask_host, obs_dev, s);
+}
+
+template <typename T>
+static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uint8_t* terminated, uint8_t* truncated,
+                     T* terminal_obs, T* info, hipStream_t s) {
+  if (!actions || !obs || !reward || !terminated || !truncated) { h->err = "tgr_step: null buffer"; return TGR_ERR_INVALID; }
+  KArgs<T> k;
+  fill_args<T>(h, k);
+  k.actions = actions; k.obs = obs; k.reward = reward; k.terminated = terminated; k.truncated = truncated;
+  k.terminal_obs = terminal_obs; k.info = info;
+  k.obs_reset = obs;
+  HIP_TRY(h, hipMemsetAsync(h->list_count, 0, sizeof(int), s));
+  int blocks = (h->n + 63) / 64;
+  hipLaunchKernelGGL(step_kernel<T>, dim3(blocks), dim3(64), 0, s, k);
+  HIP_TRY(h, hipGetLastError());
+  if (h->cfg.auto_reset) {
+    hipLaunchKernelGGL(settle_kernel<T>, dim3(blocks), dim3(64), 0, s, k);
+    HIP_TRY(h, hipGetLastError());
+  }
+  return TGR_OK;
+}
+
+extern "C" int tgr_step(tgr_handle* h, const float* actions, float* obs, float* reward, uint8_t* terminated,
+                        uint8_t* truncated, float* terminal_obs, float* info, void* hip_stream) {
+  if (!h) return TGR_ERR_INVALID;
+  if (h->cfg.precision != TGR_PRECISION_F32) { h->err = "tgr_step: handle is fp64, use tgr_step_f64"; return TGR_ERR_INVALID; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  return step_impl<float>(h, actions, obs, reward, terminated, truncated, terminal_obs, info, (hipStream_t)hip_stream);
+}
+extern "C" int tgr_step_f64(tgr_handle* h, const float* actions, double* obs, double* reward, uint8_t* terminated,
+                            uint8_t* truncated, double* terminal_obs, double* info, void* hip_stream) {
+  if (!h) return TGR_ERR_INVALID;
+  if (h->cfg.precision != TGR_PRECISION_F64) { h->err = "tgr_step_f64: handle is fp32, use tgr_step"; return TGR_ERR_INVALID; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  return step_impl<double>(h, actions, obs, reward, terminated, truncated, terminal_obs, info, (hipStream_t)hip_stream);
+}
+
+// ---- state exchange (host arrays, double)
+template <typename T> static int get_state_impl(tgr_handle* h, double* qpos, double* qvel, double* ctrl, double* warm, double* aux) {
+  size_t n = h->n;
+  std::vector<T> st(NF * n);
+  std::vector<int> ist(NI * n);
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemcpy(st.data(), h->st, sizeof(T) * NF * n, hipMemcpyDeviceToHost));
+  HIP_TRY(h, hipMemcpy(ist.data(), h->ist, sizeof(int) * NI * n, hipMemcpyDeviceToHost));
+  for (size_t e = 0; e < n; e++) {
+    if (qpos) for (int i = 0; i < 21; i++) qpos[e * 21 + i] = (double)st[(F_QPOS + i) * n + e];
+    if (qvel) for (int i = 0; i < 18; i++) qvel[e * 18 + i] = (double)st[(F_QVEL + i) * n + e];
+    if (ctrl) for (int i = 0; i < 6; i++) ctrl[e * 6 + i] = (double)st[(F_CTRL + i) * n + e];
+    if (warm) for (int i = 0; i < 18; i++) warm[e * 18 + i] = (double)st[(F_WARM + i) * n + e];
+    if (aux) {
+      double* a = aux + e * TGR_AUX_K;
+      a[TGR_AUX_XY_LAG_X] = (double)st[(F_XYLAG + 0) * n + e]; a[TGR_AUX_XY_LAG_Y] = (double)st[(F_XYLAG + 1) * n + e];
+      a[TGR_AUX_PSI_LAG] = (double)st[F_PSILAG * n + e]; a[TGR_AUX_RESET_PSI] = (double)st[F_RESETPSI * n + e];
+      a[TGR_AUX_EP_RETURN] = (double)st[F_EPRET * n + e];
+      a[TGR_AUX_STEP_NUM] = ist[I_STEPNUM * n + e]; a[TGR_AUX_ELAPSED] = ist[I_ELAPSED * n + e];
+      a[TGR_AUX_EPISODE] = ist[I_EPISODE * n + e]; a[TGR_AUX_RING_LEN] = ist[I_RINGLEN * n + e];
+      a[TGR_AUX_WAYPT_X] = (double)st[(F_WAYPT + 0) * n + e]; a[TGR_AUX_WAYPT_Y] = (double)st[(F_WAYPT + 1) * n + e];
+      a[TGR_AUX_ORI_X] = (double)st[(F_ORI + 0) * n + e]; a[TGR_AUX_ORI_Y] = (double)st[(F_ORI + 1) * n + e];
+      a[TGR_AUX_VCMD_X] = (double)st[(F_VCMD + 0) * n + e]; a[TGR_AUX_VCMD_Y] = (double)st[(F_VCMD + 1) * n + e];
+      a[TGR_AUX_VCMD_W] = (double)st[(F_VCMD + 2) * n + e];
+    }
+  }
+  return TGR_OK;
+}
+template <typename T>
+static int set_state_impl(tgr_handle* h, const double* qpos, const double* qvel, const double* ctrl, const double* warm, const double* aux) {
+  size_t n = h->n;
+  std::vector<T> st(NF * n);
+  std::vector<int> ist(NI * n);
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemcpy(st.data(), h->st, sizeof(T) * NF * n, hipMemcpyDeviceToHost));
+  HIP_TRY(h, hipMemcpy(ist.data(), h->ist, sizeof(int) * NI * n, hipMemcpyDeviceToHost));
+  for (size_t e = 0; e < n; e++) {
+    if (qpos) for (int i = 0; i < 21; i++) st[(F_QPOS + i) * n + e] = (T)qpos[e * 21 + i];
+    if (qvel) for (int i = 0; i < 18; i++) st[(F_QVEL + i) * n + e] = (T)qvel[e * 18 + i];
+    if (ctrl) for (int i = 0; i < 6; i++) st[(F_CTRL + i) * n + e] = (T)ctrl[e * 6 + i];
+    if (warm) for (int i = 0; i < 18; i++) st[(F_WARM + i) * n + e] = (T)warm[e * 18 + i];
+  }
+  HIP_TRY(h, hipMemcpy(h->st, st.data(), sizeof(T) * NF * n, hipMemcpyHostToDevice));
+  if (qpos) {
+    KArgs<T> k;
+    fill_args<T>(h, k);
+    hipLaunchKernelGGL(refresh_lag_kernel<T>, dim3((h->n + 63) / 64), dim3(64), 0, 0, k);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipDeviceSynchronize());
+  }
+  if (aux) {
+    HIP_TRY(h, hipMemcpy(st.data(), h->st, sizeof(T) * NF * n, hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < n; e++) {
+      const double* a = aux + e * TGR_AUX_K;
+      st[(F_XYLAG + 0) * n + e] = (T)a[TGR_AUX_XY_LAG_X]; st[(F_XYLAG + 1) * n + e] = (T)a[TGR_AUX_XY_LAG_Y];
+      st[F_PSILAG * n + e] = (T)a[TGR_AUX_PSI_LAG]; st[F_RESETPSI * n + e] = (T)a[TGR_AUX_RESET_PSI];
+      st[F_EPRET * n + e] = (T)a[TGR_AUX_EP_RETURN];
+      ist[I_STEPNUM * n + e] = (int)a[TGR_AUX_STEP_NUM]; ist[I_ELAPSED * n + e] = (int)a[TGR_AUX_ELAPSED];
+      ist[I_EPISODE * n + e] = (int)a[TGR_AUX_EPISODE];
+      st[(F_WAYPT + 0) * n + e] = (T)a[TGR_AUX_WAYPT_X]; st[(F_WAYPT + 1) * n + e] = (T)a[TGR_AUX_WAYPT_Y];
+      st[(F_ORI + 0) * n + e] = (T)a[TGR_AUX_ORI_X]; st[(F_ORI + 1) * n + e] = (T)a[TGR_AUX_ORI_Y];
+      st[(F_VCMD + 0) * n + e] = (T)a[TGR_AUX_VCMD_X]; st[(F_VCMD + 1) * n + e] = (T)a[TGR_AUX_VCMD_Y];
+      st[(F_VCMD + 2) * n + e] = (T)a[TGR_AUX_VCMD_W];
+    }
+    HIP_TRY(h, hipMemcpy(h->st, st.data(), sizeof(T) * NF * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->ist, ist.data(), sizeof(int) * NI * n, hipMemcpyHostToDevice));
+  }
+  return TGR_OK;
+}
+
+extern "C" int tgr_get_state(tgr_handle* h, double* qpos, double* qvel, double* ctrl, double* warm, double* aux) {
+  if (!h) return TGR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  return h->cfg.precision == TGR_PRECISION_F64 ? get_state_impl<double>(h, qpos, qvel, ctrl, warm, aux)
+                                                : get_state_impl<float>(h, qpos, qvel, ctrl, warm, aux);
+}
+extern "C" int tgr_set_state(tgr_handle* h, const double* qpos, const double* qvel, const double* ctrl, const double* warm,
+                             const double* aux) {
+  if (!h) return TGR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  return h->cfg.precision == TGR_PRECISION_F64 ? set_state_impl<double>(h, qpos, qvel, ctrl, warm, aux)
+                                                : set_state_impl<float>(h, qpos, qvel, ctrl, warm, aux);
+}

@@ -1,0 +1,102 @@
+"""Single-env Gym API with the reference's class names, constructor kwargs and return conventions
+(tensegrity_env.py:160-181,291-410,433-512; tr_env.py:137-173,327-527,709-872), backed by a
+one-env handle of the HIP simulator."""
+import os
+
+import numpy as np
+
+from . import _native as N
+from .vec_env import TensegrityVecEnv
+
+
+class _GymEnvBase:
+    metadata = {"render_modes": ["human", "rgb_array", "depth_array"], "render_fps": 50}
+    _env_id = None
+    spec = None
+    reward_range = (-float("inf"), float("inf"))
+
+    def __init__(self, xml_file=os.path.join(os.getcwd(), "3prism_jonathan_steady_side.xml"), render_mode=None,
+                 device=0, precision="f32", max_episode_steps=None, seed=1234, **kwargs):
+        # render_mode strings "None"/"human" arrive from run.py:13,412; there is no viewer on a GPU box
+        self.render_mode = None
+        self.xml_file = xml_file
+        self._venv = TensegrityVecEnv(1, self._env_id, device=device, precision=precision, auto_reset=False,
+                                      max_episode_steps=max_episode_steps, seed=seed, info_mode="full", **kwargs)
+        self.observation_space = self._venv.observation_space
+        self.action_space = self._venv.action_space
+        self.frame_skip = self._venv.frame_skip
+        self.dt = self._venv.dt
+        self.np_random = np.random.default_rng(seed)
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def reset(self, *, seed=None, options=None):
+        if seed is not None:
+            self._venv.seed(seed)
+            self.np_random = np.random.default_rng(seed)
+        obs = self._venv.reset()
+        return obs[0], {}
+
+    def step(self, action):
+        a = np.asarray(action, dtype=np.float32)
+        if a.shape != (6,):
+            raise ValueError("Action dimension mismatch")
+        obs, rew, term, trunc, tobs, info = self._venv.step_tensors(a.reshape(1, 6))
+        ih = info.cpu().numpy().astype(np.float64)[0]
+        d = dict(zip(N.INFO_KEYS, ih[:10]))
+        if self._env_id == "tr_env-v0":
+            d["waypt"] = ih[10:12].copy()
+            d["oripoint"] = ih[12:14].copy()
+        return (obs.cpu().numpy().astype(np.float64)[0], float(rew.cpu().numpy()[0]), bool(term.cpu().numpy()[0]),
+                bool(trunc.cpu().numpy()[0]), d)
+
+    def render(self):
+        return None
+
+    def close(self):
+        self._venv.close()
+
+    def get_state(self):
+        return self._venv.get_state()
+
+    def set_state(self, qpos, qvel):
+        self._venv.set_state(qpos=np.asarray(qpos).reshape(1, -1), qvel=np.asarray(qvel).reshape(1, -1))
+
+
+class tensegrity_env(_GymEnvBase):  # noqa: N801  (reference class name)
+    _env_id = "tensegrity_env-v0"
+
+
+class tr_env(_GymEnvBase):  # noqa: N801
+    _env_id = "tr_env-v0"
+
+
+REGISTRY = {"tensegrity_env-v0": tensegrity_env, "tr_env-v0": tr_env}
+
+
+def make(env_id, **kwargs):
+    """gym.make() for the two registered ids, including the registration's TimeLimit(5000)
+    (tensegrity_env/__init__.py:3-7, tr_env/__init__.py:3-7)."""
+    if env_id not in REGISTRY:
+        raise KeyError(env_id)
+    kwargs.setdefault("max_episode_steps", 5000)
+    return REGISTRY[env_id](**kwargs)
+
+
+def register_with_gym():
+    """Register both ids with gymnasium / gym when one of them is importable."""
+    done = []
+    for mod in ("gymnasium", "gym"):
+        try:
+            g = __import__(mod)
+        except Exception:
+            continue
+        for eid, cls in REGISTRY.items():
+            try:
+                g.register(id=eid, entry_point=f"tensegrity_rl_amd.envs:{cls.__name__}", max_episode_steps=5000)
+                done.append((mod, eid))
+            except Exception:
+                pass
+    return done

@@ -1,0 +1,251 @@
+"""TensegrityVecEnv: N environments behind the Stable-Baselines3 VecEnv surface, stepped by the HIP
+kernels through the C-ABI (include/tensegrity.h).
+
+Mirrors what SB3 builds around the reference env (run.py:41-85 -> DummyVecEnv(Monitor(env))):
+auto-reset with infos[i]["terminal_observation"], "TimeLimit.truncated" and Monitor's
+info["episode"] = {"r","l","t"}.  PyTorch is only plumbing here: device buffers + the current stream.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _native as N
+from .spaces import Box
+
+ENV_IDS = {"tensegrity_env-v0": N.ENV_TENSEGRITY, "tr_env-v0": N.ENV_TR, "tensegrity_env": N.ENV_TENSEGRITY, "tr_env": N.ENV_TR}
+
+# constructor kwargs of the reference classes that map 1:1 onto tgr_config fields
+_DIRECT = ["use_contact_forces", "use_cap_velocity", "terminate_when_unhealthy", "is_test", "desired_direction",
+           "ctrl_cost_weight", "contact_cost_weight", "healthy_reward", "min_reset_heading", "max_reset_heading",
+           "tendon_reset_mean", "tendon_reset_stdev", "tendon_max_length", "tendon_min_length"]
+# accepted for signature compatibility, no effect on the built path (reference defaults)
+_IGNORED = ["xml_file", "render_mode", "reset_noise_scale", "contact_with_self_penalty", "use_obs_noise",
+            "use_cap_size_noise", "obs_noise_tendon_stdev", "obs_noise_cap_pos_stdev", "cap_size_noise_range", "way_pts_range",
+            "way_pts_angle_range", "threshold_waypt", "ditch_reward_max", "ditch_reward_stdev", "waypt_reward_amplitude",
+            "waypt_reward_stdev", "yaw_reward_weight", "width", "height", "camera_id", "camera_name"]
+
+
+def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision="f32", auto_reset=True, seed=1234,
+                first_env_id=0, max_episode_steps=5000, **kwargs):
+    """tgr_config from the reference's constructor kwargs (tensegrity_env.py:160-181, tr_env.py:137-173)."""
+    if env_id not in ENV_IDS:
+        raise ValueError(f"unknown env id {env_id!r}")
+    kind = ENV_IDS[env_id]
+    if desired_action not in N.ACTIONS:
+        raise ValueError(f"unknown desired_action {desired_action!r}")
+    cfg = N.default_config(kind, desired_action)
+    for k in list(kwargs):
+        if k in _DIRECT:
+            setattr(cfg, k, type(getattr(cfg, k))(kwargs.pop(k)))
+        elif k in _IGNORED:
+            v = kwargs.pop(k)
+            if k in ("use_obs_noise", "use_cap_size_noise") and v:
+                raise NotImplementedError(f"{k}=True is not built yet (SURVEY.md 8f)")
+            if k == "reset_noise_scale" and v:
+                raise NotImplementedError("reset_noise_scale != 0 is not built")
+    if "contact_force_range" in kwargs:
+        lo, hi = kwargs.pop("contact_force_range")
+        cfg.contact_force_lo, cfg.contact_force_hi = float(lo), float(hi)
+        if desired_action == "turn":  # tensegrity_env.py:224-225
+            cfg.contact_force_lo, cfg.contact_force_hi = -1000.0, 1000.0
+    if "reward_delay_seconds" in kwargs:
+        cfg.reward_delay_steps = int(kwargs.pop("reward_delay_seconds") / (cfg.timestep * cfg.frame_skip))
+    for k in ("actuator_deriv_skip_clamped", "solver_tolerance", "solver_iterations", "async_reset"):
+        if k in kwargs:
+            setattr(cfg, k, type(getattr(cfg, k))(kwargs.pop(k)))
+    if kwargs:
+        raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
+    cfg.precision = N.PRECISION[precision]
+    cfg.auto_reset = int(bool(auto_reset))
+    cfg.seed = int(seed)
+    cfg.first_env_id = int(first_env_id)
+    cfg.max_episode_steps = int(max_episode_steps) if max_episode_steps else 2 ** 31 - 1
+    return cfg
+
+
+class TensegrityVecEnv:
+    """SB3 VecEnv duck type.  Not a subclass so that stable_baselines3 is optional; `to_sb3()` wraps it in a real
+    VecEnv subclass when SB3 is importable."""
+
+    metadata = {"render_modes": ["human", "rgb_array", "depth_array"], "render_fps": 50}
+
+    def __init__(self, num_envs, env_id="tensegrity_env-v0", device=0, info_mode="minimal", **kwargs):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("TensegrityVecEnv needs a HIP device (MI355X); there is no CPU fallback")
+        self.torch = torch
+        self.lib = N.load()
+        self.num_envs = int(num_envs)
+        self.env_id = env_id
+        self.cfg = make_config(env_id, **kwargs)
+        self.device_index = int(device)
+        self.device = torch.device(f"cuda:{self.device_index}")
+        self.handle = C.c_void_p()
+        rc = self.lib.tgr_create(C.byref(self.cfg), self.num_envs, self.device_index, C.byref(self.handle))
+        N.check(self.handle if self.handle else None, rc, "tgr_create")
+        self.obs_dim = self.lib.tgr_obs_dim(self.handle)
+        self.f64 = self.cfg.precision == 1
+        dt = torch.float64 if self.f64 else torch.float32
+        n, D = self.num_envs, self.obs_dim
+        with torch.cuda.device(self.device):
+            self.obs = torch.zeros((n, D), dtype=dt, device=self.device)
+            self.terminal_obs = torch.zeros((n, D), dtype=dt, device=self.device)
+            self.reward = torch.zeros(n, dtype=dt, device=self.device)
+            self.terminated = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            self.truncated = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            self.info = torch.zeros((n, N.INFO_K), dtype=dt, device=self.device)
+        self.observation_space = Box(low=-np.inf, high=np.inf, shape=(D,), dtype=np.float64)
+        self.action_space = Box(low=np.float32(self.cfg.ctrl_range[0]), high=np.float32(self.cfg.ctrl_range[1]), shape=(6,), dtype=np.float32)
+        self.render_mode = None
+        self.info_mode = info_mode
+        self.reset_infos = [{} for _ in range(n)]
+        self._actions = None
+        self._t0 = time.time()
+        self.dt = self.cfg.timestep * self.cfg.frame_skip
+        self.frame_skip = self.cfg.frame_skip
+
+    # ------------------------------------------------------------------ device-tensor API (zero host copies)
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset_tensors(self, mask=None):
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            if m.shape != (self.num_envs,):
+                raise ValueError("mask shape")
+        rc = self.lib.tgr_reset(self.handle, None if m is None else m.ctypes.data, self.obs.data_ptr(), self._stream())
+        N.check(self.handle, rc, "tgr_reset")
+        return self.obs
+
+    def step_tensors(self, actions):
+        """actions: float32 cuda tensor [N,6].  Returns views of the internal device buffers
+        (obs, reward, terminated, truncated, terminal_obs, info)."""
+        t = self.torch
+        if not isinstance(actions, t.Tensor):
+            actions = t.as_tensor(np.asarray(actions, dtype=np.float32), device=self.device)
+        if tuple(actions.shape) != (self.num_envs, 6):
+            raise ValueError("Action dimension mismatch")
+        if actions.dtype != t.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=t.float32).contiguous()
+        fn = self.lib.tgr_step_f64 if self.f64 else self.lib.tgr_step
+        rc = fn(self.handle, actions.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
+                self.truncated.data_ptr(), self.terminal_obs.data_ptr(), self.info.data_ptr(), self._stream())
+        N.check(self.handle, rc, "tgr_step")
+        self._keep = actions
+        return self.obs, self.reward, self.terminated, self.truncated, self.terminal_obs, self.info
+
+    # ------------------------------------------------------------------ SB3 VecEnv surface (numpy)
+    def reset(self):
+        obs = self.reset_tensors().cpu().numpy().astype(np.float64)
+        self.reset_infos = [{} for _ in range(self.num_envs)]
+        return obs
+
+    def step_async(self, actions):
+        self._actions = actions
+
+    def step_wait(self):
+        obs, rew, term, trunc, tobs, info = self.step_tensors(self._actions)
+        obs_h = obs.cpu().numpy().astype(np.float64)
+        rew_h = rew.cpu().numpy().astype(np.float32)
+        term_h = term.cpu().numpy().astype(bool)
+        trunc_h = trunc.cpu().numpy().astype(bool)
+        dones = term_h | trunc_h
+        infos = self._infos(dones, term_h, trunc_h, tobs, info)
+        return obs_h, rew_h, dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def _infos(self, dones, term_h, trunc_h, tobs, info):
+        n = self.num_envs
+        if self.info_mode == "full":
+            ih = info.cpu().numpy().astype(np.float64)
+            infos = [dict(zip(N.INFO_KEYS, ih[i, :10])) for i in range(n)]
+        else:
+            infos = [{} for _ in range(n)]
+            ih = None
+        idx = np.nonzero(dones)[0]
+        if idx.size:
+            if ih is None:
+                ih = info.cpu().numpy().astype(np.float64)
+            th = tobs.cpu().numpy().astype(np.float64)
+            now = round(time.time() - self._t0, 6)
+            for i in idx:
+                d = infos[i]
+                d["terminal_observation"] = th[i]
+                d["TimeLimit.truncated"] = bool(trunc_h[i] and not term_h[i])
+                d["episode"] = {"r": float(ih[i, 14]), "l": int(ih[i, 15]), "t": now}
+        return infos
+
+    def close(self):
+        if getattr(self, "handle", None) and self.handle:
+            self.lib.tgr_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self.lib.tgr_set_seed(self.handle, int(seed))
+        return [seed] * self.num_envs
+
+    def get_attr(self, attr_name, indices=None):
+        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+        return [getattr(self, attr_name) for _ in idx]
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+        return [getattr(self, method_name)(*args, **kwargs) for _ in idx]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+        return [False for _ in idx]
+
+    def get_images(self):
+        return [None] * self.num_envs
+
+    def render(self, mode=None):
+        return None
+
+    # ------------------------------------------------------------------ state exchange (parity tests, checkpoints)
+    def get_state(self):
+        n = self.num_envs
+        qpos = np.zeros((n, N.NQ)); qvel = np.zeros((n, N.NV)); ctrl = np.zeros((n, N.NU)); warm = np.zeros((n, N.NV))
+        aux = np.zeros((n, N.AUX_K))
+        rc = self.lib.tgr_get_state(self.handle, qpos.ctypes.data, qvel.ctypes.data, ctrl.ctypes.data, warm.ctypes.data, aux.ctypes.data)
+        N.check(self.handle, rc, "tgr_get_state")
+        return {"qpos": qpos, "qvel": qvel, "ctrl": ctrl, "qacc_warmstart": warm, "aux": aux}
+
+    def set_state(self, qpos=None, qvel=None, ctrl=None, qacc_warmstart=None, aux=None):
+        def p(a, cols):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.shape != (self.num_envs, cols):
+                raise ValueError(f"expected shape {(self.num_envs, cols)}, got {a.shape}")
+            return a, a.ctypes.data
+        keep = [p(qpos, N.NQ), p(qvel, N.NV), p(ctrl, N.NU), p(qacc_warmstart, N.NV), p(aux, N.AUX_K)]
+        rc = self.lib.tgr_set_state(self.handle, *[k[1] for k in keep])
+        N.check(self.handle, rc, "tgr_set_state")
+
+    def stats(self):
+        out = (C.c_uint64 * 4)()
+        N.check(self.handle, self.lib.tgr_stats(self.handle, out), "tgr_stats")
+        return {"dropped_contacts": int(out[0]), "sync_resets": int(out[1]), "presettled_resets": int(out[2]), "side_launches": int(out[3])}
+
+    def synchronize(self):
+        self.lib.tgr_synchronize(self.handle)
+
+    def to_sb3(self):
+        from .sb3 import as_sb3_vecenv
+        return as_sb3_vecenv(self)
