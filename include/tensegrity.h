@@ -88,7 +88,7 @@ typedef struct tgr_config {
   /* --- execution */
   int32_t precision;    /* TGR_PRECISION_* */
   int32_t auto_reset;   /* 1 = VecEnv semantics, 0 = plain Gym Env semantics */
-  int32_t async_reset;  /* 1 = pre-settle the next episode of every env on a side stream */
+  int32_t n_donors;     /* extra lanes that pre-settle fresh episodes inside the step launches; -1 = 2 * n_envs, 0 = none */
   uint64_t seed;        /* reset RNG: philox4x32-10 keyed (seed, first_env_id + i, episode) */
   uint64_t first_env_id;
   double solver_tolerance; /* <=0: default for the precision */
@@ -119,11 +119,12 @@ int tgr_step_f64(tgr_handle* h, const float* actions, double* obs, double* rewar
 
 /* HOST arrays, any may be NULL: qpos[N][21], qvel[N][18] (MuJoCo convention: world linear,
  * body-frame angular), ctrl[N][6], qacc_warmstart[N][18], aux[N][TGR_AUX_K] */
-#define TGR_AUX_K 16
+#define TGR_AUX_K 17
 enum {
   TGR_AUX_XY_LAG_X = 0, TGR_AUX_XY_LAG_Y, TGR_AUX_PSI_LAG, TGR_AUX_RESET_PSI, TGR_AUX_EP_RETURN,
   TGR_AUX_STEP_NUM, TGR_AUX_ELAPSED, TGR_AUX_EPISODE, TGR_AUX_RING_LEN, TGR_AUX_WAYPT_X, TGR_AUX_WAYPT_Y,
-  TGR_AUX_ORI_X, TGR_AUX_ORI_Y, TGR_AUX_VCMD_X, TGR_AUX_VCMD_Y, TGR_AUX_VCMD_W
+  TGR_AUX_ORI_X, TGR_AUX_ORI_Y, TGR_AUX_VCMD_X, TGR_AUX_VCMD_Y, TGR_AUX_VCMD_W,
+  TGR_AUX_SRC /* lane whose RNG key produced the current episode: the env itself or a donor lane; TGR_AUX_EPISODE is the episode index under that key */
 };
 int tgr_get_state(tgr_handle* h, double* qpos, double* qvel, double* ctrl, double* qacc_warmstart, double* aux);
 /* set_state: like MujocoEnv.set_state it also recomputes the derived (lagged) kinematics from qpos;
@@ -131,14 +132,18 @@ int tgr_get_state(tgr_handle* h, double* qpos, double* qvel, double* ctrl, doubl
 int tgr_set_state(tgr_handle* h, const double* qpos, const double* qvel, const double* ctrl,
                   const double* qacc_warmstart, const double* aux);
 
-/* counters since creation: [0] dropped bar-bar contacts (slot overflow), [1] envs reset synchronously,
- * [2] envs reset from a pre-settled state, [3] settle launches on the side stream */
-int tgr_stats(tgr_handle* h, uint64_t out[4]);
+/* counters since creation: [0] dropped bar-bar contacts (slot overflow), [1] episodes settled by the settle kernel
+ * (tgr_reset, or a finished env that found no ready donor), [2] envs reset from a donor lane, [3] Newton iterations,
+ * [4] line-search evaluations, [5] sub-steps -- [3..5] summed over wavefronts (wave-uniform loop counts) */
+int tgr_stats(tgr_handle* h, uint64_t out[8]);
 /* re-key the reset RNG (Env.reset(seed=...)); takes effect for subsequent resets */
 int tgr_set_seed(tgr_handle* h, uint64_t seed);
 int tgr_synchronize(tgr_handle* h);
 const char* tgr_last_error(const tgr_handle* h);
 const char* tgr_version(void);
+int tgr_sizeof_config(void);
+/* RNG key of lane (lane < n: the env itself, else donor lane - n): (seed, key, episode) feeds philox4x32-10 */
+uint64_t tgr_lane_key(const tgr_handle* h, int lane);
 
 #ifdef __cplusplus
 }

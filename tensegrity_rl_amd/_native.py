@@ -10,11 +10,11 @@ i32, f64, u64 = C.c_int32, C.c_double, C.c_uint64
 ENV_TENSEGRITY, ENV_TR = 0, 1
 ACTIONS = {"straight": 0, "turn": 1, "aiming": 2, "tracking": 3, "vel_track": 4}
 PRECISION = {"f32": 0, "f64": 1, "float32": 0, "float64": 1}
-INFO_K, AUX_K, NQ, NV, NU = 16, 16, 21, 18, 6
+INFO_K, AUX_K, NQ, NV, NU = 16, 17, 21, 18, 6
 INFO_KEYS = ["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
              "distance_from_origin", "x_velocity", "y_velocity", "forward_reward"]
 AUX_KEYS = ["xy_lag_x", "xy_lag_y", "psi_lag", "reset_psi", "ep_return", "step_num", "elapsed", "episode", "ring_len",
-            "waypt_x", "waypt_y", "ori_x", "ori_y", "vcmd_x", "vcmd_y", "vcmd_w"]
+            "waypt_x", "waypt_y", "ori_x", "ori_y", "vcmd_x", "vcmd_y", "vcmd_w", "src"]
 
 
 class Config(C.Structure):
@@ -28,13 +28,13 @@ class Config(C.Structure):
         ("solimp", f64 * 5), ("friction", f64 * 3), ("impratio", f64), ("gain", f64), ("bias", f64 * 3),
         ("force_range", f64 * 2), ("ctrl_range", f64 * 2), ("ten_stiffness", f64 * 9), ("ten_damping", f64 * 9),
         ("ten_springlength", f64 * 9), ("actuator_deriv_skip_clamped", i32), ("precision", i32), ("auto_reset", i32),
-        ("async_reset", i32), ("seed", u64), ("first_env_id", u64), ("solver_tolerance", f64), ("solver_iterations", i32),
+        ("n_donors", i32), ("seed", u64), ("first_env_id", u64), ("solver_tolerance", f64), ("solver_iterations", i32),
     ]
 
 
 SYMBOLS = ["tgr_default_config", "tgr_create", "tgr_destroy", "tgr_num_envs", "tgr_obs_dim", "tgr_precision", "tgr_reset",
            "tgr_step", "tgr_step_f64", "tgr_get_state", "tgr_set_state", "tgr_stats", "tgr_set_seed", "tgr_synchronize",
-           "tgr_last_error", "tgr_version"]
+           "tgr_last_error", "tgr_version", "tgr_sizeof_config", "tgr_lane_key"]
 
 _lib = None
 
@@ -44,8 +44,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.lib_path()
-    if _build.needs_build():
+    path = os.environ.get("TGR_LIB") or _build.lib_path()
+    if not os.environ.get("TGR_LIB") and _build.needs_build():
         path = _build.build()
     L = C.CDLL(path)
     vp = C.c_void_p
@@ -66,6 +66,11 @@ def load():
     L.tgr_last_error.argtypes = [vp]
     L.tgr_last_error.restype = C.c_char_p
     L.tgr_version.restype = C.c_char_p
+    L.tgr_sizeof_config.restype = C.c_int
+    L.tgr_lane_key.argtypes = [vp, C.c_int]
+    L.tgr_lane_key.restype = C.c_uint64
+    if L.tgr_sizeof_config() != C.sizeof(Config):
+        raise RuntimeError(f"tgr_config layout mismatch: C {L.tgr_sizeof_config()} vs ctypes {C.sizeof(Config)}")
     _lib = L
     return L
 

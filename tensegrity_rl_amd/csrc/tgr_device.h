@@ -1,14 +1,18 @@
 // tgr_device.h -- per-lane physics of the batched tensegrity simulator (gfx950 / CDNA4).
 //
-// One wavefront lane integrates one environment.  Everything a sub-step needs lives in that
-// lane's VGPRs; only the tendon Jacobian pieces that must survive the contact solve are parked
-// in LDS ([slot][lane] layout: conflict-free ds_read/ds_write_b32).
+// One wavefront lane integrates one environment.  The rigid-body state of the lane (3 bars: pose,
+// twist, warm-start) stays in VGPRs for the whole control period; everything the contact solve
+// works on -- the 18x18 Hessian as six 6x6 blocks, the 12 contact slots, the solver vectors and
+// the tendon Jacobians -- is staged per lane in LDS as columns  lds[slot * LW + lane]  (bank =
+// lane: conflict-free ds_read/ds_write_b32).  Loops over bars / bar pairs / slots are real loops,
+// so the live register set is one 6x6 block plus one contact at a time (no scratch spills).
 //
 // This is NOT a port of MuJoCo and shares no code with oracle/ : the sub-step is formulated for
 // this one model in world-frame twist coordinates (v, w_world) per bar, with
 //   * mass matrix  diag(m I3, Ixx I3 + (Izz-Ixx) z z^T)   (bars are axially symmetric)
 //   * contact rows written frame-free (normal n only; friction is isotropic in the tangent plane)
-//   * the elliptic-cone Hessian as "isotropic + four rank-1" updates of an 18x18 register matrix
+//   * the elliptic-cone Hessian as "isotropic + four rank-1" updates of 6x6 blocks
+//   * a blocked Cholesky that skips the off-diagonal blocks no lane of the wave couples
 //   * implicitfast (M + h sum b J J^T) solved by a 9x9 Woodbury system over the nine tendons
 // It reproduces what the reference computes through mujoco==2.3.7 mj_step (reference call sites
 // tensegrity_env.py:297, tr_env.py:346,812; model 3prism_jonathan_steady_side.xml).
@@ -45,6 +49,7 @@ template <typename T> TGR_DEV V3<T> cross(V3<T> a, V3<T> b) {
   return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 template <typename T> TGR_DEV T comp(V3<T> a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+template <typename T> TGR_DEV V3<T> sel(bool c, V3<T> a, V3<T> b) { return mk(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 
 // ------------------------------------------------------------------ model parameters (host fills; kernel arg)
 template <typename T> struct Params {
@@ -69,7 +74,27 @@ struct Tab {
                                     {1, 4, 2, 5}, {0, 3, 2, 2}, {0, 2, 1, 3}, {1, 2, 2, 3}};
 };
 
-// ------------------------------------------------------------------ per-lane simulation state
+// ------------------------------------------------------------------ per-lane LDS columns (slot indices)
+// element `slot` of this lane is lds[slot * LW]  (lds already points at this lane's column)
+enum : int {
+  L_TEN = 0,            // 9 tendons x {u(3), rA x u(3), rB x u(3), sqrt(h b)} = 90
+  L_H = 90,             // Hessian: D0,D1,D2 (21 each, packed lower) O10,O20,O21 (36 each) = 171
+  L_CF = L_H + 171,     // 6 floor slots x {rB(3), c0, Dn, active} = 36
+  L_CP = L_CF + 36,     // 6 pair slots x {n(3), rA(3), rB(3), c0, Dn, active} = 72
+  L_A = L_CP + 72,      // current acceleration estimate, 3 bars x (lin3, ang3 world) = 18
+  L_A0 = L_A + 18,      // unconstrained acceleration
+  L_BV = L_A0 + 18,     // B * twist (what the reference-acceleration adds to every contact row)
+  L_G = L_BV + 18,      // gradient
+  L_P = L_G + 18,       // search direction
+  L_FC = L_P + 18,      // constraint wrench per bar (J^T f) == cfrc_ext
+  L_EZ = L_FC + 18,     // bar axes (3 x 3)
+  L_X = L_EZ + 9,       // bar COM positions (3 x 3)
+  L_TOTAL = L_X + 9     // 495
+};
+constexpr __host__ __device__ int H_D(int b) { return L_H + 21 * b; }
+constexpr int H_O10 = L_H + 63, H_O20 = L_H + 99, H_O21 = L_H + 135;
+
+// ------------------------------------------------------------------ per-lane simulation state (registers)
 template <typename T> struct Sim {
   V3<T> x[3];   // bar COM
   T q[3][4];    // orientation (w,x,y,z)
@@ -88,6 +113,8 @@ template <typename T> struct Lag {
   T tenL[9];
   T cfrc_absmax;
   int overflow;
+  int n_it, n_ls;  // solver work of this control period (wave-uniform)
+  int n_unconv;    // sub-steps this lane left the solver at the iteration cap
 };
 
 template <typename T> struct Rot { V3<T> ex, ey, ez; };  // columns of the rotation matrix
@@ -119,10 +146,11 @@ template <typename T> TGR_DEV V3<T> inertia_mul(const Params<T>& P, V3<T> z, V3<
   return P.Ixx * a + ((P.Izz - P.Ixx) * dot(z, a)) * z;
 }
 
-// ------------------------------------------------------------------ contact slots
-// slots 0..5 : floor vs cap k (bar k/2, +z end for even k)      body A = world
-// slots 6..11: bar pair (0,1),(0,2),(1,2) x {r-cylinder pair, deepest other geom pair}
-constexpr int NSLOT = 12;
+// LDS column access
+template <typename T, int LW> TGR_DEV V3<T> ld3(const T* lds, int slot) { return mk(lds[slot * LW], lds[(slot + 1) * LW], lds[(slot + 2) * LW]); }
+template <typename T, int LW> TGR_DEV void st3(T* lds, int slot, V3<T> v) { lds[slot * LW] = v.x; lds[(slot + 1) * LW] = v.y; lds[(slot + 2) * LW] = v.z; }
+
+// ------------------------------------------------------------------ contacts
 template <typename T> struct Contact {
   V3<T> n;       // normal, from body A to body B
   V3<T> rA, rB;  // contact point relative to the COMs
@@ -146,17 +174,37 @@ template <typename T> TGR_DEV void contact_params(const Params<T>& P, T dist, in
   c.Dn = rcp_(R0);
   c.c0 = P.K * imp * dist;
 }
+template <typename T, int LW> TGR_DEV Contact<T> load_floor(const T* lds, int k) {
+  Contact<T> c;
+  const int s = L_CF + 6 * k;
+  c.n = mk(T(0), T(0), T(1));
+  c.rA = mk(T(0), T(0), T(0));
+  c.rB = ld3<T, LW>(lds, s);
+  c.c0 = lds[(s + 3) * LW]; c.Dn = lds[(s + 4) * LW]; c.active = lds[(s + 5) * LW] != T(0);
+  return c;
+}
+template <typename T, int LW> TGR_DEV Contact<T> load_pair(const T* lds, int k) {
+  Contact<T> c;
+  const int s = L_CP + 12 * k;
+  c.n = ld3<T, LW>(lds, s); c.rA = ld3<T, LW>(lds, s + 3); c.rB = ld3<T, LW>(lds, s + 6);
+  c.c0 = lds[(s + 9) * LW]; c.Dn = lds[(s + 10) * LW]; c.active = lds[(s + 11) * LW] != T(0);
+  return c;
+}
+template <typename T, int LW> TGR_DEV void store_pair(T* lds, int k, const Contact<T>& c) {
+  const int s = L_CP + 12 * k;
+  st3<T, LW>(lds, s, c.n); st3<T, LW>(lds, s + 3, c.rA); st3<T, LW>(lds, s + 6, c.rB);
+  lds[(s + 9) * LW] = c.c0; lds[(s + 10) * LW] = c.Dn; lds[(s + 11) * LW] = c.active ? T(1) : T(0);
+}
 
 // what the cone says at one jar: force, and the Hessian in "isotropic + rank-1" form
 template <typename T> struct Cone {
-  T cost;
   V3<T> fl, fa;            // efc force as world vectors (linear rows, angular rows)
   T a1, a2, b1, b2;        // C = blkdiag(a1 I + a2 nn^T, b1 I + b2 nn^T) + cg g g^T + cw w w^T
   T cg, cw;
   V3<T> gl, ga, wl, wa;
 };
 
-template <typename T, bool HESS>
+template <typename T>
 TGR_DEV Cone<T> cone_eval(const Params<T>& P, const Contact<T>& c, V3<T> jl, V3<T> ja) {
   Cone<T> o;
   T mu = P.f0 * rsqrt_(P.impratio);
@@ -174,7 +222,6 @@ TGR_DEV Cone<T> cone_eval(const Params<T>& P, const Contact<T>& c, V3<T> jl, V3<
   bool bottom = !top && (mu * N + Tn <= T(0));
   bool middle = !top && !bottom;
   // bottom (quadratic) zone
-  T costB = T(0.5) * (c.Dn * jn * jn + Dt * dot(jt, jt) + Do * jo * jo + Dr * dot(jr, jr));
   V3<T> flB = -((c.Dn * jn) * c.n + Dt * jt);
   V3<T> faB = -((Do * jo) * c.n + Dr * jr);
   // middle (cone) zone
@@ -182,113 +229,237 @@ TGR_DEV Cone<T> cone_eval(const Params<T>& P, const Contact<T>& c, V3<T> jl, V3<
   T rT = rcp_(Tsafe);
   T Dm = c.Dn * rcp_(mu * mu * (T(1) + mu * mu));
   T NT = N - mu * Tn;
-  T costM = T(0.5) * Dm * NT * NT;
   T fn = -Dm * NT * mu;
   V3<T> wl = P.f1sq * jt;
   V3<T> wa = (P.f3sq * jo) * c.n + P.f4sq * jr;
   V3<T> flM = fn * c.n - (fn * rT) * wl;
   V3<T> faM = -(fn * rT) * wa;
   T zero = T(0);
-  o.cost = bottom ? costB : (middle ? costM : zero);
-  o.fl = mk(bottom ? flB.x : (middle ? flM.x : zero), bottom ? flB.y : (middle ? flM.y : zero), bottom ? flB.z : (middle ? flM.z : zero));
-  o.fa = mk(bottom ? faB.x : (middle ? faM.x : zero), bottom ? faB.y : (middle ? faM.y : zero), bottom ? faB.z : (middle ? faM.z : zero));
-  if (HESS) {
-    T kap = -Dm * mu * NT * rT;  // >= 0 in the middle zone
-    o.a1 = bottom ? Dt : (middle ? kap * P.f1sq : zero);
-    o.a2 = bottom ? (c.Dn - Dt) : (middle ? -kap * P.f1sq : zero);
-    o.b1 = bottom ? Dr : (middle ? kap * P.f4sq : zero);
-    o.b2 = bottom ? (Do - Dr) : (middle ? kap * (P.f3sq - P.f4sq) : zero);
-    o.cg = middle ? Dm : zero;
-    o.cw = middle ? -kap * rT * rT : zero;
-    o.gl = mu * c.n - (mu * rT) * wl;
-    o.ga = -(mu * rT) * wa;
-    o.wl = wl;
-    o.wa = wa;
-  }
+  V3<T> z3 = mk(zero, zero, zero);
+  o.fl = sel(bottom, flB, sel(middle, flM, z3));
+  o.fa = sel(bottom, faB, sel(middle, faM, z3));
+  T kap = -Dm * mu * NT * rT;  // >= 0 in the middle zone
+  o.a1 = bottom ? Dt : (middle ? kap * P.f1sq : zero);
+  o.a2 = bottom ? (c.Dn - Dt) : (middle ? -kap * P.f1sq : zero);
+  o.b1 = bottom ? Dr : (middle ? kap * P.f4sq : zero);
+  o.b2 = bottom ? (Do - Dr) : (middle ? kap * (P.f3sq - P.f4sq) : zero);
+  o.cg = middle ? Dm : zero;
+  o.cw = middle ? -kap * rT * rT : zero;
+  o.gl = mu * c.n - (mu * rT) * wl;
+  o.ga = -(mu * rT) * wa;
+  o.wl = wl;
+  o.wa = wa;
   return o;
 }
 
-// ------------------------------------------------------------------ 18x18 symmetric matrix in registers (lower triangle)
-constexpr __host__ __device__ int hidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+// ------------------------------------------------------------------ 6x6 block algebra (registers)
+constexpr __host__ __device__ int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
-template <typename T, int X, int HS = 1> TGR_DEV void h_rank1_self(T* H, T c, const T* u) {
+template <typename T, int LW> TGR_DEV void ld21(const T* lds, int off, T* D) {
 #pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int j = 0; j <= i; j++) H[HS * hidx(6 * X + i, 6 * X + j)] += c * u[i] * u[j];
+  for (int i = 0; i < 21; i++) D[i] = lds[(off + i) * LW];
 }
-template <typename T, int A, int B, int HS = 1> TGR_DEV void h_rank1_cross(T* H, T c, const T* uA, const T* uB) {  // A < B
+template <typename T, int LW> TGR_DEV void st21(T* lds, int off, const T* D) {
 #pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int j = 0; j < 6; j++) H[HS * hidx(6 * B + i, 6 * A + j)] += c * uB[i] * uA[j];
+  for (int i = 0; i < 21; i++) lds[(off + i) * LW] = D[i];
 }
-// isotropic pieces:  a1 * Jlin^T Jlin + b1 * Jang^T Jang  for (rows of body X, cols of body Y), sign s
-template <typename T, int X, int Y, int HS = 1> TGR_DEV void h_iso(T* H, T s, T a1, T b1, V3<T> rX, V3<T> rY) {
-  T sa = s * a1, sb = s * b1;
-  // lin-lin
+template <typename T, int LW> TGR_DEV void ld36(const T* lds, int off, T* O) {
 #pragma unroll
-  for (int i = 0; i < 3; i++) H[HS * hidx(6 * X + i, 6 * Y + i)] += sa;
-  // ang(X)-lin(Y): [rX]x
-  const T cx[3][3] = {{T(0), -rX.z, rX.y}, {rX.z, T(0), -rX.x}, {-rX.y, rX.x, T(0)}};
-  const T cy[3][3] = {{T(0), -rY.z, rY.y}, {rY.z, T(0), -rY.x}, {-rY.y, rY.x, T(0)}};
+  for (int i = 0; i < 36; i++) O[i] = lds[(off + i) * LW];
+}
+template <typename T, int LW> TGR_DEV void st36(T* lds, int off, const T* O) {
 #pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      if (i != j) H[HS * hidx(6 * X + 3 + i, 6 * Y + j)] += sa * cx[i][j];
-      // lin(X)-ang(Y): -[rY]x   (only stored when it is in the lower triangle, i.e. X > Y)
-      if (X != Y && i != j) H[HS * hidx(6 * X + i, 6 * Y + 3 + j)] += -sa * cy[i][j];
-    }
-  // ang-ang: (rX.rY) I - rY rX^T
-  T d = dot(rX, rY);
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      if (X == Y && j > i) continue;
-      T e = -comp(rY, i) * comp(rX, j) + (i == j ? d + T(0) : T(0));
-      H[HS * hidx(6 * X + 3 + i, 6 * Y + 3 + j)] += sa * e + (i == j ? sb : T(0));
-    }
+  for (int i = 0; i < 36; i++) lds[(off + i) * LW] = O[i];
 }
 
 // body-space image of a contact-space vector (cl, ca) :  (cl, r x cl + ca)
-template <typename T> TGR_DEV void body_vec(V3<T> cl, V3<T> ca, V3<T> r, T s, T* u) {
+template <typename T> TGR_DEV void body_vec(V3<T> cl, V3<T> ca, V3<T> r, T* u) {
   V3<T> t = cross(r, cl) + ca;
-  u[0] = s * cl.x; u[1] = s * cl.y; u[2] = s * cl.z; u[3] = s * t.x; u[4] = s * t.y; u[5] = s * t.z;
+  u[0] = cl.x; u[1] = cl.y; u[2] = cl.z; u[3] = t.x; u[4] = t.y; u[5] = t.z;
 }
 
-// in-place Cholesky of the packed lower triangle, n x n
-template <typename T, int NN, int HS = 1> TGR_DEV void chol_factor(T* H) {
+// D (packed lower 6x6 of one bar) += J^T C J of a contact with arm r on this bar
+template <typename T> TGR_DEV void self_block_add(T* D, const Cone<T>& o, V3<T> n, V3<T> r) {
+  // isotropic: a1 [I, -[r]x ; [r]x , |r|^2 I - r r^T] + b1 [0 0; 0 I]
+  D[tri(0, 0)] += o.a1; D[tri(1, 1)] += o.a1; D[tri(2, 2)] += o.a1;
+  D[tri(3, 1)] += -o.a1 * r.z; D[tri(3, 2)] += o.a1 * r.y;
+  D[tri(4, 0)] += o.a1 * r.z;  D[tri(4, 2)] += -o.a1 * r.x;
+  D[tri(5, 0)] += -o.a1 * r.y; D[tri(5, 1)] += o.a1 * r.x;
+  T rr = dot(r, r);
+  D[tri(3, 3)] += o.a1 * (rr - r.x * r.x) + o.b1;
+  D[tri(4, 3)] += -o.a1 * r.y * r.x;
+  D[tri(4, 4)] += o.a1 * (rr - r.y * r.y) + o.b1;
+  D[tri(5, 3)] += -o.a1 * r.z * r.x;
+  D[tri(5, 4)] += -o.a1 * r.z * r.y;
+  D[tri(5, 5)] += o.a1 * (rr - r.z * r.z) + o.b1;
+  // four rank-1 terms
+  V3<T> z3 = mk(T(0), T(0), T(0));
+  const V3<T> cls[4] = {n, z3, o.gl, o.wl};
+  const V3<T> cas[4] = {z3, n, o.ga, o.wa};
+  const T cf[4] = {o.a2, o.b2, o.cg, o.cw};
 #pragma unroll
-  for (int j = 0; j < NN; j++) {
-    // right-looking: column j is final when we get here
-    T col[NN];
-    T s = max_(H[HS * hidx(j, j)], T(1e-30));
-    T il = rsqrt_(s);
-    H[HS * hidx(j, j)] = il;  // store 1/L_jj
+  for (int k = 0; k < 4; k++) {
+    T u[6];
+    body_vec(cls[k], cas[k], r, u);
 #pragma unroll
-    for (int i = j + 1; i < NN; i++) { col[i] = H[HS * hidx(i, j)] * il; H[HS * hidx(i, j)] = col[i]; }
+    for (int i = 0; i < 6; i++)
 #pragma unroll
-    for (int i = j + 1; i < NN; i++)
-#pragma unroll
-      for (int k = j + 1; k <= i; k++) H[HS * hidx(i, k)] -= col[i] * col[k];
+      for (int j = 0; j <= i; j++) D[tri(i, j)] += cf[k] * u[i] * u[j];
   }
 }
-template <typename T, int NN, int HS = 1> TGR_DEV void chol_solve(const T* L, T* x) {
+// O (full 6x6, rows = body B dofs, cols = body A dofs) += J_B^T C J_A  (J_A carries the minus sign)
+template <typename T> TGR_DEV void cross_block_add(T* O, const Cone<T>& o, V3<T> n, V3<T> rB, V3<T> rA) {
+  T a = -o.a1, b = -o.b1;
+  O[0 * 6 + 0] += a; O[1 * 6 + 1] += a; O[2 * 6 + 2] += a;
+  // ang(B)-lin(A): [rB]x
+  O[3 * 6 + 1] += -a * rB.z; O[3 * 6 + 2] += a * rB.y;
+  O[4 * 6 + 0] += a * rB.z;  O[4 * 6 + 2] += -a * rB.x;
+  O[5 * 6 + 0] += -a * rB.y; O[5 * 6 + 1] += a * rB.x;
+  // lin(B)-ang(A): -[rA]x
+  O[0 * 6 + 4] += a * rA.z;  O[0 * 6 + 5] += -a * rA.y;
+  O[1 * 6 + 3] += -a * rA.z; O[1 * 6 + 5] += a * rA.x;
+  O[2 * 6 + 3] += a * rA.y;  O[2 * 6 + 4] += -a * rA.x;
+  // ang-ang: (rA.rB) I - rA rB^T
+  T d = dot(rA, rB);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) O[(3 + i) * 6 + 3 + j] += a * ((i == j ? d : T(0)) - comp(rA, i) * comp(rB, j)) + (i == j ? b : T(0));
+  V3<T> z3 = mk(T(0), T(0), T(0));
+  const V3<T> cls[4] = {n, z3, o.gl, o.wl};
+  const V3<T> cas[4] = {z3, n, o.ga, o.wa};
+  const T cf[4] = {o.a2, o.b2, o.cg, o.cw};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    T uB[6], uA[6];
+    body_vec(cls[k], cas[k], rB, uB);
+    body_vec(cls[k], cas[k], rA, uA);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < 6; j++) O[i * 6 + j] -= cf[k] * uB[i] * uA[j];
+  }
+}
+
+// in-place Cholesky of a packed lower 6x6; diagonal stores 1/L_jj
+template <typename T> TGR_DEV void chol6(T* D) {
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    T s = D[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= D[tri(j, k)] * D[tri(j, k)];
+    s = max_(s, T(1e-30));
+    T il = rsqrt_(s);
+    D[tri(j, j)] = il;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      T t = D[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= D[tri(i, k)] * D[tri(j, k)];
+      D[tri(i, j)] = t * il;
+    }
+  }
+}
+// O <- O L^-T   (O full 6x6 row-major, L packed lower with inverse diagonal)
+template <typename T> TGR_DEV void trsm6(T* O, const T* L) {
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      T s = O[r * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= O[r * 6 + k] * L[tri(j, k)];
+      O[r * 6 + j] = s * L[tri(j, j)];
+    }
+}
+// D -= O O^T (lower)
+template <typename T> TGR_DEV void syrk6(T* D, const T* O) {
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      T s = T(0);
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += O[i * 6 + k] * O[j * 6 + k];
+      D[tri(i, j)] -= s;
+    }
+}
+// O2 -= Oa Ob^T
+template <typename T> TGR_DEV void gemm6(T* O2, const T* Oa, const T* Ob) {
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      T s = T(0);
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += Oa[i * 6 + k] * Ob[j * 6 + k];
+      O2[i * 6 + j] -= s;
+    }
+}
+template <typename T> TGR_DEV void fsolve6(const T* L, T* x) {  // x <- L^-1 x
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    T s = x[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[tri(i, k)] * x[k];
+    x[i] = s * L[tri(i, i)];
+  }
+}
+template <typename T> TGR_DEV void bsolve6(const T* L, T* x) {  // x <- L^-T x
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    T s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) s -= L[tri(k, i)] * x[k];
+    x[i] = s * L[tri(i, i)];
+  }
+}
+template <typename T> TGR_DEV void gemv_sub(const T* O, const T* x, T* y) {  // y -= O x
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int k = 0; k < 6; k++) y[i] -= O[i * 6 + k] * x[k];
+}
+template <typename T> TGR_DEV void gemvT_sub(const T* O, const T* x, T* y) {  // y -= O^T x
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int k = 0; k < 6; k++) y[i] -= O[k * 6 + i] * x[k];
+}
+
+// small dense helpers for the 9x9 Woodbury system (registers)
+template <typename T, int NN> TGR_DEV void chol_factor(T* H) {
+#pragma unroll
+  for (int j = 0; j < NN; j++) {
+    T s = H[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= H[tri(j, k)] * H[tri(j, k)];
+    s = max_(s, T(1e-30));
+    T il = rsqrt_(s);
+    H[tri(j, j)] = il;
+#pragma unroll
+    for (int i = j + 1; i < NN; i++) {
+      T t = H[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= H[tri(i, k)] * H[tri(j, k)];
+      H[tri(i, j)] = t * il;
+    }
+  }
+}
+template <typename T, int NN> TGR_DEV void chol_solve(const T* L, T* x) {
 #pragma unroll
   for (int i = 0; i < NN; i++) {
     T s = x[i];
 #pragma unroll
-    for (int k = 0; k < i; k++) s -= L[HS * hidx(i, k)] * x[k];
-    x[i] = s * L[HS * hidx(i, i)];
+    for (int k = 0; k < i; k++) s -= L[tri(i, k)] * x[k];
+    x[i] = s * L[tri(i, i)];
   }
 #pragma unroll
   for (int i = NN - 1; i >= 0; i--) {
     T s = x[i];
 #pragma unroll
-    for (int k = i + 1; k < NN; k++) s -= L[HS * hidx(k, i)] * x[k];
-    x[i] = s * L[HS * hidx(i, i)];
+    for (int k = i + 1; k < NN; k++) s -= L[tri(k, i)] * x[k];
+    x[i] = s * L[tri(i, i)];
   }
 }
 
@@ -300,22 +471,22 @@ template <typename T> TGR_DEV void keep_deeper(Cand<T>& best, int& count, T dist
   count += hit ? 1 : 0;
   bool take = hit && (!best.ok || dist < best.dist);
   best.dist = take ? dist : best.dist;
-  best.n = mk(take ? n.x : best.n.x, take ? n.y : best.n.y, take ? n.z : best.n.z);
-  best.p = mk(take ? p.x : best.p.x, take ? p.y : best.p.y, take ? p.z : best.p.z);
+  best.n = sel(take, n, best.n);
+  best.p = sel(take, p, best.p);
   best.ok = best.ok || hit;
 }
 
-// sphere (centre c, body "S") against the coaxial cylinders of the other bar (centre xo, axis zo).
+// sphere (centre c) against the coaxial cylinders of the other bar (centre xo, axis zo).
 // flip=false: sphere belongs to body A (normal = sphere->cyl), flip=true: sphere belongs to body B.
 template <typename T>
-TGR_DEV void sphere_vs_bar(const Params<T>& P, V3<T> c, V3<T> xo, V3<T> zo, bool flip, Cand<T>& best, int& count) {
+TGR_DEV void sphere_vs_bar(const Params<T>& P, V3<T> c, V3<T> xo, V3<T> zo, bool flip, bool enable, Cand<T>& best, int& count) {
   V3<T> wv = c - xo;
   T t = dot(wv, zo);
   V3<T> rad = wv - t * zo;
   T rho = sqrt_(dot(rad, rad));
   T irho = rcp_(max_(rho, T(1e-30)));
   // three cylinders: r (|t|<=half, R=rcyl), b+ (t in [lo,hi]), b- (t in [-hi,-lo])
-#pragma unroll
+#pragma unroll 1
   for (int k = 0; k < 3; k++) {
     T cen = k == 0 ? T(0) : (k == 1 ? T(0.5) * (P.bcyl_hi + P.bcyl_lo) : -T(0.5) * (P.bcyl_hi + P.bcyl_lo));
     T hh = k == 0 ? P.bar_half : T(0.5) * (P.bcyl_hi - P.bcyl_lo);
@@ -335,9 +506,9 @@ TGR_DEV void sphere_vs_bar(const Params<T>& P, V3<T> c, V3<T> xo, V3<T> zo, bool
     T distI = rho - rc - P.cap_r;
     V3<T> nI = -irho * rad;
     dist = inside ? distI : dist;
-    n = mk(inside ? nI.x : n.x, inside ? nI.y : n.y, inside ? nI.z : n.z);
+    n = sel(inside, nI, n);
     V3<T> pos = c + (P.cap_r + T(0.5) * dist) * n;
-    bool valid = inside ? (rho > T(1e-12)) : (dd > T(1e-12));
+    bool valid = enable && (inside ? (rho > T(1e-12)) : (dd > T(1e-12)));
     V3<T> nn = flip ? -n : n;
     keep_deeper(best, count, dist, nn, pos, valid);
   }
@@ -364,16 +535,19 @@ TGR_DEV void bar_pair_contacts(const Params<T>& P, V3<T> xA, V3<T> zA, V3<T> xB,
   V3<T> n = idd * dif;
   bool okdir = skew && dd > T(1e-9);
   // cheap cull: clamped segment-segment distance against the largest reach (two cap spheres)
+  bool near;
   {
     T sc = clamp_(skew ? s : T(0), -P.bar_half, P.bar_half);
     T tc = clamp_(dB + b * sc, -P.bar_half, P.bar_half);
     sc = clamp_(b * tc - dA, -P.bar_half, P.bar_half);
     V3<T> dv = (xB + tc * zB) - (xA + sc * zA);
-    if (dot(dv, dv) > (T(2) * P.cap_r + T(1e-6)) * (T(2) * P.cap_r + T(1e-6))) return;
+    T reach = T(2) * P.cap_r + T(1e-6);
+    near = dot(dv, dv) <= reach * reach;
   }
+  if (!__any(near)) return;
   // r-cylinder vs r-cylinder: the frequent one, own slot
   {
-    bool interior = okdir && abs_(s) < P.bar_half && abs_(t) < P.bar_half;
+    bool interior = near && okdir && abs_(s) < P.bar_half && abs_(t) < P.bar_half;
     T dist = dd - T(2) * P.rcyl_r;
     if (interior && dist < T(0)) {
       c0.active = true;
@@ -383,7 +557,27 @@ TGR_DEV void bar_pair_contacts(const Params<T>& P, V3<T> xA, V3<T> zA, V3<T> xB,
       contact_params(P, dist, 2, c0);
     }
   }
-  // everything else: keep the deepest, count the rest
+  // everything else: keep the deepest, count the rest.  Only possible when a cap sphere is within reach of the other
+  // bar (end region), or the r-cylinders overlap by more than the b-cylinder clearance.
+  bool deep = near && okdir && (dd - T(2) * P.rcyl_r < -(P.rcyl_r - P.bcyl_r));
+  // is any of the four cap centres within two cap radii of the other bar's axis segment?
+  bool ends = false;
+  {
+    T reach2 = (T(2) * P.cap_r + T(1e-6)) * (T(2) * P.cap_r + T(1e-6));
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      T sg = e == 0 ? P.bar_half : -P.bar_half;
+      V3<T> ea = (xA + sg * zA) - xB;   // A's end relative to B
+      T ta = clamp_(dot(ea, zB), -P.bar_half, P.bar_half);
+      V3<T> da = ea - ta * zB;
+      V3<T> eb = (xB + sg * zB) - xA;   // B's end relative to A
+      T tb = clamp_(dot(eb, zA), -P.bar_half, P.bar_half);
+      V3<T> db = eb - tb * zA;
+      ends = ends || dot(da, da) <= reach2 || dot(db, db) <= reach2;
+    }
+    ends = ends && near;
+  }
+  if (!__any(deep || ends)) return;
   Cand<T> best; best.ok = false; best.dist = T(0); best.n = c0.n; best.p = xA;
   int count = 0;
   T bc = T(0.5) * (P.bcyl_hi + P.bcyl_lo), bh = T(0.5) * (P.bcyl_hi - P.bcyl_lo);
@@ -395,17 +589,17 @@ TGR_DEV void bar_pair_contacts(const Params<T>& P, V3<T> xA, V3<T> zA, V3<T> xB,
       if (i == 0 && j == 0) continue;
       T ci = i == 0 ? T(0) : (i == 1 ? bc : -bc), hi_ = i == 0 ? P.bar_half : bh, ri = i == 0 ? P.rcyl_r : P.bcyl_r;
       T cj = j == 0 ? T(0) : (j == 1 ? bc : -bc), hj_ = j == 0 ? P.bar_half : bh, rj = j == 0 ? P.rcyl_r : P.bcyl_r;
-      bool interior = okdir && abs_(s - ci) < hi_ && abs_(t - cj) < hj_;
+      bool interior = near && okdir && abs_(s - ci) < hi_ && abs_(t - cj) < hj_;
       T dist = dd - ri - rj;
       V3<T> pos = pa + (ri + T(0.5) * dist) * n;
       keep_deeper(best, count, dist, n, pos, interior);
     }
   // spheres
-#pragma unroll
+#pragma unroll 1
   for (int ea = 0; ea < 2; ea++) {
     V3<T> ca = xA + (ea == 0 ? P.bar_half : -P.bar_half) * zA;
-    sphere_vs_bar(P, ca, xB, zB, false, best, count);
-#pragma unroll
+    sphere_vs_bar(P, ca, xB, zB, false, near, best, count);
+#pragma unroll 1
     for (int eb = 0; eb < 2; eb++) {
       V3<T> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
       V3<T> dv = cb - ca;
@@ -413,13 +607,13 @@ TGR_DEV void bar_pair_contacts(const Params<T>& P, V3<T> xA, V3<T> zA, V3<T> xB,
       T dist = cd - T(2) * P.cap_r;
       V3<T> nn = rcp_(max_(cd, T(1e-30))) * dv;
       V3<T> pos = ca + (P.cap_r + T(0.5) * dist) * nn;
-      keep_deeper(best, count, dist, nn, pos, cd > T(1e-12));
+      keep_deeper(best, count, dist, nn, pos, near && cd > T(1e-12));
     }
   }
-#pragma unroll
+#pragma unroll 1
   for (int eb = 0; eb < 2; eb++) {
     V3<T> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
-    sphere_vs_bar(P, cb, xA, zA, true, best, count);
+    sphere_vs_bar(P, cb, xA, zA, true, near, best, count);
   }
   if (best.ok) {
     c1.active = true;
@@ -430,300 +624,372 @@ TGR_DEV void bar_pair_contacts(const Params<T>& P, V3<T> xA, V3<T> zA, V3<T> xB,
   dropped += count > 1 ? count - 1 : 0;
 }
 
-// ------------------------------------------------------------------ slot evaluation helpers
-template <int SLOT> struct SlotBodies {
-  static constexpr int A = SLOT < 6 ? -1 : (SLOT < 10 ? 0 : 1);
-  static constexpr int B = SLOT < 6 ? SLOT / 2 : (SLOT < 8 ? 1 : 2);
-};
+// bodies of pair p: (0,1), (0,2), (1,2)
+TGR_DEV int pair_A(int p) { return p == 2 ? 1 : 0; }
+TGR_DEV int pair_B(int p) { return p == 0 ? 1 : 2; }
+TGR_DEV int pair_O(int p) { return p == 0 ? H_O10 : (p == 1 ? H_O20 : H_O21); }
 
-template <typename T, int SLOT>
-TGR_DEV void slot_jar(const Contact<T>& c, const V3<T>* yl, const V3<T>* ya, V3<T>& jl, V3<T>& ja) {
-  constexpr int A = SlotBodies<SLOT>::A, B = SlotBodies<SLOT>::B;
-  jl = yl[B] + cross(ya[B], c.rB);
-  ja = ya[B];
-  if (A >= 0) {
-    jl = jl - (yl[A < 0 ? 0 : A] + cross(ya[A < 0 ? 0 : A], c.rA));
-    ja = ja - ya[A < 0 ? 0 : A];
+// ------------------------------------------------------------------ Newton pieces (LDS-centric)
+// evaluate every contact at the current A (in LDS): builds Hessian blocks, constraint wrench FC, gradient G.
+// returns |G|^2 ; cpl[p] = some lane of the wave couples pair p
+template <typename T, int LW>
+TGR_DEV T newton_assemble(const Params<T>& P, T* lds, unsigned& cpl, T& cfrc_max) {
+  cpl = 0u;
+  // ---- per bar: mass block + its two floor contacts
+#pragma unroll 1
+  for (int b = 0; b < 3; b++) {
+    V3<T> ez = ld3<T, LW>(lds, L_EZ + 3 * b);
+    T D[21];
+#pragma unroll
+    for (int i = 0; i < 21; i++) D[i] = T(0);
+    T dI = P.Izz - P.Ixx;
+    D[tri(0, 0)] = P.mass; D[tri(1, 1)] = P.mass; D[tri(2, 2)] = P.mass;
+    D[tri(3, 3)] = P.Ixx + dI * ez.x * ez.x;
+    D[tri(4, 3)] = dI * ez.y * ez.x; D[tri(4, 4)] = P.Ixx + dI * ez.y * ez.y;
+    D[tri(5, 3)] = dI * ez.z * ez.x; D[tri(5, 4)] = dI * ez.z * ez.y; D[tri(5, 5)] = P.Ixx + dI * ez.z * ez.z;
+    V3<T> yl = ld3<T, LW>(lds, L_A + 6 * b) + ld3<T, LW>(lds, L_BV + 6 * b);
+    V3<T> ya = ld3<T, LW>(lds, L_A + 6 * b + 3) + ld3<T, LW>(lds, L_BV + 6 * b + 3);
+    V3<T> fl = mk(T(0), T(0), T(0)), fa = fl;
+#pragma unroll 1
+    for (int e = 0; e < 2; e++) {
+      Contact<T> c = load_floor<T, LW>(lds, 2 * b + e);
+      if (__any(c.active)) {
+        V3<T> jl = yl + cross(ya, c.rB);
+        jl.z += c.c0;
+        Cone<T> o = cone_eval(P, c, jl, ya);
+        fl = fl + o.fl;
+        fa = fa + cross(c.rB, o.fl) + o.fa;
+        self_block_add(D, o, c.n, c.rB);
+      }
+    }
+    st21<T, LW>(lds, H_D(b), D);
+    st3<T, LW>(lds, L_FC + 6 * b, fl);
+    st3<T, LW>(lds, L_FC + 6 * b + 3, fa);
+  }
+  // ---- bar pairs
+#pragma unroll 1
+  for (int p = 0; p < 3; p++) {
+    const int A = pair_A(p), B = pair_B(p);
+    Contact<T> c0 = load_pair<T, LW>(lds, 2 * p);
+    Contact<T> c1 = load_pair<T, LW>(lds, 2 * p + 1);
+    bool any0 = __any(c0.active), any1 = __any(c1.active);
+    if (!(any0 || any1)) continue;
+    cpl |= 1u << p;
+    T DA[21], DB[21], O[36];
+    ld21<T, LW>(lds, H_D(A), DA);
+    ld21<T, LW>(lds, H_D(B), DB);
+#pragma unroll
+    for (int i = 0; i < 36; i++) O[i] = T(0);
+    V3<T> ylA = ld3<T, LW>(lds, L_A + 6 * A) + ld3<T, LW>(lds, L_BV + 6 * A);
+    V3<T> yaA = ld3<T, LW>(lds, L_A + 6 * A + 3) + ld3<T, LW>(lds, L_BV + 6 * A + 3);
+    V3<T> ylB = ld3<T, LW>(lds, L_A + 6 * B) + ld3<T, LW>(lds, L_BV + 6 * B);
+    V3<T> yaB = ld3<T, LW>(lds, L_A + 6 * B + 3) + ld3<T, LW>(lds, L_BV + 6 * B + 3);
+    V3<T> flA = mk(T(0), T(0), T(0)), faA = flA, flB = flA, faB = flA;
+#pragma unroll 1
+    for (int s = 0; s < 2; s++) {
+      if (!(s == 0 ? any0 : any1)) continue;
+      Contact<T> c = s == 0 ? c0 : c1;
+      V3<T> jl = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
+      V3<T> ja = yaB - yaA;
+      Cone<T> o = cone_eval(P, c, jl, ja);
+      flB = flB + o.fl; faB = faB + cross(c.rB, o.fl) + o.fa;
+      flA = flA - o.fl; faA = faA - (cross(c.rA, o.fl) + o.fa);
+      self_block_add(DB, o, c.n, c.rB);
+      self_block_add(DA, o, c.n, c.rA);
+      cross_block_add(O, o, c.n, c.rB, c.rA);
+    }
+    st21<T, LW>(lds, H_D(A), DA);
+    st21<T, LW>(lds, H_D(B), DB);
+    st36<T, LW>(lds, pair_O(p), O);
+    st3<T, LW>(lds, L_FC + 6 * A, ld3<T, LW>(lds, L_FC + 6 * A) + flA);
+    st3<T, LW>(lds, L_FC + 6 * A + 3, ld3<T, LW>(lds, L_FC + 6 * A + 3) + faA);
+    st3<T, LW>(lds, L_FC + 6 * B, ld3<T, LW>(lds, L_FC + 6 * B) + flB);
+    st3<T, LW>(lds, L_FC + 6 * B + 3, ld3<T, LW>(lds, L_FC + 6 * B + 3) + faB);
+  }
+  // ---- gradient  G = M (a - a0) - FC
+  T gn = T(0);
+  cfrc_max = T(0);
+#pragma unroll 1
+  for (int b = 0; b < 3; b++) {
+    V3<T> ez = ld3<T, LW>(lds, L_EZ + 3 * b);
+    V3<T> dl = ld3<T, LW>(lds, L_A + 6 * b) - ld3<T, LW>(lds, L_A0 + 6 * b);
+    V3<T> da = ld3<T, LW>(lds, L_A + 6 * b + 3) - ld3<T, LW>(lds, L_A0 + 6 * b + 3);
+    V3<T> fl = ld3<T, LW>(lds, L_FC + 6 * b), fa = ld3<T, LW>(lds, L_FC + 6 * b + 3);
+    V3<T> gl = P.mass * dl - fl;
+    V3<T> ga = inertia_mul(P, ez, da) - fa;
+    st3<T, LW>(lds, L_G + 6 * b, gl);
+    st3<T, LW>(lds, L_G + 6 * b + 3, ga);
+    gn += dot(gl, gl) + dot(ga, ga);
+    cfrc_max = max_(cfrc_max, max_(max_(abs_(fl.x), abs_(fl.y)), abs_(fl.z)));
+    cfrc_max = max_(cfrc_max, max_(max_(abs_(fa.x), abs_(fa.y)), abs_(fa.z)));
+  }
+  return gn;
+}
+
+// blocked Cholesky of the Hessian in LDS, then P = -H^-1 G (P = 0 for converged lanes)
+template <typename T, int LW> TGR_DEV void newton_direction(T* lds, unsigned cpl, bool conv) {
+  const bool c10 = cpl & 1u, c20 = cpl & 2u, c21in = cpl & 4u;
+  const bool c21 = c21in || (c10 && c20);  // fill-in
+  T L[21];
+  // column 0
+  ld21<T, LW>(lds, H_D(0), L);
+  chol6(L);
+  st21<T, LW>(lds, H_D(0), L);
+  if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); trsm6(O, L); st36<T, LW>(lds, H_O10, O); }
+  if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); trsm6(O, L); st36<T, LW>(lds, H_O20, O); }
+  // column 1
+  ld21<T, LW>(lds, H_D(1), L);
+  if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); syrk6(L, O); }
+  chol6(L);
+  st21<T, LW>(lds, H_D(1), L);
+  if (c21) {
+    T O21[36];
+    if (c21in) ld36<T, LW>(lds, H_O21, O21);
+    else {
+#pragma unroll
+      for (int i = 0; i < 36; i++) O21[i] = T(0);
+    }
+    if (c10 && c20) { T Oa[36], Ob[36]; ld36<T, LW>(lds, H_O20, Oa); ld36<T, LW>(lds, H_O10, Ob); gemm6(O21, Oa, Ob); }
+    trsm6(O21, L);
+    st36<T, LW>(lds, H_O21, O21);
+  }
+  // column 2
+  ld21<T, LW>(lds, H_D(2), L);
+  if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); syrk6(L, O); }
+  if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); syrk6(L, O); }
+  chol6(L);
+  st21<T, LW>(lds, H_D(2), L);
+  // ---- solve  L L^T x = G
+  T x0[6], x1[6], x2[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { x0[i] = lds[(L_G + i) * LW]; x1[i] = lds[(L_G + 6 + i) * LW]; x2[i] = lds[(L_G + 12 + i) * LW]; }
+  ld21<T, LW>(lds, H_D(0), L); fsolve6(L, x0);
+  if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); gemv_sub(O, x0, x1); }
+  if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); gemv_sub(O, x0, x2); }
+  ld21<T, LW>(lds, H_D(1), L); fsolve6(L, x1);
+  if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); gemv_sub(O, x1, x2); }
+  ld21<T, LW>(lds, H_D(2), L); fsolve6(L, x2);
+  bsolve6(L, x2);
+  if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); gemvT_sub(O, x2, x1); }
+  ld21<T, LW>(lds, H_D(1), L); bsolve6(L, x1);
+  if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); gemvT_sub(O, x2, x0); }
+  if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); gemvT_sub(O, x1, x0); }
+  ld21<T, LW>(lds, H_D(0), L); bsolve6(L, x0);
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    lds[(L_P + i) * LW] = conv ? T(0) : -x0[i];
+    lds[(L_P + 6 + i) * LW] = conv ? T(0) : -x1[i];
+    lds[(L_P + 12 + i) * LW] = conv ? T(0) : -x2[i];
+  }
+}
+
+// derivative of the cost along A + alpha P:  phi'(alpha), phi''(alpha)
+template <typename T, int LW>
+TGR_DEV void newton_dphi(const Params<T>& P, const T* lds, unsigned cpl, T alpha, T g1, T g2, T& d1, T& d2) {
+  d1 = g1 + alpha * g2; d2 = g2;
+#pragma unroll 1
+  for (int b = 0; b < 3; b++) {
+    V3<T> pl = ld3<T, LW>(lds, L_P + 6 * b), pa = ld3<T, LW>(lds, L_P + 6 * b + 3);
+    V3<T> yl = ld3<T, LW>(lds, L_A + 6 * b) + ld3<T, LW>(lds, L_BV + 6 * b) + alpha * pl;
+    V3<T> ya = ld3<T, LW>(lds, L_A + 6 * b + 3) + ld3<T, LW>(lds, L_BV + 6 * b + 3) + alpha * pa;
+#pragma unroll 1
+    for (int e = 0; e < 2; e++) {
+      Contact<T> c = load_floor<T, LW>(lds, 2 * b + e);
+      if (__any(c.active)) {
+        V3<T> jl = yl + cross(ya, c.rB);
+        jl.z += c.c0;
+        V3<T> ql = pl + cross(pa, c.rB);
+        Cone<T> o = cone_eval(P, c, jl, ya);
+        d1 -= dot(o.fl, ql) + dot(o.fa, pa);
+        T nl = ql.z, na = pa.z;
+        T gq = dot(o.gl, ql) + dot(o.ga, pa), wq = dot(o.wl, ql) + dot(o.wa, pa);
+        d2 += o.a1 * dot(ql, ql) + o.a2 * nl * nl + o.b1 * dot(pa, pa) + o.b2 * na * na + o.cg * gq * gq + o.cw * wq * wq;
+      }
+    }
+  }
+#pragma unroll 1
+  for (int p = 0; p < 3; p++) {
+    if (!((cpl >> p) & 1u)) continue;
+    const int A = pair_A(p), B = pair_B(p);
+    V3<T> plA = ld3<T, LW>(lds, L_P + 6 * A), paA = ld3<T, LW>(lds, L_P + 6 * A + 3);
+    V3<T> plB = ld3<T, LW>(lds, L_P + 6 * B), paB = ld3<T, LW>(lds, L_P + 6 * B + 3);
+    V3<T> ylA = ld3<T, LW>(lds, L_A + 6 * A) + ld3<T, LW>(lds, L_BV + 6 * A) + alpha * plA;
+    V3<T> yaA = ld3<T, LW>(lds, L_A + 6 * A + 3) + ld3<T, LW>(lds, L_BV + 6 * A + 3) + alpha * paA;
+    V3<T> ylB = ld3<T, LW>(lds, L_A + 6 * B) + ld3<T, LW>(lds, L_BV + 6 * B) + alpha * plB;
+    V3<T> yaB = ld3<T, LW>(lds, L_A + 6 * B + 3) + ld3<T, LW>(lds, L_BV + 6 * B + 3) + alpha * paB;
+#pragma unroll 1
+    for (int s = 0; s < 2; s++) {
+      Contact<T> c = load_pair<T, LW>(lds, 2 * p + s);
+      if (!__any(c.active)) continue;
+      V3<T> jl = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
+      V3<T> ja = yaB - yaA;
+      V3<T> ql = (plB + cross(paB, c.rB)) - (plA + cross(paA, c.rA));
+      V3<T> qa = paB - paA;
+      Cone<T> o = cone_eval(P, c, jl, ja);
+      d1 -= dot(o.fl, ql) + dot(o.fa, qa);
+      T nl = dot(c.n, ql), na = dot(c.n, qa);
+      T gq = dot(o.gl, ql) + dot(o.ga, qa), wq = dot(o.wl, ql) + dot(o.wa, qa);
+      d2 += o.a1 * dot(ql, ql) + o.a2 * nl * nl + o.b1 * dot(qa, qa) + o.b2 * na * na + o.cg * gq * gq + o.cw * wq * wq;
+    }
   }
 }
 
 // ------------------------------------------------------------------ the sub-step
-// lds: per-lane scratch, element k of lane l at lds[k * 64 + l]; needs >= 99 slots
-template <typename T>
-TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int lane, bool last, Lag<T>& lag) {
-  // ---- kinematics
-  Rot<T> R[3];
-#pragma unroll
-  for (int b = 0; b < 3; b++) {
-    normalize_quat(S.q[b]);
-    R[b] = quat_rot(S.q[b]);
-  }
-  if (last) {
+// lds: this lane's column base (lds_block + lane); needs L_TOTAL slots of pitch LW
+template <typename T, int LW>
+TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, bool last, Lag<T>& lag) {
+  const T im = rcp_(P.mass);
+  // ---- kinematics, tendons -> smooth wrench; Jacobian pieces parked in LDS
+  {
+    Rot<T> R[3];
 #pragma unroll
     for (int b = 0; b < 3; b++) {
-      lag.x[b] = S.x[b];
-      lag.z[b] = R[b].ez;
+      normalize_quat(S.q[b]);
+      R[b] = quat_rot(S.q[b]);
+      st3<T, LW>(lds, L_EZ + 3 * b, R[b].ez);
+      st3<T, LW>(lds, L_X + 3 * b, S.x[b]);
+      st3<T, LW>(lds, L_BV + 6 * b, P.B * S.v[b]);
+      st3<T, LW>(lds, L_BV + 6 * b + 3, P.B * S.w[b]);
+    }
+    if (last) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) lag.q[b][i] = S.q[b][i];
+      for (int b = 0; b < 3; b++) {
+        lag.x[b] = S.x[b];
+        lag.z[b] = R[b].ez;
+#pragma unroll
+        for (int i = 0; i < 4; i++) lag.q[b][i] = S.q[b][i];
+      }
+    }
+    V3<T> F[3], Tq[3];
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      F[b] = mk(T(0), T(0), -P.mass * P.grav);
+      // gyroscopic: -w x (I w) = -(Izz-Ixx)(z.w)(w x z)
+      T zw = dot(R[b].ez, S.w[b]);
+      Tq[b] = (-(P.Izz - P.Ixx) * zw) * cross(S.w[b], R[b].ez);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int ba = Tab::TEN[t][0], sa = Tab::TEN[t][1], bb = Tab::TEN[t][2], sb = Tab::TEN[t][3];
+      V3<T> ra = rot_apply(R[ba], mk(T(Tab::S[sa][0]) * P.site_off, T(Tab::S[sa][1]) * P.site_off, T(Tab::S[sa][2]) * P.site_z));
+      V3<T> rb = rot_apply(R[bb], mk(T(Tab::S[sb][0]) * P.site_off, T(Tab::S[sb][1]) * P.site_off, T(Tab::S[sb][2]) * P.site_z));
+      V3<T> dif = (S.x[bb] + rb) - (S.x[ba] + ra);
+      T L2 = dot(dif, dif);
+      T iL = rsqrt_(max_(L2, T(1e-30)));
+      T L = L2 * iL;
+      V3<T> u = iL * dif;
+      V3<T> va = S.v[ba] + cross(S.w[ba], ra), vb = S.v[bb] + cross(S.w[bb], rb);
+      T Ld = dot(u, vb - va);
+      T f, damp;
+      if (t < 6) {
+        T cc = clamp_(S.ctrl[t], P.ctrl_lo, P.ctrl_hi);
+        T fr = P.gain * cc + P.bias0 + P.bias1 * L + P.bias2 * Ld;
+        f = clamp_(fr, P.force_lo, P.force_hi);
+        bool clamped = (f <= P.force_lo) || (f >= P.force_hi);
+        damp = -P.bias2;
+        if (P.skip_clamped && clamped) damp = T(0);
+        // passive part of an actuated tendon (zero in the flat model)
+        f += -P.ten_k[t] * (L - P.ten_L0[t]) - P.ten_b[t] * Ld;
+        damp += P.ten_b[t];
+      } else {
+        f = -P.ten_k[t] * (L - P.ten_L0[t]) - P.ten_b[t] * Ld;
+        damp = P.ten_b[t];
+      }
+      if (last) lag.tenL[t] = L;
+      V3<T> fu = f * u;
+      V3<T> ma = cross(ra, u), mb = cross(rb, u);
+      F[bb] = F[bb] + fu; Tq[bb] = Tq[bb] + f * mb;
+      F[ba] = F[ba] - fu; Tq[ba] = Tq[ba] - f * ma;
+      st3<T, LW>(lds, L_TEN + 10 * t, u);
+      st3<T, LW>(lds, L_TEN + 10 * t + 3, ma);
+      st3<T, LW>(lds, L_TEN + 10 * t + 6, mb);
+      lds[(L_TEN + 10 * t + 9) * LW] = sqrt_(P.h * damp);
+    }
+    // unconstrained acceleration
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      st3<T, LW>(lds, L_A0 + 6 * b, im * F[b]);
+      st3<T, LW>(lds, L_A0 + 6 * b + 3, inv_inertia(P, R[b].ez, Tq[b]));
+    }
+    // floor contacts: cap k of bar k/2
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int b = k / 2;
+      T sg = (k % 2 == 0) ? P.bar_half : -P.bar_half;
+      V3<T> arm = sg * R[b].ez;
+      T dist = S.x[b].z + arm.z - P.cap_r;
+      Contact<T> c;
+      contact_params(P, dist, 1, c);
+      const int s = L_CF + 6 * k;
+      lds[s * LW] = arm.x; lds[(s + 1) * LW] = arm.y; lds[(s + 2) * LW] = arm.z - (P.cap_r + T(0.5) * dist);
+      lds[(s + 3) * LW] = c.c0; lds[(s + 4) * LW] = c.Dn; lds[(s + 5) * LW] = dist < T(0) ? T(1) : T(0);
     }
   }
-  // ---- tendons: smooth wrench per bar, Jacobian pieces parked in LDS
-  V3<T> F[3], Tq[3];
-#pragma unroll
-  for (int b = 0; b < 3; b++) {
-    F[b] = mk(T(0), T(0), -P.mass * P.grav);
-    // gyroscopic: -w x (I w) = -(Izz-Ixx)(z.w)(w x z)
-    T zw = dot(R[b].ez, S.w[b]);
-    Tq[b] = (-(P.Izz - P.Ixx) * zw) * cross(S.w[b], R[b].ez);
-  }
-#pragma unroll
-  for (int t = 0; t < 9; t++) {
-    constexpr int dummy = 0; (void)dummy;
-    const int ba = Tab::TEN[t][0], sa = Tab::TEN[t][1], bb = Tab::TEN[t][2], sb = Tab::TEN[t][3];
-    V3<T> ra = rot_apply(R[ba], mk(T(Tab::S[sa][0]) * P.site_off, T(Tab::S[sa][1]) * P.site_off, T(Tab::S[sa][2]) * P.site_z));
-    V3<T> rb = rot_apply(R[bb], mk(T(Tab::S[sb][0]) * P.site_off, T(Tab::S[sb][1]) * P.site_off, T(Tab::S[sb][2]) * P.site_z));
-    V3<T> dif = (S.x[bb] + rb) - (S.x[ba] + ra);
-    T L2 = dot(dif, dif);
-    T iL = rsqrt_(max_(L2, T(1e-30)));
-    T L = L2 * iL;
-    V3<T> u = iL * dif;
-    V3<T> va = S.v[ba] + cross(S.w[ba], ra), vb = S.v[bb] + cross(S.w[bb], rb);
-    T Ld = dot(u, vb - va);
-    T f, damp;
-    if (t < 6) {
-      T cc = clamp_(S.ctrl[t], P.ctrl_lo, P.ctrl_hi);
-      T fr = P.gain * cc + P.bias0 + P.bias1 * L + P.bias2 * Ld;
-      f = clamp_(fr, P.force_lo, P.force_hi);
-      bool clamped = (f <= P.force_lo) || (f >= P.force_hi);
-      damp = -P.bias2;
-      if (P.skip_clamped && clamped) damp = T(0);
-      // passive part of an actuated tendon (zero in the flat model)
-      f += -P.ten_k[t] * (L - P.ten_L0[t]) - P.ten_b[t] * Ld;
-      damp += P.ten_b[t];
-    } else {
-      f = -P.ten_k[t] * (L - P.ten_L0[t]) - P.ten_b[t] * Ld;
-      damp = P.ten_b[t];
-    }
-    if (last) lag.tenL[t] = L;
-    V3<T> fu = f * u;
-    V3<T> ma = cross(ra, u), mb = cross(rb, u);
-    F[bb] = F[bb] + fu; Tq[bb] = Tq[bb] + f * mb;
-    F[ba] = F[ba] - fu; Tq[ba] = Tq[ba] - f * ma;
-    T sc = sqrt_(P.h * damp);
-    T* p = lds + (t * 10) * 64 + lane;
-    p[0 * 64] = u.x; p[1 * 64] = u.y; p[2 * 64] = u.z;
-    p[3 * 64] = ma.x; p[4 * 64] = ma.y; p[5 * 64] = ma.z;
-    p[6 * 64] = mb.x; p[7 * 64] = mb.y; p[8 * 64] = mb.z;
-    p[9 * 64] = sc;
-  }
-  // ---- unconstrained acceleration
-  V3<T> sl[3], sa_[3];
-  T im = rcp_(P.mass);
-#pragma unroll
-  for (int b = 0; b < 3; b++) {
-    sl[b] = im * F[b];
-    sa_[b] = inv_inertia(P, R[b].ez, Tq[b]);
-  }
-  // ---- contacts
-  Contact<T> C[NSLOT];
+  // ---- bar-bar contacts
   int dropped = 0;
+  bool any_contact = false;
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const int b = k / 2;
-    T sg = (k % 2 == 0) ? P.bar_half : -P.bar_half;
-    V3<T> arm = sg * R[b].ez;
-    T cz = S.x[b].z + arm.z;
-    T dist = cz - P.cap_r;
-    C[k].active = dist < T(0);
-    C[k].n = mk(T(0), T(0), T(1));
-    C[k].rA = mk(T(0), T(0), T(0));
-    C[k].rB = mk(arm.x, arm.y, arm.z - (P.cap_r + T(0.5) * dist));
-    contact_params(P, dist, 1, C[k]);
+  for (int k = 0; k < 6; k++) any_contact = any_contact || (lds[(L_CF + 6 * k + 5) * LW] != T(0));
+#pragma unroll 1
+  for (int p = 0; p < 3; p++) {
+    const int A = pair_A(p), B = pair_B(p);
+    Contact<T> c0, c1;
+    bar_pair_contacts(P, ld3<T, LW>(lds, L_X + 3 * A), ld3<T, LW>(lds, L_EZ + 3 * A), ld3<T, LW>(lds, L_X + 3 * B),
+                      ld3<T, LW>(lds, L_EZ + 3 * B), c0, c1, dropped);
+    store_pair<T, LW>(lds, 2 * p, c0);
+    store_pair<T, LW>(lds, 2 * p + 1, c1);
+    any_contact = any_contact || c0.active || c1.active;
   }
-  bar_pair_contacts(P, S.x[0], R[0].ez, S.x[1], R[1].ez, C[6], C[7], dropped);
-  bar_pair_contacts(P, S.x[0], R[0].ez, S.x[2], R[2].ez, C[8], C[9], dropped);
-  bar_pair_contacts(P, S.x[1], R[1].ez, S.x[2], R[2].ez, C[10], C[11], dropped);
   if (last) lag.overflow = dropped;
 
   // ---- Newton on  1/2 (a-a0)^T M (a-a0) + sum_c s_c( J (a + B v) + c0 n )
-  // y = a + B v is what every contact row sees
-  V3<T> al[3], aa[3];
-  bool any_contact = false;
+  // start from last sub-step's solution where there are contacts, from a0 otherwise (the optimum is unique)
 #pragma unroll
-  for (int k = 0; k < NSLOT; k++) any_contact = any_contact || C[k].active;
-
-  auto total_cost = [&](const V3<T>* xl, const V3<T>* xa) -> T {
-    T cost = T(0);
-    V3<T> yl[3], ya[3];
-#pragma unroll
-    for (int b = 0; b < 3; b++) {
-      V3<T> dl = xl[b] - sl[b], da = xa[b] - sa_[b];
-      cost += T(0.5) * (P.mass * dot(dl, dl) + dot(da, inertia_mul(P, R[b].ez, da)));
-      yl[b] = xl[b] + P.B * S.v[b];
-      ya[b] = xa[b] + P.B * S.w[b];
-    }
-#define TGR_SLOT_COST(K)                                                \
-    if (__any(C[K].active)) {                                           \
-      V3<T> jl, ja; slot_jar<T, K>(C[K], yl, ya, jl, ja);               \
-      jl = jl + C[K].c0 * C[K].n;                                       \
-      cost += cone_eval<T, false>(P, C[K], jl, ja).cost;                \
-    }
-    TGR_SLOT_COST(0) TGR_SLOT_COST(1) TGR_SLOT_COST(2) TGR_SLOT_COST(3) TGR_SLOT_COST(4) TGR_SLOT_COST(5)
-    TGR_SLOT_COST(6) TGR_SLOT_COST(7) TGR_SLOT_COST(8) TGR_SLOT_COST(9) TGR_SLOT_COST(10) TGR_SLOT_COST(11)
-#undef TGR_SLOT_COST
-    return cost;
-  };
-
-  // warm start: the cheaper of last step's solution and the unconstrained acceleration
-  {
-    T cw = total_cost(S.al, S.aa);
-    T cs = total_cost(sl, sa_);
-    bool usew = cw < cs;
-#pragma unroll
-    for (int b = 0; b < 3; b++) {
-      al[b] = mk(usew ? S.al[b].x : sl[b].x, usew ? S.al[b].y : sl[b].y, usew ? S.al[b].z : sl[b].z);
-      aa[b] = mk(usew ? S.aa[b].x : sa_[b].x, usew ? S.aa[b].y : sa_[b].y, usew ? S.aa[b].z : sa_[b].z);
-    }
+  for (int b = 0; b < 3; b++) {
+    V3<T> l0 = ld3<T, LW>(lds, L_A0 + 6 * b), a0 = ld3<T, LW>(lds, L_A0 + 6 * b + 3);
+    st3<T, LW>(lds, L_A + 6 * b, sel(any_contact, S.al[b], l0));
+    st3<T, LW>(lds, L_A + 6 * b + 3, sel(any_contact, S.aa[b], a0));
   }
-
-  V3<T> fcl[3], fca[3];  // constraint wrench per bar (J^T f)
-  T cfrc_max = T(0);
   const T scale = rcp_((T(3) * P.mass + T(2) * P.Ixx + P.Izz) * T(1.0 / 6.0) * T(18));
   bool conv = !any_contact;
+  T cfrc_max = T(0);
+  unsigned cpl = 0u;
+  int n_it = 0, n_ls = 0;
+#pragma unroll 1
   for (int it = 0;; it++) {
-    // ---------- evaluate gradient / Hessian / forces at (al, aa)
-    T* H = lds + 92 * 64 + lane;  // 18x18 lower triangle lives in LDS, [entry][lane]
-#pragma unroll
-    for (int i = 0; i < 171; i++) H[64 * i] = T(0);
-    T g[18];
-    V3<T> yl[3], ya[3];
-#pragma unroll
-    for (int b = 0; b < 3; b++) {
-      V3<T> dl = al[b] - sl[b], da = aa[b] - sa_[b];
-      V3<T> Ida = inertia_mul(P, R[b].ez, da);
-      g[6 * b + 0] = P.mass * dl.x; g[6 * b + 1] = P.mass * dl.y; g[6 * b + 2] = P.mass * dl.z;
-      g[6 * b + 3] = Ida.x; g[6 * b + 4] = Ida.y; g[6 * b + 5] = Ida.z;
-      yl[b] = al[b] + P.B * S.v[b];
-      ya[b] = aa[b] + P.B * S.w[b];
-      fcl[b] = mk(T(0), T(0), T(0)); fca[b] = fcl[b];
-      // mass block
-      V3<T> z = R[b].ez;
-      T dI = P.Izz - P.Ixx;
-      H[64 * hidx(6 * b + 0, 6 * b + 0)] = P.mass; H[64 * hidx(6 * b + 1, 6 * b + 1)] = P.mass; H[64 * hidx(6 * b + 2, 6 * b + 2)] = P.mass;
-      H[64 * hidx(6 * b + 3, 6 * b + 3)] = P.Ixx + dI * z.x * z.x;
-      H[64 * hidx(6 * b + 4, 6 * b + 3)] = dI * z.y * z.x;
-      H[64 * hidx(6 * b + 4, 6 * b + 4)] = P.Ixx + dI * z.y * z.y;
-      H[64 * hidx(6 * b + 5, 6 * b + 3)] = dI * z.z * z.x;
-      H[64 * hidx(6 * b + 5, 6 * b + 4)] = dI * z.z * z.y;
-      H[64 * hidx(6 * b + 5, 6 * b + 5)] = P.Ixx + dI * z.z * z.z;
-    }
-    cfrc_max = T(0);
-    V3<T> wf[3], wt[3];  // cfrc_ext accumulators
-#pragma unroll
-    for (int b = 0; b < 3; b++) { wf[b] = mk(T(0), T(0), T(0)); wt[b] = wf[b]; }
-
-#define TGR_SLOT_EVAL(K)                                                                         \
-    if (__any(C[K].active)) {                                                                    \
-      constexpr int A_ = SlotBodies<K>::A, B_ = SlotBodies<K>::B;                                \
-      constexpr int A0 = A_ < 0 ? 0 : A_;                                                        \
-      V3<T> jl, ja; slot_jar<T, K>(C[K], yl, ya, jl, ja);                                        \
-      jl = jl + C[K].c0 * C[K].n;                                                                \
-      Cone<T> o = cone_eval<T, true>(P, C[K], jl, ja);                                           \
-      V3<T> tB = cross(C[K].rB, o.fl) + o.fa;                                                    \
-      fcl[B_] = fcl[B_] + o.fl; fca[B_] = fca[B_] + tB;                                          \
-      wf[B_] = wf[B_] + o.fl; wt[B_] = wt[B_] + tB;                                              \
-      T uB[6], uA[6];                                                                            \
-      if (A_ >= 0) {                                                                             \
-        V3<T> tA = cross(C[K].rA, o.fl) + o.fa;                                                  \
-        fcl[A0] = fcl[A0] - o.fl; fca[A0] = fca[A0] - tA;                                        \
-        wf[A0] = wf[A0] - o.fl; wt[A0] = wt[A0] - tA;                                            \
-      }                                                                                          \
-      h_iso<T, B_, B_, 64>(H, T(1), o.a1, o.b1, C[K].rB, C[K].rB);                                   \
-      if (A_ >= 0) {                                                                             \
-        h_iso<T, A0, A0, 64>(H, T(1), o.a1, o.b1, C[K].rA, C[K].rA);                                 \
-        h_iso<T, B_, A0, 64>(H, T(-1), o.a1, o.b1, C[K].rB, C[K].rA);                                \
-      }                                                                                          \
-      V3<T> zero3 = mk(T(0), T(0), T(0));                                                        \
-      const V3<T> cls[4] = {C[K].n, zero3, o.gl, o.wl};                                          \
-      const V3<T> cas[4] = {zero3, C[K].n, o.ga, o.wa};                                          \
-      const T cf[4] = {o.a2, o.b2, o.cg, o.cw};                                                  \
-      _Pragma("unroll") for (int r = 0; r < 4; r++) {                                            \
-        body_vec(cls[r], cas[r], C[K].rB, T(1), uB);                                             \
-        h_rank1_self<T, B_, 64>(H, cf[r], uB);                                                       \
-        if (A_ >= 0) {                                                                           \
-          body_vec(cls[r], cas[r], C[K].rA, T(-1), uA);                                          \
-          h_rank1_self<T, A0, 64>(H, cf[r], uA);                                                     \
-          h_rank1_cross<T, A0, (A_ >= 0 ? B_ : 1), 64>(H, cf[r], uA, uB);                            \
-        }                                                                                        \
-      }                                                                                          \
-    }
-    TGR_SLOT_EVAL(0) TGR_SLOT_EVAL(1) TGR_SLOT_EVAL(2) TGR_SLOT_EVAL(3) TGR_SLOT_EVAL(4) TGR_SLOT_EVAL(5)
-    TGR_SLOT_EVAL(6) TGR_SLOT_EVAL(7) TGR_SLOT_EVAL(8) TGR_SLOT_EVAL(9) TGR_SLOT_EVAL(10) TGR_SLOT_EVAL(11)
-#undef TGR_SLOT_EVAL
-#pragma unroll
-    for (int b = 0; b < 3; b++) {
-      g[6 * b + 0] -= fcl[b].x; g[6 * b + 1] -= fcl[b].y; g[6 * b + 2] -= fcl[b].z;
-      g[6 * b + 3] -= fca[b].x; g[6 * b + 4] -= fca[b].y; g[6 * b + 5] -= fca[b].z;
-      cfrc_max = max_(cfrc_max, max_(max_(abs_(wf[b].x), abs_(wf[b].y)), abs_(wf[b].z)));
-      cfrc_max = max_(cfrc_max, max_(max_(abs_(wt[b].x), abs_(wt[b].y)), abs_(wt[b].z)));
-    }
-    T gn = T(0);
-#pragma unroll
-    for (int i = 0; i < 18; i++) gn += g[i] * g[i];
+    T gn = newton_assemble<T, LW>(P, lds, cpl, cfrc_max);
     conv = conv || !(scale * sqrt_(gn) >= P.tol);
     if (__all(conv) || it >= P.max_iter) break;
-
-    // ---------- Newton direction
-    chol_factor<T, 18, 64>(H);
-    T p[18];
-#pragma unroll
-    for (int i = 0; i < 18; i++) p[i] = conv ? T(0) : -g[i];
-    chol_solve<T, 18, 64>(H, p);
-    V3<T> pl[3], pa[3];
-#pragma unroll
-    for (int b = 0; b < 3; b++) { pl[b] = mk(p[6 * b], p[6 * b + 1], p[6 * b + 2]); pa[b] = mk(p[6 * b + 3], p[6 * b + 4], p[6 * b + 5]); }
-
-    // ---------- line search on the convex 1-d restriction (safeguarded Newton on phi')
-    T g1 = T(0), g2 = T(0);  // Gauss part: phi_g'(alpha) = g1 + alpha g2
-#pragma unroll
+    n_it++;
+    newton_direction<T, LW>(lds, cpl, conv);
+    // Gauss part of the line derivative  phi_g'(alpha) = g1 + alpha g2 ;  d0 = G.P
+    T g1 = T(0), g2 = T(0), d0 = T(0);
+#pragma unroll 1
     for (int b = 0; b < 3; b++) {
-      V3<T> dl = al[b] - sl[b], da = aa[b] - sa_[b];
-      V3<T> Ipa = inertia_mul(P, R[b].ez, pa[b]);
-      g1 += P.mass * dot(pl[b], dl) + dot(Ipa, da);
-      g2 += P.mass * dot(pl[b], pl[b]) + dot(Ipa, pa[b]);
+      V3<T> ez = ld3<T, LW>(lds, L_EZ + 3 * b);
+      V3<T> pl = ld3<T, LW>(lds, L_P + 6 * b), pa = ld3<T, LW>(lds, L_P + 6 * b + 3);
+      V3<T> dl = ld3<T, LW>(lds, L_A + 6 * b) - ld3<T, LW>(lds, L_A0 + 6 * b);
+      V3<T> da = ld3<T, LW>(lds, L_A + 6 * b + 3) - ld3<T, LW>(lds, L_A0 + 6 * b + 3);
+      V3<T> Ipa = inertia_mul(P, ez, pa);
+      g1 += P.mass * dot(pl, dl) + dot(Ipa, da);
+      g2 += P.mass * dot(pl, pl) + dot(Ipa, pa);
+      d0 += dot(pl, ld3<T, LW>(lds, L_G + 6 * b)) + dot(pa, ld3<T, LW>(lds, L_G + 6 * b + 3));
     }
-    auto dphi = [&](T alpha, T& d1, T& d2) {
-      d1 = g1 + alpha * g2; d2 = g2;
-      V3<T> xl[3], xa[3];
-#pragma unroll
-      for (int b = 0; b < 3; b++) { xl[b] = yl[b] + alpha * pl[b]; xa[b] = ya[b] + alpha * pa[b]; }
-#define TGR_SLOT_LS(K)                                                                           \
-      if (__any(C[K].active)) {                                                                  \
-        V3<T> jl, ja, ql, qa;                                                                    \
-        slot_jar<T, K>(C[K], xl, xa, jl, ja);                                                    \
-        jl = jl + C[K].c0 * C[K].n;                                                              \
-        slot_jar<T, K>(C[K], pl, pa, ql, qa);                                                    \
-        Cone<T> o = cone_eval<T, true>(P, C[K], jl, ja);                                         \
-        d1 -= dot(o.fl, ql) + dot(o.fa, qa);                                                     \
-        T nl = dot(C[K].n, ql), na = dot(C[K].n, qa);                                            \
-        T gq = dot(o.gl, ql) + dot(o.ga, qa), wq = dot(o.wl, ql) + dot(o.wa, qa);                \
-        d2 += o.a1 * dot(ql, ql) + o.a2 * nl * nl + o.b1 * dot(qa, qa) + o.b2 * na * na +        \
-              o.cg * gq * gq + o.cw * wq * wq;                                                   \
-      }
-      TGR_SLOT_LS(0) TGR_SLOT_LS(1) TGR_SLOT_LS(2) TGR_SLOT_LS(3) TGR_SLOT_LS(4) TGR_SLOT_LS(5)
-      TGR_SLOT_LS(6) TGR_SLOT_LS(7) TGR_SLOT_LS(8) TGR_SLOT_LS(9) TGR_SLOT_LS(10) TGR_SLOT_LS(11)
-#undef TGR_SLOT_LS
-    };
-    T d0, h0;
-    dphi(T(0), d0, h0);
+    // mujoco's second stopping rule: expected improvement of this step (|d0| / 2) below tolerance
+    conv = conv || !(scale * T(0.5) * abs_(d0) >= P.tol);
+    // exact line search: safeguarded Newton on phi'
     T alpha = T(1), lo = T(0), hi = T(-1);
-    bool ls_done = conv || !(d0 < T(0));
+    conv = conv || !(d0 < T(0));  // no descent left at working precision
+    bool ls_done = conv;
     if (ls_done) alpha = T(0);
+    T gtol = P.ls_tol * abs_(d0);
+#pragma unroll 1
     for (int ls = 0; ls < P.ls_iter; ls++) {
       if (__all(ls_done)) break;
       T d1, d2;
-      dphi(alpha, d1, d2);
-      bool ok = abs_(d1) <= P.ls_tol * abs_(d0);
+      n_ls++;
+      newton_dphi<T, LW>(P, lds, cpl, alpha, g1, g2, d1, d2);
+      bool ok = abs_(d1) <= gtol;
       if (!ls_done) {
         if (ok) ls_done = true;
         else {
@@ -731,26 +997,26 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int lane, bool last,
           T na = d2 > T(0) ? alpha - d1 * rcp_(d2) : T(-1);
           if (hi < T(0)) { if (!(na > lo) || na > T(10) * (lo + T(1))) na = T(2) * alpha + T(1e-3); }
           else if (!(na > lo) || !(na < hi)) na = T(0.5) * (lo + hi);
+          if (hi > T(0) && (hi - lo) <= T(1e-6) * hi) ls_done = true;
           alpha = na;
         }
       }
     }
-#ifdef TGR_DEBUG_ENV
-    if (blockIdx.x * 64 + lane == TGR_DEBUG_ENV) printf("it %d gn %.3e d0 %.3e alpha %.6f lo %.4f hi %.4f conv %d al0 %.5f\n", it, (double)sqrt_(gn), (double)d0, (double)alpha, (double)lo, (double)hi, (int)conv, (double)al[0].x);
-#endif
 #pragma unroll
-    for (int b = 0; b < 3; b++) { al[b] = al[b] + alpha * pl[b]; aa[b] = aa[b] + alpha * pa[b]; }
+    for (int i = 0; i < 18; i++) lds[(L_A + i) * LW] += alpha * lds[(L_P + i) * LW];
   }
   if (last) lag.cfrc_absmax = cfrc_max;
+  lag.n_it += n_it; lag.n_ls += n_ls; lag.n_unconv += conv ? 0 : 1;
 #pragma unroll
-  for (int b = 0; b < 3; b++) { S.al[b] = al[b]; S.aa[b] = aa[b]; }
+  for (int b = 0; b < 3; b++) { S.al[b] = ld3<T, LW>(lds, L_A + 6 * b); S.aa[b] = ld3<T, LW>(lds, L_A + 6 * b + 3); }
 
   // ---- implicitfast: (M + h sum_t b_t J_t J_t^T) a_new = F_smooth + F_constraint   (Woodbury over 9 tendons)
-  V3<T> yl[3], ya[3];
+  V3<T> yl[3], ya[3], ez[3];
 #pragma unroll
   for (int b = 0; b < 3; b++) {
-    yl[b] = im * (F[b] + fcl[b]);
-    ya[b] = inv_inertia(P, R[b].ez, Tq[b] + fca[b]);
+    ez[b] = ld3<T, LW>(lds, L_EZ + 3 * b);
+    yl[b] = ld3<T, LW>(lds, L_A0 + 6 * b) + im * ld3<T, LW>(lds, L_FC + 6 * b);
+    ya[b] = ld3<T, LW>(lds, L_A0 + 6 * b + 3) + inv_inertia(P, ez[b], ld3<T, LW>(lds, L_FC + 6 * b + 3));
   }
   {
     // tendon Jacobians back from LDS, scaled by sqrt(h b_t);  W = M^-1 J
@@ -759,13 +1025,12 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int lane, bool last,
 #pragma unroll
     for (int t = 0; t < 9; t++) {
       const int ba = Tab::TEN[t][0], bb = Tab::TEN[t][2];
-      const T* p = lds + (t * 10) * 64 + lane;
-      T sc = p[9 * 64];
-      u[t] = sc * mk(p[0 * 64], p[1 * 64], p[2 * 64]);
-      ma[t] = sc * mk(p[3 * 64], p[4 * 64], p[5 * 64]);
-      mb[t] = sc * mk(p[6 * 64], p[7 * 64], p[8 * 64]);
-      wa_[t] = inv_inertia(P, R[ba].ez, ma[t]);
-      wb_[t] = inv_inertia(P, R[bb].ez, mb[t]);
+      T sc = lds[(L_TEN + 10 * t + 9) * LW];
+      u[t] = sc * ld3<T, LW>(lds, L_TEN + 10 * t);
+      ma[t] = sc * ld3<T, LW>(lds, L_TEN + 10 * t + 3);
+      mb[t] = sc * ld3<T, LW>(lds, L_TEN + 10 * t + 6);
+      wa_[t] = inv_inertia(P, ez[ba], ma[t]);
+      wb_[t] = inv_inertia(P, ez[bb], mb[t]);
       // z_t = J_t^T y  with J_t = (A: -u, -ma ; B: +u, +mb)
       zt[t] = dot(u[t], yl[bb] - yl[ba]) + dot(mb[t], ya[bb]) - dot(ma[t], ya[ba]);
     }
@@ -781,7 +1046,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int lane, bool last,
         if (bi == bj) s += im * dot(u[i], u[j]) + dot(mb[i], wb_[j]);
         if (ai == bj) s -= im * dot(u[i], u[j]) + dot(ma[i], wb_[j]);
         if (bi == aj) s -= im * dot(u[i], u[j]) + dot(mb[i], wa_[j]);
-        Sm[hidx(i, j)] = s;
+        Sm[tri(i, j)] = s;
       }
     chol_factor<T, 9>(Sm);
     chol_solve<T, 9>(Sm, zt);

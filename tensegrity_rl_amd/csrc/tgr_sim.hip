@@ -28,9 +28,8 @@ enum : int {
   F_QPOS = 0, F_QVEL = 21, F_WARM = 39, F_CTRL = 57, F_XYLAG = 63, F_PSILAG = 65, F_RESETPSI = 66,
   F_EPRET = 67, F_WAYPT = 68, F_ORI = 70, F_VCMD = 72, NF = 75
 };
-enum : int { I_STEPNUM = 0, I_ELAPSED, I_RINGLEN, I_RINGHEAD, I_EPISODE, NI };
+enum : int { I_STEPNUM = 0, I_ELAPSED, I_RINGLEN, I_RINGHEAD, I_EPISODE, I_PHASE, I_SRC, I_SRCEP, NI };
 constexpr int RING = 32;
-constexpr int LDS_SLOTS = 92 + 171;
 constexpr double PI = 3.14159265358979323846;
 
 template <typename T> struct EnvCfg {
@@ -44,11 +43,13 @@ template <typename T> struct EnvCfg {
 template <typename T> struct KArgs {
   Params<T> P;
   EnvCfg<T> E;
-  int n;
+  int n, m;  // live envs, total lanes (live + donors)
   T* st; int* ist; T* ring;
   const float* actions;
   T* obs; T* reward; uint8_t* terminated; uint8_t* truncated; T* terminal_obs; T* info;
-  int* list_count; int* list;  // envs to (re)settle
+  int* list_count; int* list; int* rlist;  // envs to (re)settle / ready donors
+  uint8_t* doneflag;
+  T* dobs;  // reset observations of the donors [m-n][D]
   unsigned long long* counters;
   int auto_reset;
   T* obs_reset;  // where the settle kernel writes reset observations ([N][D]) or null
@@ -292,183 +293,334 @@ TGR_DEV StepOut<T> env_epilogue(const Params<T>& P, const EnvCfg<T>& E, const Si
   return o;
 }
 
+// ------------------------------------------------------------------ lanes, roles, keys
+// lanes [0, n)  : live environments (slot i == lane i)
+// lanes [n, m)  : donors.  A donor settles a fresh episode (reset_model's 50 control periods) inside the SAME step
+//                 launches that advance the live lanes; when a live env finishes, match_kernel hands it a ready
+//                 donor state and the donor starts over.  Nothing ever waits for a settle.
+enum : int { PH_LIVE = -1, PH_READY = 0, PH_INIT = -2 };  // > 0: settle periods still to run
+
+template <typename T> TGR_DEV unsigned long long lane_key(const EnvCfg<T>& E, int n, int lane) {
+  return lane < n ? E.first_env_id + (unsigned long long)lane
+                  : (1ull << 62) + E.first_env_id * 8ull + (unsigned long long)(lane - n);
+}
+
+// start pose of an episode: yaw-randomised table pose, zero velocity, random tendon targets
+template <typename T> TGR_DEV void init_episode(const EnvCfg<T>& E, unsigned long long key, unsigned long long episode, Sim<T>& S) {
+  Draws dr = reset_draws(E, key, episode);
+  double c = cos(dr.theta), s = sin(dr.theta), ch = cos(0.5 * dr.theta), sh = sin(0.5 * dr.theta);
+  const double* q0 = E.env_kind == TGR_ENV_TR ? c_rolling[dr.pose] : c_qpos0;
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    const double* q = q0 + 7 * b;
+    S.x[b] = mk(T(c * q[0] - s * q[1]), T(s * q[0] + c * q[1]), T(q[2]));
+    double w = q[3], x = q[4], y = q[5], z = q[6];
+    S.q[b][0] = T(ch * w - sh * z); S.q[b][1] = T(ch * x - sh * y); S.q[b][2] = T(ch * y + sh * x); S.q[b][3] = T(ch * z + sh * w);
+    S.v[b] = mk(T(0), T(0), T(0)); S.w[b] = S.v[b]; S.al[b] = S.v[b]; S.aa[b] = S.v[b];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) S.ctrl[i] = T(dr.tendons[i]);
+}
+
+template <typename T> TGR_DEV int settle_total(const EnvCfg<T>& E) {
+  // tr_env turn: reward_delay_steps extra full env steps after the 50 settle periods (tr_env.py:864-866)
+  return 50 + ((E.env_kind == TGR_ENV_TR && E.action == TGR_ACT_TURN) ? E.reward_delay_steps : 0);
+}
+
+// bookkeeping after settle period `st` (0-based) of reset_model(); returns true when the episode is ready
+template <typename T>
+TGR_DEV void settle_period_done(const Params<T>& P, const EnvCfg<T>& E, const Lag<T>& lag, int st, RingRef<T>& ring, int& step_num,
+                                T& reset_psi) {
+  V3<T> cap[6], l, r;
+  caps_of(P, lag, cap);
+  left_right(cap, l, r);
+  if (st == 49) reset_psi = atan2_(-(l.x - r.x), l.y - r.y);
+  const bool turn = E.action == TGR_ACT_TURN;
+  bool env_step = (E.env_kind == TGR_ENV_TENSEGRITY) || st >= 50;  // settling through self.step() vs do_simulation()
+  if (env_step && turn) {
+    T psi = E.env_kind == TGR_ENV_TENSEGRITY ? atan2_(r.y - l.y, r.x - l.x) : atan2_(-(l.x - r.x), l.y - r.y);
+    ring_push(ring, psi);
+    if (ring.len > E.reward_delay_steps) (void)ring_pop(ring);
+  }
+  if (st >= 50) step_num += 1;
+}
+
+// what reset_model() leaves behind besides qpos/qvel
+template <typename T>
+TGR_DEV void store_reset_aux(const Params<T>& P, T* st, int* ist, int m, int e, const Lag<T>& lag, T reset_psi, int step_num,
+                             const RingRef<T>& ring) {
+  T third = T(1.0 / 3.0);
+  st[(F_XYLAG + 0) * m + e] = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x);
+  st[(F_XYLAG + 1) * m + e] = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
+  V3<T> cap[6], l, r;
+  caps_of(P, lag, cap);
+  left_right(cap, l, r);
+  st[F_PSILAG * m + e] = atan2_(-(l.x - r.x), l.y - r.y);
+  st[F_RESETPSI * m + e] = reset_psi;
+  st[F_EPRET * m + e] = T(0);
+  ist[I_STEPNUM * m + e] = step_num;
+  ist[I_ELAPSED * m + e] = 0;
+  ist[I_RINGLEN * m + e] = ring.len; ist[I_RINGHEAD * m + e] = ring.head;
+}
+
 // ------------------------------------------------------------------ step kernel
-template <typename T> __global__ __launch_bounds__(64) void step_kernel(KArgs<T> k) {
-  __shared__ T lds[LDS_SLOTS * 64];
+template <typename T, int LW> __global__ __launch_bounds__(LW) void step_kernel(KArgs<T> k) {
+  __shared__ T lds_all[L_TOTAL * LW];
   const int lane = threadIdx.x;
-  const int gid = blockIdx.x * 64 + lane;
-  const bool valid = gid < k.n;
-  const int e = valid ? gid : k.n - 1;
-  const int n = k.n;
+  const int gid = blockIdx.x * LW + lane;
+  const int n = k.n, m = k.m;
+  const bool valid = gid < m;
+  const int e = valid ? gid : m - 1;
   const Params<T>& P = k.P;
   const EnvCfg<T>& E = k.E;
+  T* lds = lds_all + lane;
+
+  const bool live = e < n;
+  int phase = k.ist[I_PHASE * m + e];
+  const bool donor_run = !live && (phase > 0 || phase == PH_INIT);
+  const bool active = valid && (live || donor_run);
+  if (!__any(active)) return;  // a wave of idle donors
 
   Sim<T> S;
-  load_sim(k.st, n, e, S);
+  int episode = k.ist[I_EPISODE * m + e];
+  const int total = settle_total(E);
+  if (!live && phase == PH_INIT) {
+    init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
+    phase = total;
+  } else {
+    load_sim(k.st, m, e, S);
+  }
   T action[6];
+  if (live) {
 #pragma unroll
-  for (int i = 0; i < 6; i++) action[i] = T(k.actions[e * 6 + i]);
-  if (E.env_kind == TGR_ENV_TR) {
+    for (int i = 0; i < 6; i++) action[i] = T(k.actions[e * 6 + i]);
+    if (E.env_kind == TGR_ENV_TR) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) S.ctrl[i] = S.ctrl[i] + (action[i] - S.ctrl[i]) * E.dt;  // _action_filter, k_FILTER = 1
+      for (int i = 0; i < 6; i++) S.ctrl[i] = S.ctrl[i] + (action[i] - S.ctrl[i]) * E.dt;  // _action_filter, k_FILTER = 1
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; i++) S.ctrl[i] = action[i];
+    }
   } else {
 #pragma unroll
-    for (int i = 0; i < 6; i++) S.ctrl[i] = action[i];
+    for (int i = 0; i < 6; i++) action[i] = S.ctrl[i];  // settling: constant tendon targets
   }
-  T xy_bx = k.st[(F_XYLAG + 0) * n + e], xy_by = k.st[(F_XYLAG + 1) * n + e];
-  T reset_psi = k.st[F_RESETPSI * n + e];
-  T ep_ret = k.st[F_EPRET * n + e];
-  int step_num = k.ist[I_STEPNUM * n + e], elapsed = k.ist[I_ELAPSED * n + e];
-  RingRef<T> ring; ring.ring = k.ring; ring.n = n; ring.e = e;
-  ring.len = k.ist[I_RINGLEN * n + e]; ring.head = k.ist[I_RINGHEAD * n + e];
+  T xy_bx = k.st[(F_XYLAG + 0) * m + e], xy_by = k.st[(F_XYLAG + 1) * m + e];
+  T reset_psi = k.st[F_RESETPSI * m + e];
+  T ep_ret = k.st[F_EPRET * m + e];
+  int step_num = k.ist[I_STEPNUM * m + e], elapsed = k.ist[I_ELAPSED * m + e];
+  RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
+  ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
 
   Lag<T> lag;
-  lag.cfrc_absmax = T(0); lag.overflow = 0;
+  lag.cfrc_absmax = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
 #pragma unroll 1
-  for (int s = 0; s < E.frame_skip; s++) substep(P, S, lds, lane, s == E.frame_skip - 1, lag);
+  for (int s = 0; s < E.frame_skip; s++) substep<T, LW>(P, S, lds, s == E.frame_skip - 1, lag);
 
+  if (lane == 0) {
+    atomicAdd(&k.counters[3], (unsigned long long)lag.n_it);
+    atomicAdd(&k.counters[4], (unsigned long long)lag.n_ls);
+    atomicAdd(&k.counters[5], (unsigned long long)E.frame_skip);
+  }
+  if (active && lag.n_unconv) atomicAdd(&k.counters[6], (unsigned long long)lag.n_unconv);
   V3<T> wb[3];
-  if (valid) store_sim(k.st, n, e, S, lag, wb);
+  if (active) store_sim(k.st, m, e, S, lag, wb);
   else {
 #pragma unroll
     for (int b = 0; b < 3; b++) wb[b] = mk(T(0), T(0), T(0));
   }
-  StepOut<T> out = env_epilogue(P, E, S, lag, wb, action, xy_bx, xy_by, reset_psi, ring);
-  if (E.env_kind == TGR_ENV_TR) step_num += 1;
-  elapsed += 1;
-  bool truncated = elapsed >= E.max_episode_steps;
-  ep_ret += out.reward;
-  bool done = out.terminated || truncated;
-
-  T ob[48];
-  make_obs(P, E, S, lag, wb, ob);
   const int D = E.obs_dim;
-  if (valid) {
-    k.st[(F_XYLAG + 0) * n + e] = out.xy[0]; k.st[(F_XYLAG + 1) * n + e] = out.xy[1];
-    k.st[F_PSILAG * n + e] = out.psi_straight;
-    k.st[F_EPRET * n + e] = ep_ret;
-    k.ist[I_STEPNUM * n + e] = step_num; k.ist[I_ELAPSED * n + e] = elapsed;
-    k.ist[I_RINGLEN * n + e] = ring.len; k.ist[I_RINGHEAD * n + e] = ring.head;
-    k.reward[e] = out.reward;
-    k.terminated[e] = out.terminated ? 1 : 0;
-    k.truncated[e] = truncated ? 1 : 0;
-    if (k.info) {
-      T* ip = k.info + (size_t)e * TGR_INFO_K;
+  T ob[48];
+  if (!live) {
+    // ---- donor lane: one more settle period done
+    if (active) {
+      const int stp = total - phase;  // 0-based index of the period just run
+      if (stp == 0) { step_num = 0; }
+      settle_period_done(P, E, lag, stp, ring, step_num, reset_psi);
+      phase -= 1;
+      k.st[F_RESETPSI * m + e] = reset_psi;
+      k.ist[I_STEPNUM * m + e] = step_num;
+      k.ist[I_RINGLEN * m + e] = ring.len; k.ist[I_RINGHEAD * m + e] = ring.head;
+      k.ist[I_PHASE * m + e] = phase;
+      if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
+      if (phase == PH_READY) {
+        store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
+        make_obs(P, E, S, lag, wb, ob);
+        T* op = k.dobs + (size_t)(e - n) * D;
+        for (int i = 0; i < D; i++) op[i] = ob[i];
+      }
+    }
+    // donors never take part in the observation transpose below (their rows do not exist)
+  }
+  StepOut<T> out;
+  bool truncated = false, done = false;
+  if (live) {
+    out = env_epilogue(P, E, S, lag, wb, action, xy_bx, xy_by, reset_psi, ring);
+    if (E.env_kind == TGR_ENV_TR) step_num += 1;
+    elapsed += 1;
+    truncated = elapsed >= E.max_episode_steps;
+    ep_ret += out.reward;
+    done = out.terminated || truncated;
+    make_obs(P, E, S, lag, wb, ob);
+    if (valid) {
+      k.st[(F_XYLAG + 0) * m + e] = out.xy[0]; k.st[(F_XYLAG + 1) * m + e] = out.xy[1];
+      k.st[F_PSILAG * m + e] = out.psi_straight;
+      k.st[F_EPRET * m + e] = ep_ret;
+      k.ist[I_STEPNUM * m + e] = step_num; k.ist[I_ELAPSED * m + e] = elapsed;
+      k.ist[I_RINGLEN * m + e] = ring.len; k.ist[I_RINGHEAD * m + e] = ring.head;
+      k.reward[e] = out.reward;
+      k.terminated[e] = out.terminated ? 1 : 0;
+      k.truncated[e] = truncated ? 1 : 0;
+      k.doneflag[e] = (done && k.auto_reset) ? 1 : 0;
+      if (k.info) {
+        T* ip = k.info + (size_t)e * TGR_INFO_K;
 #pragma unroll
-      for (int i = 0; i < 10; i++) ip[i] = out.info[i];
-      ip[TGR_INFO_WAYPT_X] = k.st[(F_WAYPT + 0) * n + e]; ip[TGR_INFO_WAYPT_Y] = k.st[(F_WAYPT + 1) * n + e];
-      ip[TGR_INFO_ORI_X] = k.st[(F_ORI + 0) * n + e]; ip[TGR_INFO_ORI_Y] = k.st[(F_ORI + 1) * n + e];
-      ip[TGR_INFO_EP_RETURN] = ep_ret; ip[TGR_INFO_EP_LENGTH] = T(elapsed);
-    }
-    if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
-    if (done && k.terminal_obs) {
-      T* tp = k.terminal_obs + (size_t)e * D;
-      for (int i = 0; i < D; i++) tp[i] = ob[i];
-    }
-    if (done && k.auto_reset) {
-      int slot = atomicAdd(k.list_count, 1);
-      k.list[slot] = e;
+        for (int i = 0; i < 10; i++) ip[i] = out.info[i];
+        ip[TGR_INFO_WAYPT_X] = k.st[(F_WAYPT + 0) * m + e]; ip[TGR_INFO_WAYPT_Y] = k.st[(F_WAYPT + 1) * m + e];
+        ip[TGR_INFO_ORI_X] = k.st[(F_ORI + 0) * m + e]; ip[TGR_INFO_ORI_Y] = k.st[(F_ORI + 1) * m + e];
+        ip[TGR_INFO_EP_RETURN] = ep_ret; ip[TGR_INFO_EP_LENGTH] = T(elapsed);
+      }
+      if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
+      if (done && k.terminal_obs) {
+        T* tp = k.terminal_obs + (size_t)e * D;
+        for (int i = 0; i < D; i++) tp[i] = ob[i];
+      }
     }
   }
-  // observations: transpose through LDS so the [N][D] buffer is written with coalesced stores
-  __syncthreads();
-  {
-    const int Dp = (D & 1) ? D : D + 1;  // odd row pitch: conflict-free
-#pragma unroll
-    for (int i = 0; i < 48; i++)
-      if (i < D) lds[lane * Dp + i] = ob[i];
+  // observations of the live lanes of this block: transpose through LDS so the [N][D] buffer is written with
+  // coalesced stores (the physics scratch columns are dead by now)
+  const int base = blockIdx.x * LW;
+  const int rows = min(LW, n - base);
+  if (rows > 0) {
     __syncthreads();
-    const int base = blockIdx.x * 64;
-    const int rows = min(64, n - base);
-    for (int f = lane; f < rows * D; f += 64) {
+    const int Dp = (D & 1) ? D : D + 1;  // odd row pitch: conflict-free
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < 48; i++)
+        if (i < D) lds_all[lane * Dp + i] = ob[i];
+    }
+    __syncthreads();
+    for (int f = lane; f < rows * D; f += LW) {
       int r = f / D, c = f - r * D;
-      k.obs[(size_t)base * D + f] = lds[r * Dp + c];
+      k.obs[(size_t)base * D + f] = lds_all[r * Dp + c];
     }
   }
 }
 
-// ------------------------------------------------------------------ settle kernel: reset_model()
-// one lane per entry of list[]; reproduces tensegrity_env.py:433-512 / tr_env.py:709-872:
-// yaw-randomised start pose, random tendon targets, 50 control periods of settling.
-template <typename T> __global__ __launch_bounds__(64) void settle_kernel(KArgs<T> k) {
-  __shared__ T lds[LDS_SLOTS * 64];
+// ------------------------------------------------------------------ settle kernel: reset_model() in one go
+// one lane per entry of list[]; used by tgr_reset() and for live envs that found no ready donor.
+// reproduces tensegrity_env.py:433-512 / tr_env.py:709-872.
+template <typename T, int LW> __global__ __launch_bounds__(LW) void settle_kernel(KArgs<T> k) {
+  __shared__ T lds_all[L_TOTAL * LW];
   const int lane = threadIdx.x;
   const int count = *k.list_count;
-  if (blockIdx.x * 64 >= count) return;
-  const int li = blockIdx.x * 64 + lane;
+  if (blockIdx.x * LW >= count) return;
+  const int li = blockIdx.x * LW + lane;
   const bool valid = li < count;
   const int e = k.list[valid ? li : count - 1];
-  const int n = k.n;
+  const int n = k.n, m = k.m;
   const Params<T>& P = k.P;
   const EnvCfg<T>& E = k.E;
+  T* lds = lds_all + lane;
 
-  unsigned long long episode = (unsigned long long)(unsigned)k.ist[I_EPISODE * n + e];
-  Draws dr = reset_draws(E, E.first_env_id + (unsigned long long)e, episode);
+  int episode = k.ist[I_EPISODE * m + e];
   Sim<T> S;
-  {
-    double c = cos(dr.theta), s = sin(dr.theta), ch = cos(0.5 * dr.theta), sh = sin(0.5 * dr.theta);
-    const double* q0 = E.env_kind == TGR_ENV_TR ? c_rolling[dr.pose] : c_qpos0;
-#pragma unroll
-    for (int b = 0; b < 3; b++) {
-      const double* q = q0 + 7 * b;
-      S.x[b] = mk(T(c * q[0] - s * q[1]), T(s * q[0] + c * q[1]), T(q[2]));
-      double w = q[3], x = q[4], y = q[5], z = q[6];
-      S.q[b][0] = T(ch * w - sh * z); S.q[b][1] = T(ch * x - sh * y); S.q[b][2] = T(ch * y + sh * x); S.q[b][3] = T(ch * z + sh * w);
-      S.v[b] = mk(T(0), T(0), T(0)); S.w[b] = S.v[b]; S.al[b] = S.v[b]; S.aa[b] = S.v[b];
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) S.ctrl[i] = T(dr.tendons[i]);
-  }
-  RingRef<T> ring; ring.ring = k.ring; ring.n = n; ring.e = e;
-  ring.len = k.ist[I_RINGLEN * n + e]; ring.head = k.ist[I_RINGHEAD * n + e];
+  init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
+  RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
+  ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
   int step_num = 0;
-  const bool turn = E.action == TGR_ACT_TURN;
-  // tr_env turn: reward_delay_steps extra full env steps after the settle (tr_env.py:864-866)
-  const int extra = (E.env_kind == TGR_ENV_TR && turn) ? E.reward_delay_steps : 0;
+  const int total = settle_total(E);
   Lag<T> lag;
-  lag.cfrc_absmax = T(0); lag.overflow = 0;
+  lag.cfrc_absmax = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
   T reset_psi = T(0);
 #pragma unroll 1
-  for (int st = 0; st < 50 + extra; st++) {
+  for (int st = 0; st < total; st++) {
 #pragma unroll 1
-    for (int s = 0; s < E.frame_skip; s++) substep(P, S, lds, lane, s == E.frame_skip - 1, lag);
-    V3<T> cap[6], l, r;
-    caps_of(P, lag, cap);
-    left_right(cap, l, r);
-    if (st == 49) reset_psi = atan2_(-(l.x - r.x), l.y - r.y);
-    bool env_step = (E.env_kind == TGR_ENV_TENSEGRITY) || st >= 50;  // settling through self.step() vs do_simulation()
-    if (env_step && turn && valid) {
-      T psi = E.env_kind == TGR_ENV_TENSEGRITY ? atan2_(r.y - l.y, r.x - l.x) : atan2_(-(l.x - r.x), l.y - r.y);
-      ring_push(ring, psi);
-      if (ring.len > E.reward_delay_steps) (void)ring_pop(ring);
-    }
-    if (st >= 50) step_num += 1;
+    for (int s = 0; s < E.frame_skip; s++) substep<T, LW>(P, S, lds, s == E.frame_skip - 1, lag);
+    if (valid) settle_period_done(P, E, lag, st, ring, step_num, reset_psi);
   }
-  V3<T> wb[3];
   if (!valid) return;
-  store_sim(k.st, n, e, S, lag, wb);
-  T third = T(1.0 / 3.0);
-  k.st[(F_XYLAG + 0) * n + e] = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x);
-  k.st[(F_XYLAG + 1) * n + e] = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
-  {
-    V3<T> cap[6], l, r;
-    caps_of(P, lag, cap);
-    left_right(cap, l, r);
-    k.st[F_PSILAG * n + e] = atan2_(-(l.x - r.x), l.y - r.y);
-  }
-  k.st[F_RESETPSI * n + e] = reset_psi;
-  k.st[F_EPRET * n + e] = T(0);
-  k.ist[I_STEPNUM * n + e] = step_num;
-  k.ist[I_ELAPSED * n + e] = 0;
-  k.ist[I_RINGLEN * n + e] = ring.len; k.ist[I_RINGHEAD * n + e] = ring.head;
-  k.ist[I_EPISODE * n + e] = (int)(episode + 1);
+  V3<T> wb[3];
+  store_sim(k.st, m, e, S, lag, wb);
+  store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
+  k.ist[I_SRC * m + e] = e;
+  k.ist[I_SRCEP * m + e] = episode;
+  k.ist[I_EPISODE * m + e] = episode + 1;
+  k.ist[I_PHASE * m + e] = e < n ? PH_LIVE : PH_READY;
   atomicAdd(&k.counters[1], 1ull);
   if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
-  if (k.obs_reset) {
-    T ob[48];
-    make_obs(P, E, S, lag, wb, ob);
-    T* op = k.obs_reset + (size_t)e * E.obs_dim;
+  T ob[48];
+  make_obs(P, E, S, lag, wb, ob);
+  T* op = e < n ? (k.obs_reset ? k.obs_reset + (size_t)e * E.obs_dim : nullptr) : k.dobs + (size_t)(e - n) * E.obs_dim;
+  if (op)
     for (int i = 0; i < E.obs_dim; i++) op[i] = ob[i];
+}
+
+// ------------------------------------------------------------------ match kernel (one block)
+// pairs the k-th finished live env (ascending index) with the k-th ready donor (ascending index), copies the donor's
+// settled episode into the env's lane, re-arms the donor, and lists the envs that found no donor for settle_kernel.
+template <typename T> __global__ __launch_bounds__(1024) void match_kernel(KArgs<T> k) {
+  __shared__ int cnt[1024];
+  __shared__ int nd_s, nr_s;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int n = k.n, m = k.m, nd_lanes = m - n;
+  // ordered compaction of done slots -> list (temporarily) ; ready donors -> rlist
+  auto compact = [&](int total, auto pred, int* out, int* total_out) {
+    int chunk = (total + NT - 1) / NT;
+    int lo = min(tid * chunk, total), hi = min(lo + chunk, total);
+    int c = 0;
+    for (int i = lo; i < hi; i++) c += pred(i) ? 1 : 0;
+    cnt[tid] = c;
+    __syncthreads();
+    // exclusive scan (Hillis-Steele on NT entries)
+    for (int off = 1; off < NT; off <<= 1) {
+      int v = tid >= off ? cnt[tid - off] : 0;
+      __syncthreads();
+      cnt[tid] += v;
+      __syncthreads();
+    }
+    int start = cnt[tid] - c;
+    for (int i = lo; i < hi; i++)
+      if (pred(i)) out[start++] = i;
+    if (tid == NT - 1) *total_out = cnt[tid];
+    __syncthreads();
+  };
+  compact(n, [&](int i) { return k.doneflag[i] != 0; }, k.list, &nd_s);
+  compact(nd_lanes, [&](int i) { return k.ist[I_PHASE * m + n + i] == PH_READY; }, k.rlist, &nr_s);
+  const int nd = nd_s, nr = nr_s;
+  const int pairs = min(nd, nr);
+  const int D = k.E.obs_dim;
+  // copy donor -> slot : state fields, int fields, heading ring, reset observation
+  const int per = NF + RING + D;
+  for (int w = tid; w < pairs * per; w += NT) {
+    int p = w / per, f = w - p * per;
+    int slot = k.list[p], donor = n + k.rlist[p];
+    if (f < NF) k.st[f * m + slot] = k.st[f * m + donor];
+    else if (f < NF + RING) k.ring[(f - NF) * m + slot] = k.ring[(f - NF) * m + donor];
+    else if (k.obs_reset) k.obs_reset[(size_t)slot * D + (f - NF - RING)] = k.dobs[(size_t)(donor - n) * D + (f - NF - RING)];
+  }
+  __syncthreads();
+  for (int p = tid; p < pairs; p += NT) {
+    int slot = k.list[p], donor = n + k.rlist[p];
+    k.ist[I_STEPNUM * m + slot] = k.ist[I_STEPNUM * m + donor];
+    k.ist[I_ELAPSED * m + slot] = 0;
+    k.ist[I_RINGLEN * m + slot] = k.ist[I_RINGLEN * m + donor];
+    k.ist[I_RINGHEAD * m + slot] = k.ist[I_RINGHEAD * m + donor];
+    k.ist[I_SRC * m + slot] = donor;
+    k.ist[I_SRCEP * m + slot] = k.ist[I_EPISODE * m + donor];
+    k.ist[I_EPISODE * m + donor] += 1;
+    k.ist[I_PHASE * m + donor] = PH_INIT;
+    k.doneflag[slot] = 0;
+  }
+  __syncthreads();
+  // starved envs: shift to the front of list[] for the synchronous settle
+  int starved = nd - pairs;
+  for (int p = tid; p < starved; p += NT) k.rlist[p] = k.list[pairs + p];
+  __syncthreads();
+  for (int p = tid; p < starved; p += NT) { k.list[p] = k.rlist[p]; k.doneflag[k.rlist[p]] = 0; }
+  if (tid == 0) {
+    *k.list_count = starved;
+    if (pairs) atomicAdd(&k.counters[2], (unsigned long long)pairs);
   }
 }
 
@@ -476,9 +628,9 @@ template <typename T> __global__ __launch_bounds__(64) void settle_kernel(KArgs<
 template <typename T> __global__ void refresh_lag_kernel(KArgs<T> k) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= k.n) return;
-  const int n = k.n;
+  const int m = k.m;
   Sim<T> S;
-  load_sim(k.st, n, e, S);
+  load_sim(k.st, m, e, S);
   Lag<T> lag;
 #pragma unroll
   for (int b = 0; b < 3; b++) {
@@ -486,12 +638,12 @@ template <typename T> __global__ void refresh_lag_kernel(KArgs<T> k) {
     lag.z[b] = quat_rot(S.q[b]).ez;
   }
   T third = T(1.0 / 3.0);
-  k.st[(F_XYLAG + 0) * n + e] = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x);
-  k.st[(F_XYLAG + 1) * n + e] = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
+  k.st[(F_XYLAG + 0) * m + e] = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x);
+  k.st[(F_XYLAG + 1) * m + e] = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
   V3<T> cap[6], l, r;
   caps_of(k.P, lag, cap);
   left_right(cap, l, r);
-  k.st[F_PSILAG * n + e] = atan2_(-(l.x - r.x), l.y - r.y);
+  k.st[F_PSILAG * m + e] = atan2_(-(l.x - r.x), l.y - r.y);
 }
 
 }  // namespace tgr
@@ -501,12 +653,15 @@ using namespace tgr;
 
 struct tgr_handle {
   tgr_config cfg;
-  int n = 0, device = 0, obs_dim = 0;
-  void* st = nullptr;   // T[NF][n]
-  int* ist = nullptr;   // int[NI][n]
-  void* ring = nullptr; // T[RING][n]
+  int n = 0, m = 0, device = 0, obs_dim = 0;
+  void* st = nullptr;   // T[NF][m]
+  int* ist = nullptr;   // int[NI][m]
+  void* ring = nullptr; // T[RING][m]
+  void* dobs = nullptr; // T[m-n][D]
   int* list_count = nullptr;
   int* list = nullptr;
+  int* rlist = nullptr;
+  uint8_t* doneflag = nullptr;
   unsigned long long* counters = nullptr;
   std::string err;
 };
@@ -522,7 +677,16 @@ static thread_local std::string g_err;
     }                                                                                            \
   } while (0)
 
-extern "C" const char* tgr_version(void) { return "tensegrity-mi355x 0.1 (gfx950)"; }
+#ifndef TGR_LW_F32
+#define TGR_LW_F32 64
+#endif
+#ifndef TGR_LW_F64
+#define TGR_LW_F64 32
+#endif
+template <typename T> struct LaneW { static constexpr int value = sizeof(T) == 4 ? TGR_LW_F32 : TGR_LW_F64; };  // lanes (envs) per block
+
+extern "C" const char* tgr_version(void) { return "tensegrity-mi355x 0.2 (gfx950)"; }
+extern "C" int tgr_sizeof_config(void) { return (int)sizeof(tgr_config); }
 
 extern "C" int tgr_default_config(tgr_config* c, int env_kind, int desired_action) {
   if (!c) return TGR_ERR_INVALID;
@@ -570,7 +734,7 @@ extern "C" int tgr_default_config(tgr_config* c, int env_kind, int desired_actio
   c->actuator_deriv_skip_clamped = 0;
   c->precision = TGR_PRECISION_F32;
   c->auto_reset = 1;
-  c->async_reset = 0;
+  c->n_donors = -1;
   c->seed = 1234;
   c->first_env_id = 0;
   c->solver_tolerance = 0;
@@ -610,10 +774,10 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   P.f0 = T(c.friction[0]); P.f1sq = T(c.friction[0] * c.friction[0]); P.f3sq = T(c.friction[1] * c.friction[1]);
   P.f4sq = T(c.friction[2] * c.friction[2]); P.impratio = T(c.impratio);
   P.invweight = T(0.25);
-  double tol = c.solver_tolerance > 0 ? c.solver_tolerance : (sizeof(T) == 4 ? 1e-6 : 1e-11);
+  double tol = c.solver_tolerance > 0 ? c.solver_tolerance : (sizeof(T) == 4 ? 1e-5 : 1e-11);
   P.tol = T(tol); P.ls_tol = T(0.01);
-  P.max_iter = c.solver_iterations > 0 ? c.solver_iterations : (sizeof(T) == 4 ? 12 : 40);
-  P.ls_iter = sizeof(T) == 4 ? 12 : 50;
+  P.max_iter = c.solver_iterations > 0 ? c.solver_iterations : (sizeof(T) == 4 ? 8 : 40);
+  P.ls_iter = sizeof(T) == 4 ? 6 : 50;
   P.skip_clamped = c.actuator_deriv_skip_clamped;
   EnvCfg<T>& E = k.E;
   E.env_kind = c.env_kind; E.action = c.desired_action; E.terminate_when_unhealthy = c.terminate_when_unhealthy;
@@ -626,9 +790,9 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   E.min_heading = c.min_reset_heading; E.max_heading = c.max_reset_heading;
   E.ten_mean = c.tendon_reset_mean; E.ten_std = c.tendon_reset_stdev; E.ten_max = c.tendon_max_length; E.ten_min = c.tendon_min_length;
   E.seed = c.seed; E.first_env_id = c.first_env_id;
-  k.n = h->n;
-  k.st = (T*)h->st; k.ist = h->ist; k.ring = (T*)h->ring;
-  k.list_count = h->list_count; k.list = h->list; k.counters = h->counters;
+  k.n = h->n; k.m = h->m;
+  k.st = (T*)h->st; k.ist = h->ist; k.ring = (T*)h->ring; k.dobs = (T*)h->dobs;
+  k.list_count = h->list_count; k.list = h->list; k.rlist = h->rlist; k.doneflag = h->doneflag; k.counters = h->counters;
   k.auto_reset = c.auto_reset;
   k.actions = nullptr; k.obs = nullptr; k.reward = nullptr; k.terminated = nullptr; k.truncated = nullptr;
   k.terminal_obs = nullptr; k.info = nullptr; k.obs_reset = nullptr;
@@ -642,6 +806,7 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   }
   if (cfg->use_contact_forces) { g_err = "tgr_create: use_contact_forces not built yet"; return TGR_ERR_UNSUPPORTED; }
   if (cfg->solimp[4] != 2.0 || cfg->solref[0] >= 0) { g_err = "tgr_create: only direct solref and power-2 solimp"; return TGR_ERR_UNSUPPORTED; }
+  if (cfg->n_donors > 8 * n_envs) { g_err = "tgr_create: n_donors must be <= 8 * n_envs"; return TGR_ERR_INVALID; }
   if (cfg->reward_delay_steps >= RING - 1 || cfg->reward_delay_steps < 0) { g_err = "tgr_create: reward_delay_steps too large"; return TGR_ERR_INVALID; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "tgr_create: no HIP device (the HIP path is required; there is no CPU fallback)"; return TGR_ERR_HIP; }
@@ -649,27 +814,41 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   tgr_handle* h = new (std::nothrow) tgr_handle();
   if (!h) return TGR_ERR_INVALID;
   h->cfg = *cfg; h->n = n_envs; h->device = device; h->obs_dim = obs_dim_of(*cfg);
+  int donors = cfg->n_donors < 0 ? 2 * n_envs : cfg->n_donors;
+  if (!cfg->auto_reset) donors = 0;
+  h->m = n_envs + donors;
   *out = h;
   HIP_TRY(h, hipSetDevice(device));
   size_t ts = cfg->precision == TGR_PRECISION_F64 ? 8 : 4;
-  HIP_TRY(h, hipMalloc(&h->st, ts * NF * (size_t)n_envs));
-  HIP_TRY(h, hipMemset(h->st, 0, ts * NF * (size_t)n_envs));
-  HIP_TRY(h, hipMalloc((void**)&h->ist, sizeof(int) * NI * (size_t)n_envs));
-  HIP_TRY(h, hipMemset(h->ist, 0, sizeof(int) * NI * (size_t)n_envs));
-  HIP_TRY(h, hipMalloc(&h->ring, ts * RING * (size_t)n_envs));
-  HIP_TRY(h, hipMemset(h->ring, 0, ts * RING * (size_t)n_envs));
+  size_t m = (size_t)h->m;
+  HIP_TRY(h, hipMalloc(&h->st, ts * NF * m));
+  HIP_TRY(h, hipMemset(h->st, 0, ts * NF * m));
+  HIP_TRY(h, hipMalloc((void**)&h->ist, sizeof(int) * NI * m));
+  {
+    std::vector<int> ist(NI * m, 0);
+    for (size_t e = 0; e < m; e++) ist[I_PHASE * m + e] = e < (size_t)n_envs ? PH_LIVE : PH_INIT;
+    HIP_TRY(h, hipMemcpy(h->ist, ist.data(), sizeof(int) * NI * m, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(h, hipMalloc(&h->ring, ts * RING * m));
+  HIP_TRY(h, hipMemset(h->ring, 0, ts * RING * m));
+  HIP_TRY(h, hipMalloc(&h->dobs, ts * (size_t)h->obs_dim * (size_t)(donors > 0 ? donors : 1)));
   HIP_TRY(h, hipMalloc((void**)&h->list_count, sizeof(int)));
-  HIP_TRY(h, hipMalloc((void**)&h->list, sizeof(int) * (size_t)n_envs));
-  HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 4));
-  HIP_TRY(h, hipMemset(h->counters, 0, sizeof(unsigned long long) * 4));
+  HIP_TRY(h, hipMemset(h->list_count, 0, sizeof(int)));
+  HIP_TRY(h, hipMalloc((void**)&h->list, sizeof(int) * m));
+  HIP_TRY(h, hipMalloc((void**)&h->rlist, sizeof(int) * m));
+  HIP_TRY(h, hipMalloc((void**)&h->doneflag, m));
+  HIP_TRY(h, hipMemset(h->doneflag, 0, m));
+  HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 8));
+  HIP_TRY(h, hipMemset(h->counters, 0, sizeof(unsigned long long) * 8));
   return TGR_OK;
 }
 
 extern "C" int tgr_destroy(tgr_handle* h) {
   if (!h) return TGR_OK;
-  hipSetDevice(h->device);
-  hipDeviceSynchronize();
-  hipFree(h->st); hipFree(h->ist); hipFree(h->ring); hipFree(h->list_count); hipFree(h->list); hipFree(h->counters);
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(h->st); (void)hipFree(h->ist); (void)hipFree(h->ring); (void)hipFree(h->dobs); (void)hipFree(h->list_count);
+  (void)hipFree(h->list); (void)hipFree(h->rlist); (void)hipFree(h->doneflag); (void)hipFree(h->counters);
   delete h;
   return TGR_OK;
 }
@@ -683,37 +862,46 @@ extern "C" int tgr_synchronize(tgr_handle* h) {
   HIP_TRY(h, hipDeviceSynchronize());
   return TGR_OK;
 }
+extern "C" uint64_t tgr_lane_key(const tgr_handle* h, int lane) {
+  if (!h) return 0;
+  return lane < h->n ? h->cfg.first_env_id + (uint64_t)lane : (1ull << 62) + h->cfg.first_env_id * 8ull + (uint64_t)(lane - h->n);
+}
 extern "C" int tgr_set_seed(tgr_handle* h, uint64_t seed) {
   if (!h) return TGR_ERR_INVALID;
   h->cfg.seed = seed;
   return TGR_OK;
 }
-extern "C" int tgr_stats(tgr_handle* h, uint64_t out[4]) {
+extern "C" int tgr_stats(tgr_handle* h, uint64_t out[8]) {
   if (!h || !out) return TGR_ERR_INVALID;
-  unsigned long long tmp[4];
+  unsigned long long tmp[8];
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipDeviceSynchronize());
   HIP_TRY(h, hipMemcpy(tmp, h->counters, sizeof(tmp), hipMemcpyDeviceToHost));
-  for (int i = 0; i < 4; i++) out[i] = tmp[i];
+  for (int i = 0; i < 8; i++) out[i] = tmp[i];
   return TGR_OK;
 }
 
 template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, void* obs, hipStream_t s) {
   std::vector<int> idx;
-  idx.reserve(h->n);
+  idx.reserve(h->m);
   for (int i = 0; i < h->n; i++)
     if (!mask || mask[i]) idx.push_back(i);
+  // a full reset also settles every donor, so the pool starts out ready
+  if (!mask)
+    for (int i = h->n; i < h->m; i++) idx.push_back(i);
   int cnt = (int)idx.size();
   if (cnt == 0) return TGR_OK;
   HIP_TRY(h, hipMemcpyAsync(h->list, idx.data(), sizeof(int) * cnt, hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemcpyAsync(h->list_count, &cnt, sizeof(int), hipMemcpyHostToDevice, s));
-  HIP_TRY(h, hipStreamSynchronize(s));  // idx / cnt are stack/heap temporaries
+  HIP_TRY(h, hipStreamSynchronize(s));  // idx / cnt are host temporaries
   KArgs<T> k;
   fill_args<T>(h, k);
   k.obs_reset = (T*)obs;
-  int blocks = (cnt + 63) / 64;
-  hipLaunchKernelGGL(settle_kernel<T>, dim3(blocks), dim3(64), 0, s, k);
+  constexpr int LW = LaneW<T>::value;
+  int blocks = (cnt + LW - 1) / LW;
+  hipLaunchKernelGGL((settle_kernel<T, LW>), dim3(blocks), dim3(LW), 0, s, k);
   HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemsetAsync(h->list_count, 0, sizeof(int), s));
   return TGR_OK;
 }
 
@@ -733,12 +921,16 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
   k.actions = actions; k.obs = obs; k.reward = reward; k.terminated = terminated; k.truncated = truncated;
   k.terminal_obs = terminal_obs; k.info = info;
   k.obs_reset = obs;
-  HIP_TRY(h, hipMemsetAsync(h->list_count, 0, sizeof(int), s));
-  int blocks = (h->n + 63) / 64;
-  hipLaunchKernelGGL(step_kernel<T>, dim3(blocks), dim3(64), 0, s, k);
+  constexpr int LW = LaneW<T>::value;
+  int blocks = (h->m + LW - 1) / LW;
+  hipLaunchKernelGGL((step_kernel<T, LW>), dim3(blocks), dim3(LW), 0, s, k);
   HIP_TRY(h, hipGetLastError());
   if (h->cfg.auto_reset) {
-    hipLaunchKernelGGL(settle_kernel<T>, dim3(blocks), dim3(64), 0, s, k);
+    hipLaunchKernelGGL((match_kernel<T>), dim3(1), dim3(1024), 0, s, k);
+    HIP_TRY(h, hipGetLastError());
+    // envs that found no ready donor are settled here and now (grid sized for the worst case, exits on an empty list)
+    int sblocks = (h->n + LW - 1) / LW;
+    hipLaunchKernelGGL((settle_kernel<T, LW>), dim3(sblocks), dim3(LW), 0, s, k);
     HIP_TRY(h, hipGetLastError());
   }
   return TGR_OK;
@@ -761,13 +953,13 @@ extern "C" int tgr_step_f64(tgr_handle* h, const float* actions, double* obs, do
 
 // ---- state exchange (host arrays, double)
 template <typename T> static int get_state_impl(tgr_handle* h, double* qpos, double* qvel, double* ctrl, double* warm, double* aux) {
-  size_t n = h->n;
+  size_t n = h->m, nlive = h->n;
   std::vector<T> st(NF * n);
   std::vector<int> ist(NI * n);
   HIP_TRY(h, hipDeviceSynchronize());
   HIP_TRY(h, hipMemcpy(st.data(), h->st, sizeof(T) * NF * n, hipMemcpyDeviceToHost));
   HIP_TRY(h, hipMemcpy(ist.data(), h->ist, sizeof(int) * NI * n, hipMemcpyDeviceToHost));
-  for (size_t e = 0; e < n; e++) {
+  for (size_t e = 0; e < nlive; e++) {
     if (qpos) for (int i = 0; i < 21; i++) qpos[e * 21 + i] = (double)st[(F_QPOS + i) * n + e];
     if (qvel) for (int i = 0; i < 18; i++) qvel[e * 18 + i] = (double)st[(F_QVEL + i) * n + e];
     if (ctrl) for (int i = 0; i < 6; i++) ctrl[e * 6 + i] = (double)st[(F_CTRL + i) * n + e];
@@ -778,7 +970,7 @@ template <typename T> static int get_state_impl(tgr_handle* h, double* qpos, dou
       a[TGR_AUX_PSI_LAG] = (double)st[F_PSILAG * n + e]; a[TGR_AUX_RESET_PSI] = (double)st[F_RESETPSI * n + e];
       a[TGR_AUX_EP_RETURN] = (double)st[F_EPRET * n + e];
       a[TGR_AUX_STEP_NUM] = ist[I_STEPNUM * n + e]; a[TGR_AUX_ELAPSED] = ist[I_ELAPSED * n + e];
-      a[TGR_AUX_EPISODE] = ist[I_EPISODE * n + e]; a[TGR_AUX_RING_LEN] = ist[I_RINGLEN * n + e];
+      a[TGR_AUX_EPISODE] = ist[I_SRCEP * n + e]; a[TGR_AUX_RING_LEN] = ist[I_RINGLEN * n + e]; a[TGR_AUX_SRC] = ist[I_SRC * n + e];
       a[TGR_AUX_WAYPT_X] = (double)st[(F_WAYPT + 0) * n + e]; a[TGR_AUX_WAYPT_Y] = (double)st[(F_WAYPT + 1) * n + e];
       a[TGR_AUX_ORI_X] = (double)st[(F_ORI + 0) * n + e]; a[TGR_AUX_ORI_Y] = (double)st[(F_ORI + 1) * n + e];
       a[TGR_AUX_VCMD_X] = (double)st[(F_VCMD + 0) * n + e]; a[TGR_AUX_VCMD_Y] = (double)st[(F_VCMD + 1) * n + e];
@@ -789,13 +981,13 @@ template <typename T> static int get_state_impl(tgr_handle* h, double* qpos, dou
 }
 template <typename T>
 static int set_state_impl(tgr_handle* h, const double* qpos, const double* qvel, const double* ctrl, const double* warm, const double* aux) {
-  size_t n = h->n;
+  size_t n = h->m, nlive = h->n;
   std::vector<T> st(NF * n);
   std::vector<int> ist(NI * n);
   HIP_TRY(h, hipDeviceSynchronize());
   HIP_TRY(h, hipMemcpy(st.data(), h->st, sizeof(T) * NF * n, hipMemcpyDeviceToHost));
   HIP_TRY(h, hipMemcpy(ist.data(), h->ist, sizeof(int) * NI * n, hipMemcpyDeviceToHost));
-  for (size_t e = 0; e < n; e++) {
+  for (size_t e = 0; e < nlive; e++) {
     if (qpos) for (int i = 0; i < 21; i++) st[(F_QPOS + i) * n + e] = (T)qpos[e * 21 + i];
     if (qvel) for (int i = 0; i < 18; i++) st[(F_QVEL + i) * n + e] = (T)qvel[e * 18 + i];
     if (ctrl) for (int i = 0; i < 6; i++) st[(F_CTRL + i) * n + e] = (T)ctrl[e * 6 + i];
@@ -805,19 +997,18 @@ static int set_state_impl(tgr_handle* h, const double* qpos, const double* qvel,
   if (qpos) {
     KArgs<T> k;
     fill_args<T>(h, k);
-    hipLaunchKernelGGL(refresh_lag_kernel<T>, dim3((h->n + 63) / 64), dim3(64), 0, 0, k);
+    hipLaunchKernelGGL((refresh_lag_kernel<T>), dim3((h->n + 63) / 64), dim3(64), 0, 0, k);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipDeviceSynchronize());
   }
   if (aux) {
     HIP_TRY(h, hipMemcpy(st.data(), h->st, sizeof(T) * NF * n, hipMemcpyDeviceToHost));
-    for (size_t e = 0; e < n; e++) {
+    for (size_t e = 0; e < nlive; e++) {
       const double* a = aux + e * TGR_AUX_K;
       st[(F_XYLAG + 0) * n + e] = (T)a[TGR_AUX_XY_LAG_X]; st[(F_XYLAG + 1) * n + e] = (T)a[TGR_AUX_XY_LAG_Y];
       st[F_PSILAG * n + e] = (T)a[TGR_AUX_PSI_LAG]; st[F_RESETPSI * n + e] = (T)a[TGR_AUX_RESET_PSI];
       st[F_EPRET * n + e] = (T)a[TGR_AUX_EP_RETURN];
       ist[I_STEPNUM * n + e] = (int)a[TGR_AUX_STEP_NUM]; ist[I_ELAPSED * n + e] = (int)a[TGR_AUX_ELAPSED];
-      ist[I_EPISODE * n + e] = (int)a[TGR_AUX_EPISODE];
       st[(F_WAYPT + 0) * n + e] = (T)a[TGR_AUX_WAYPT_X]; st[(F_WAYPT + 1) * n + e] = (T)a[TGR_AUX_WAYPT_Y];
       st[(F_ORI + 0) * n + e] = (T)a[TGR_AUX_ORI_X]; st[(F_ORI + 1) * n + e] = (T)a[TGR_AUX_ORI_Y];
       st[(F_VCMD + 0) * n + e] = (T)a[TGR_AUX_VCMD_X]; st[(F_VCMD + 1) * n + e] = (T)a[TGR_AUX_VCMD_Y];

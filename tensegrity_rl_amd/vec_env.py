@@ -51,7 +51,7 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
             cfg.contact_force_lo, cfg.contact_force_hi = -1000.0, 1000.0
     if "reward_delay_seconds" in kwargs:
         cfg.reward_delay_steps = int(kwargs.pop("reward_delay_seconds") / (cfg.timestep * cfg.frame_skip))
-    for k in ("actuator_deriv_skip_clamped", "solver_tolerance", "solver_iterations", "async_reset"):
+    for k in ("actuator_deriv_skip_clamped", "solver_tolerance", "solver_iterations", "n_donors"):
         if k in kwargs:
             setattr(cfg, k, type(getattr(cfg, k))(kwargs.pop(k)))
     if kwargs:
@@ -239,9 +239,11 @@ class TensegrityVecEnv:
         N.check(self.handle, rc, "tgr_set_state")
 
     def stats(self):
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         N.check(self.handle, self.lib.tgr_stats(self.handle, out), "tgr_stats")
-        return {"dropped_contacts": int(out[0]), "sync_resets": int(out[1]), "presettled_resets": int(out[2]), "side_launches": int(out[3])}
+        sub = max(int(out[5]), 1)
+        return {"dropped_contacts": int(out[0]), "settle_kernel_resets": int(out[1]), "donor_resets": int(out[2]),
+                "newton_iters_per_substep": int(out[3]) / sub, "linesearch_evals_per_substep": int(out[4]) / sub, "unconverged_lane_substeps": int(out[6])}
 
     def synchronize(self):
         self.lib.tgr_synchronize(self.handle)

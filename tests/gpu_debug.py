@@ -21,7 +21,7 @@ def run(kind, action, prec, n=64, steps=6):
     worst = {}
     for t in range(steps):
         qpos, qvel, ctrl, warm, aux = ob.get_state()
-        A = np.zeros((n, 16)); A[:, 0] = aux["xy_lag_x"]; A[:, 1] = aux["xy_lag_y"]; A[:, 3] = aux["reset_psi"]
+        A = np.zeros((n, 17)); A[:, 0] = aux["xy_lag_x"]; A[:, 1] = aux["xy_lag_y"]; A[:, 3] = aux["reset_psi"]
         A[:, 5] = aux["step_num"]; A[:, 6] = aux["elapsed"]
         env.set_state(qpos, qvel, ctrl, warm, A)
         a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)

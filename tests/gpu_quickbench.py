@@ -6,7 +6,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 kind = sys.argv[2] if len(sys.argv) > 2 else "tensegrity_env-v0"
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 auto = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-env = TensegrityVecEnv(n, kind, auto_reset=bool(auto))
+kw = {}
+for a in sys.argv[5:]:
+    k_, v_ = a.split('='); kw[k_] = float(v_) if '.' in v_ or 'e' in v_ else int(v_)
+env = TensegrityVecEnv(n, kind, auto_reset=bool(auto), **kw)
 t0 = time.time(); env.reset_tensors(); torch.cuda.synchronize(); t_reset = time.time() - t0
 g = torch.Generator(device="cuda"); g.manual_seed(0)
 acts = [torch.rand((n, 6), device="cuda", generator=g) * 0.6 - 0.45 for _ in range(16)]
@@ -17,4 +20,4 @@ for i in range(steps):
     o, r, te, tr, _, _ = env.step_tensors(acts[i % 16])
     dones += int((te | tr).sum().item()) if i % 10 == 0 else 0
 torch.cuda.synchronize(); dt = time.time() - t0
-print(f"n={n} {kind} auto={auto} reset {t_reset*1e3:.1f} ms; {steps} steps {dt*1e3:.1f} ms -> {dt/steps*1e3:.3f} ms/step, {n*steps/dt/1e6:.3f} M env-steps/s; dones sampled {dones}; stats {env.stats()}", flush=True)
+print(f"n={n} {kind} auto={auto} {kw} reset {t_reset*1e3:.1f} ms; {steps} steps {dt*1e3:.1f} ms -> {dt/steps*1e3:.3f} ms/step, {n*steps/dt/1e6:.3f} M env-steps/s; dones sampled {dones}; stats {env.stats()}", flush=True)
