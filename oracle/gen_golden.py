@@ -181,7 +181,7 @@ def run_case(kind, action, seed, steps, direction=1, **kwargs):
     env = cls(xml_file="unused.xml", desired_action=action, desired_direction=direction, **kwargs)
     out = {"kind": kind, "action": action, "direction": direction}
     ep_resets = []
-    rec = {k: [] for k in ["obs", "reward", "terminated", "qpos", "qvel", "actions"] + INFO_SCALARS}
+    rec = {k: [] for k in ["obs", "reward", "terminated", "qpos", "qvel", "actions", "ctrl"] + INFO_SCALARS}
     arng = _real_default_rng(1000 + seed)
     n_resets = 2
     for ep in range(n_resets):
@@ -191,7 +191,8 @@ def run_case(kind, action, seed, steps, direction=1, **kwargs):
         obs0, _ = env.reset()
         pose, theta, tendons, u_way = replay_draws(kind, s, mean, std, lo, hi, action)
         ep_resets.append(dict(pose=pose, theta=theta, tendons=tendons, u_way=u_way, obs=np.array(obs0, dtype=np.float64),
-                              qpos=env.data.qpos.copy(), qvel=env.data.qvel.copy(), reset_psi=float(env._reset_psi),
+                              qpos=env.data.qpos.copy(), qvel=env.data.qvel.copy(), reset_psi=float(env._reset_psi), ctrl=env.data.ctrl.copy(),
+                              xy_lag=np.array([np.mean([env.data.body(b).xpos[i] for b in ('r01_body', 'r23_body', 'r45_body')]) for i in range(2)]),
                               waypt=np.array(getattr(env, "_waypt", np.zeros(2)), dtype=np.float64).reshape(-1)[:2]
                               if np.size(getattr(env, "_waypt", np.zeros(0))) == 2 else np.zeros(2),
                               oripoint=np.array(getattr(env, "_oripoint", np.zeros(2)), dtype=np.float64)))
@@ -201,7 +202,7 @@ def run_case(kind, action, seed, steps, direction=1, **kwargs):
                 a = (a * 1.5).astype(np.float32)  # exercise ctrl clamping (values outside ctrlrange)
             obs, r, term, trunc, info = env.step(a)
             rec["obs"].append(np.array(obs, dtype=np.float64)); rec["reward"].append(float(r)); rec["terminated"].append(bool(term))
-            rec["qpos"].append(env.data.qpos.copy()); rec["qvel"].append(env.data.qvel.copy()); rec["actions"].append(a)
+            rec["qpos"].append(env.data.qpos.copy()); rec["qvel"].append(env.data.qvel.copy()); rec["actions"].append(a); rec["ctrl"].append(env.data.ctrl.copy())
             for k in INFO_SCALARS:
                 rec[k].append(float(info[k]))
     for k, v in rec.items():

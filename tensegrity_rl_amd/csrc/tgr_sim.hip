@@ -387,6 +387,7 @@ template <typename T, int LW> __global__ __launch_bounds__(LW) void step_kernel(
   if (!live && phase == PH_INIT) {
     init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
     phase = total;
+    if (valid) { k.ist[I_SRC * m + e] = e; k.ist[I_SRCEP * m + e] = episode; k.ist[I_EPISODE * m + e] = episode + 1; }
   } else {
     load_sim(k.st, m, e, S);
   }
@@ -607,8 +608,7 @@ template <typename T> __global__ __launch_bounds__(1024) void match_kernel(KArgs
     k.ist[I_RINGLEN * m + slot] = k.ist[I_RINGLEN * m + donor];
     k.ist[I_RINGHEAD * m + slot] = k.ist[I_RINGHEAD * m + donor];
     k.ist[I_SRC * m + slot] = donor;
-    k.ist[I_SRCEP * m + slot] = k.ist[I_EPISODE * m + donor];
-    k.ist[I_EPISODE * m + donor] += 1;
+    k.ist[I_SRCEP * m + slot] = k.ist[I_SRCEP * m + donor];
     k.ist[I_PHASE * m + donor] = PH_INIT;
     k.doneflag[slot] = 0;
   }

@@ -1,0 +1,32 @@
+"""helpers shared by the -m gpu tests"""
+import numpy as np
+
+AUX = {"xy_lag_x": 0, "xy_lag_y": 1, "psi_lag": 2, "reset_psi": 3, "ep_return": 4, "step_num": 5, "elapsed": 6, "episode": 7,
+       "ring_len": 8, "src": 16}
+
+
+def qfix(a, b):
+    """flip quaternion signs of a to match b (q and -q are the same rotation)"""
+    a = np.asarray(a, dtype=np.float64).reshape(-1, 3, 7).copy()
+    b = np.asarray(b, dtype=np.float64).reshape(-1, 3, 7)
+    s = np.sign(np.sum(a[:, :, 3:] * b[:, :, 3:], axis=2, keepdims=True))
+    s[s == 0] = 1
+    a[:, :, 3:] *= s
+    return a.reshape(-1, 21)
+
+
+def oracle_to_gpu_state(ob, env):
+    """copy the oracle batch's full per-env state into the HIP handle (identical (state, action) parity)"""
+    qpos, qvel, ctrl, warm, aux = ob.get_state()
+    n = ob.n
+    A = np.zeros((n, 17))
+    A[:, AUX["xy_lag_x"]] = aux["xy_lag_x"]; A[:, AUX["xy_lag_y"]] = aux["xy_lag_y"]
+    A[:, AUX["reset_psi"]] = aux["reset_psi"]; A[:, AUX["step_num"]] = aux["step_num"]
+    A[:, AUX["elapsed"]] = aux["elapsed"]; A[:, AUX["ep_return"]] = aux["ep_return"]
+    env.set_state(qpos, qvel, ctrl, warm, A)
+    return qpos, qvel
+
+
+def rel_env(err, ref, floor):
+    """per-env relative error: max |err| over components / max(|ref| over components, floor)"""
+    return np.abs(err).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), floor)

@@ -1,0 +1,157 @@
+"""-m gpu: reset_model() on the device (settle kernel and donor lanes) against the oracle, and the SB3 VecEnv contract."""
+import numpy as np
+import pytest
+
+from gpu_common import AUX, qfix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind,action", [("tensegrity_env", "straight"), ("tensegrity_env", "turn"), ("tr_env", "straight"), ("tr_env", "turn")])
+def test_reset_matches_oracle_fp64(oracle, kind, action):
+    """same philox draws -> same start pose -> 1000 sub-steps of settling agree (fp64)"""
+    from tensegrity_rl_amd import TensegrityVecEnv
+    O = oracle
+    n = 32
+    env = TensegrityVecEnv(n, kind + "-v0", desired_action=action, precision="f64", auto_reset=False, seed=77, first_env_id=5)
+    obs = env.reset()
+    ob = O.OracleBatch(O.make_cfg(kind, action), n, seed=77, first_env_id=5)
+    oobs = ob.reset()
+    st = env.get_state()
+    q, v, c, w, aux = ob.get_state()
+    assert np.abs(qfix(st["qpos"], q) - q).max() < 1e-6
+    assert np.abs(st["qvel"] - v).max() < 1e-5
+    assert np.abs(st["ctrl"] - c).max() < 1e-12
+    assert np.abs(st["aux"][:, AUX["reset_psi"]] - aux["reset_psi"]).max() < 1e-6
+    assert np.abs(obs - oobs).max() < 1e-5
+    # and the first steps after the reset, including the heading ring the settle left behind (turn mode)
+    rng = np.random.default_rng(3)
+    for t in range(3):
+        a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+        o_obs, o_rew, o_term, _, _, _ = ob.step(a, auto_reset=False)
+        g_obs, g_rew, g_term, _ = env.step(a)
+        assert np.abs(g_rew - o_rew).max() < 1e-4 and np.abs(g_obs - o_obs).max() < 1e-3
+    env.close(); ob.close()
+
+
+def test_reset_fp32_close_to_oracle(oracle):
+    from tensegrity_rl_amd import TensegrityVecEnv
+    O = oracle
+    n = 128
+    env = TensegrityVecEnv(n, "tr_env-v0", precision="f32", auto_reset=False, seed=5)
+    obs = env.reset()
+    ob = O.OracleBatch(O.make_cfg("tr_env", "straight"), n, seed=5)
+    oobs = ob.reset()
+    st = env.get_state(); q = ob.get_state()[0]
+    err = np.abs(qfix(st["qpos"], q) - q).max(axis=1)
+    assert np.median(err) < 1e-3 and np.mean(err < 2e-2) > 0.9  # 1000 sub-steps; settling is dissipative but not contractive
+    assert np.isfinite(obs).all() and np.median(np.abs(obs - oobs).max(axis=1)) < 5e-3
+    env.close(); ob.close()
+
+
+def test_vecenv_contract_autoreset_truncation_and_donors(oracle):
+    """SB3 VecEnv semantics [ext]: auto-reset, terminal_observation, TimeLimit.truncated, Monitor-style episode info;
+    and the state an env receives from a donor lane is exactly reset_model() under that donor's RNG key."""
+    from tensegrity_rl_amd import TensegrityVecEnv
+    O = oracle
+    n = 16
+    env = TensegrityVecEnv(n, "tensegrity_env-v0", precision="f64", max_episode_steps=3, seed=11, n_donors=32, info_mode="full")
+    assert env.observation_space.shape == (39,) and env.action_space.shape == (6,) and env.action_space.dtype == np.float32
+    assert abs(float(env.action_space.low[0]) + 0.45) < 1e-6 and abs(float(env.action_space.high[0]) - 0.15) < 1e-6
+    obs = env.reset()
+    assert obs.shape == (n, 39) and obs.dtype == np.float64
+    rng = np.random.default_rng(0)
+    rets = np.zeros(n)
+    for t in range(3):
+        a = (-0.2 + 0.02 * rng.standard_normal((n, 6))).astype(np.float32)  # gentle: nobody terminates before the time limit
+        obs, rew, dones, infos = env.step(a)
+        assert t == 2 or not dones.any()
+        rets += rew
+        assert rew.dtype == np.float32 and dones.dtype == bool and len(infos) == n
+        assert {"reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi", "distance_from_origin",
+                "x_velocity", "y_velocity", "forward_reward"} <= set(infos[0])
+    assert dones.all()  # TimeLimit at 3 steps
+    for i in range(n):
+        assert "terminal_observation" in infos[i] and infos[i]["terminal_observation"].shape == (39,)
+        assert infos[i]["episode"]["l"] == 3 and abs(infos[i]["episode"]["r"] - rets[i]) < 1e-4
+        assert isinstance(infos[i]["TimeLimit.truncated"], bool)
+        assert not np.allclose(infos[i]["terminal_observation"], obs[i])  # obs row already belongs to the new episode
+    st = env.get_state()
+    stats = env.stats()
+    assert stats["donor_resets"] == n and st["aux"][:, AUX["elapsed"]].max() == 0
+    # every env now carries a donor's settled episode: reproduce it with the oracle from (key, episode)
+    cfg = O.make_cfg("tensegrity_env", "straight")
+    for i in range(0, n, 5):
+        src = int(st["aux"][i, AUX["src"]]); ep = int(st["aux"][i, AUX["episode"]])
+        assert src >= n
+        key = env.lib.tgr_lane_key(env.handle, src)
+        oe = O.OracleEnv(cfg)
+        oobs = oe.reset_seeded(11, key, ep)
+        assert np.abs(qfix(st["qpos"][i], O.arr(oe.data.qpos)) - O.arr(oe.data.qpos)).max() < 1e-6
+        assert np.abs(obs[i] - oobs).max() < 1e-5
+    # Gym single-env API
+    from tensegrity_rl_amd import make
+    e1 = make("tr_env-v0", precision="f64", seed=3)
+    o, info = e1.reset()
+    assert o.shape == (45,) and info == {}
+    o, r, term, trunc, info = e1.step(np.zeros(6, dtype=np.float32))
+    assert isinstance(r, float) and isinstance(term, bool) and trunc is False and "waypt" in info and e1.dt == 0.02
+    with pytest.raises(ValueError):
+        e1.step(np.zeros(5))
+    e1.close(); env.close()
+
+
+def test_starved_envs_fall_back_to_settle_kernel(oracle):
+    from tensegrity_rl_amd import TensegrityVecEnv
+    n = 8
+    env = TensegrityVecEnv(n, "tr_env-v0", precision="f32", max_episode_steps=2, n_donors=0, seed=1)
+    env.reset()
+    a = np.zeros((n, 6), dtype=np.float32)
+    env.step(a); obs, rew, dones, infos = env.step(a)
+    assert dones.all() and env.stats()["settle_kernel_resets"] == 2 * n and env.stats()["donor_resets"] == 0
+    st = env.get_state()
+    assert (st["aux"][:, AUX["src"]] == np.arange(n)).all() and (st["aux"][:, AUX["episode"]] == 1).all()
+    env.close()
+
+
+def test_full_size_properties():
+    """BASELINE config size (N = 4096): size-independent properties -- determinism, shard invariance, finiteness,
+    unit quaternions, done envs restart with elapsed = 0."""
+    import torch
+    from tensegrity_rl_amd import TensegrityVecEnv
+    n = 4096
+
+    def rollout(first, count, steps=12):
+        env = TensegrityVecEnv(count, "tensegrity_env-v0", seed=42, first_env_id=first, auto_reset=False)
+        env.reset_tensors()
+        g = torch.Generator(device="cuda"); g.manual_seed(9)
+        acts = [torch.rand((n, 6), device="cuda", generator=g) * 0.6 - 0.45 for _ in range(steps)]
+        outs = []
+        for a in acts:
+            o, r, te, tr, _, _ = env.step_tensors(a[first:first + count].contiguous())
+            outs.append((o.clone(), r.clone(), te.clone()))
+        st = env.get_state(); env.close()
+        return outs, st
+
+    full, st_full = rollout(0, n)
+    again, _ = rollout(0, n)
+    for (o1, r1, t1), (o2, r2, t2) in zip(full, again):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(t1, t2)  # bitwise deterministic
+    part, st_part = rollout(1024, 512)
+    for (o1, r1, t1), (o2, r2, t2) in zip(full, part):
+        assert torch.equal(o1[1024:1536], o2) and torch.equal(r1[1024:1536], r2)  # results do not depend on the sharding
+    o, r, t = full[-1]
+    assert torch.isfinite(o).all() and torch.isfinite(r).all()
+    q = st_full["qpos"].reshape(n, 3, 7)[:, :, 3:]
+    assert np.abs(np.linalg.norm(q, axis=2) - 1).max() < 1e-5
+    assert np.abs(o[:, :12].cpu().numpy().reshape(n, 3, 4) ** 2).sum(axis=2).max() < 1 + 1e-4
+    # auto-reset at full size
+    env = TensegrityVecEnv(n, "tensegrity_env-v0", seed=42, max_episode_steps=4)
+    env.reset_tensors()
+    for i in range(4):
+        o, r, te, tr, tobs, info = env.step_tensors(torch.zeros((n, 6), device="cuda") - 0.2)
+    trh = tr.cpu().numpy().astype(bool)
+    assert trh.mean() > 0.9  # the rest terminated earlier and restarted their clock
+    assert env.get_state()["aux"][trh, 6].max() == 0 and env.stats()["donor_resets"] >= int(trh.sum())
+    assert env.stats()["settle_kernel_resets"] == 3 * n  # the initial reset of envs + donors only: nobody was starved
+    env.close()

@@ -1,0 +1,116 @@
+"""Physics restatement (oracle/tgr_physics.c) against the only MuJoCo-generated material the reference ships
+ plus self-consistency properties.  Physics vs MuJoCo itself stays "parity unpinned"."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_fk_tendon_table_qpos0(oracle):
+    """xml:71,90,108 initial pose -> tendon lengths / cap heights recorded in SURVEY.md App. D."""
+    O = oracle
+    m = O.default_model(); d = O.new_data(m)
+    O.lib().tgo_forward(C.byref(m), C.byref(d))
+    np.testing.assert_allclose(O.arr(d.ten_length), [0.57384, 0.57174, 0.57109, 0.57362, 0.57200, 0.57000, 1.05355, 1.05407, 1.05429], atol=6e-6)
+    np.testing.assert_allclose(O.arr(d.cap_xpos)[:, 2], [0.0499, 0.4467, 0.6513, 0.0497, 0.0498, 0.7409], atol=6e-5)
+    assert abs(m.mass - 4.0) < 1e-12 and abs(m.inertia[0] - 1.0964112358) < 1e-9 and abs(m.inertia[2] - 0.003773305) < 1e-9
+
+
+def test_fk_rolling_poses(oracle):
+    """tr_env.py:723-728: settled MuJoCo poses; FK values of SURVEY.md App. D; rows 3,4,5 are bar relabelings."""
+    O = oracle
+    m = O.default_model(); rq = O.rolling_qpos()
+    d = O.new_data(m); O.arr(d.qpos)[:] = rq[0]
+    O.lib().tgo_forward(C.byref(m), C.byref(d))
+    np.testing.assert_allclose(O.arr(d.ten_length), [0.47567, 0.47418, 0.47287, 0.47659, 0.47329, 0.47162, 1.11797, 1.11944, 1.13383], atol=6e-6)
+    np.testing.assert_allclose(rq[4][:7], rq[3][7:14], atol=0)
+    np.testing.assert_allclose(rq[5][:7], rq[3][14:21], atol=0)
+
+
+@pytest.mark.parametrize("pose", range(6))
+def test_rolling_poses_are_near_equilibria(oracle, pose):
+    """The six poses were produced by MuJoCo's own settle.  With the best-fitting constant ctrl, this restatement must
+    leave them (nearly) static: residual generalised forces below 10 N (the captures still carry ~cm/s of motion,
+    i.e. a few N of tendon damping), total floor reaction within 3 % of the weight.  A wrong contact stiffness scaling
+    (e.g. no 1/dmax^2) or tendon table would miss this by 10 % or more."""
+    from scipy.optimize import least_squares
+    O = oracle
+    L = O.lib(); m = O.default_model(); rq = O.rolling_qpos()
+    d = O.new_data(m); O.arr(d.qpos)[:] = rq[pose]
+    L.tgo_forward(C.byref(m), C.byref(d))
+    tl = O.arr(d.ten_length).copy()
+
+    def res(c):
+        O.arr(d.ctrl)[:] = c; O.arr(d.qacc_warmstart)[:] = 0
+        L.tgo_forward(C.byref(m), C.byref(d))
+        return O.arr(d.qacc).copy()
+
+    c0 = (-100 - 3290 + 6666 * tl[:6]) / 6667
+    r = least_squares(res, c0, bounds=(-0.45, 0.15), x_scale=0.01)
+    q = res(r.x)
+    Md = np.tile([4, 4, 4, m.inertia[0], m.inertia[1], m.inertia[2]], 3)
+    assert np.abs(Md * q).max() < 10.0  # newton; tendon and contact forces here are 40-70 N each
+    fz = sum(d.con[k].force[0] for k in range(d.ncon))
+    assert d.ncon == 3 and abs(fz - 12 * 9.81) < 0.05 * 12 * 9.81
+    caps = sorted(O.arr(d.cap_xpos)[:, 2])[:3]
+    assert all(0.0670 < z < 0.0675 for z in caps)  # 0.1-0.5 mm penetration of r = 0.0675 caps
+
+
+def test_settle_reaches_rest_on_three_caps(oracle):
+    O = oracle
+    L = O.lib(); m = O.default_model(); d = O.new_data(m)
+    O.arr(d.ctrl)[:] = -0.15
+    L.tgo_step(C.byref(m), C.byref(d), 1500)
+    assert d.ncon == 3 and d.flags == 0
+    assert np.abs(O.arr(d.qvel)).max() < 0.2
+    assert sorted(O.arr(d.cap_xpos)[:, 2])[2] < 0.0675
+
+
+def test_yaw_invariance_of_dynamics(oracle):
+    """Flat floor: rotating the whole state about z commutes with stepping."""
+    O = oracle
+    L = O.lib(); m = O.default_model()
+    outs = []
+    for theta in (0.0, 1.234):
+        d = O.new_data(m)
+        q = np.zeros(21)
+        L.tgo_yaw_pose(O.dptr(np.array(m.qpos0)), theta, O.dptr(q))
+        O.arr(d.qpos)[:] = q; O.arr(d.ctrl)[:] = [-0.2, -0.1, -0.3, -0.15, -0.25, -0.2]
+        L.tgo_step(C.byref(m), C.byref(d), 300)
+        outs.append((O.arr(d.qpos).copy(), O.arr(d.ten_length).copy()))
+    np.testing.assert_allclose(outs[0][1], outs[1][1], atol=1e-7)
+    np.testing.assert_allclose(outs[0][0][[2, 9, 16]], outs[1][0][[2, 9, 16]], atol=1e-7)
+
+
+def test_bar_relabeling_invariance(oracle):
+    """rolling_qpos[3..5] are the same physical pose with the bars renamed cyclically; tendon lengths permute accordingly."""
+    O = oracle
+    L = O.lib(); m = O.default_model(); rq = O.rolling_qpos()
+    ls = []
+    for i in (3, 4, 5):
+        d = O.new_data(m); O.arr(d.qpos)[:] = rq[i]
+        L.tgo_forward(C.byref(m), C.byref(d))
+        ls.append(O.arr(d.ten_length).copy())
+    assert np.allclose(sorted(ls[0][:6]), sorted(ls[1][:6]), atol=1e-12) and np.allclose(sorted(ls[0][6:]), sorted(ls[2][6:]), atol=1e-12)
+
+
+def test_philox_known_answer(oracle):
+    """Random123 known-answer test for philox4x32-10 (counter = key = 0 and the all-ones vector)."""
+    O = oracle
+    out = (C.c_uint32 * 4)()
+    O.lib().tgo_philox4x32((C.c_uint32 * 4)(0, 0, 0, 0), (C.c_uint32 * 2)(0, 0), out)
+    assert [hex(x) for x in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    O.lib().tgo_philox4x32((C.c_uint32 * 4)(*[0xFFFFFFFF] * 4), (C.c_uint32 * 2)(0xFFFFFFFF, 0xFFFFFFFF), out)
+    assert [hex(x) for x in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+def test_reset_draw_distributions(oracle):
+    O = oracle
+    th, tend = [], []
+    for i in range(2000):
+        pose = C.c_int(); theta = C.c_double(); t = (C.c_double * 6)(); u = (C.c_double * 2)()
+        O.lib().tgo_rng_draws(1234, i, 0, 1, 0.15, 0.2, -0.45, 0.15, 0.0, 2 * np.pi, C.byref(pose), C.byref(theta), t, u)
+        th.append(theta.value); tend.append(list(t)); assert 0 <= pose.value < 6
+    th = np.array(th); tend = np.array(tend)
+    assert 0 <= th.min() and th.max() < 2 * np.pi and abs(th.mean() - np.pi) < 0.15
+    assert tend.max() <= 0.15 and tend.min() >= -0.45 and abs(np.mean(tend >= 0.15) - 0.5) < 0.03
