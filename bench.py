@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched tensegrity step on N MI355X (BASELINE.json metric).
+
+One "step" = one control period (20 physics sub-steps of 1 ms) of every env: ONE pass of the hot path over the batch.
+Workload at every N: BASELINE.json configs[1] per GPU -- 3-bar flat ground, tensegrity_env-v0 straight/+1, 4096 envs per
+GPU, i.i.d. U[-0.45, 0.15]^6 float32 actions generated on the device before the timed region, auto-reset on (finished envs
+restart from donor lanes inside the same launches, so resets are part of the measured time).  Weak scaling: rank g owns
+global env ids [g*4096, (g+1)*4096); no collective on the data path, one RCCL all-gather of the rollout buffers
+(obs, reward, done) per --gather-every steps, inside the timed region.
+
+Prints ONE JSON line (rank 0).  roofline: algorithmic HBM bytes (674 B per env-step) over the step kernel's
+mean duration measured with HIP events on the launch stream.  cpu_baseline: the CPU oracle (oracle/, fp64 restatement --
+MuJoCo is not installed) timed on the host cores for a bounded sample; a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_ENV_STEP = 674  # fp32: 61 state words in + 6 action words in, 61 state words + 39 obs words + reward + 2 flags out
+HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate 6290
+
+
+def cpu_baseline(seconds, envs):
+    """oracle batch (OpenMP over envs) on this host: env-steps/s with the same semantics (auto-reset included)."""
+    import numpy as np
+    from oracle import oracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    threads = min(cores, envs)
+    ob = O.OracleBatch(O.make_cfg("tensegrity_env", "straight"), envs, seed=1234, threads=threads)
+    ob.reset()
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-0.45, 0.15, (8, envs, 6)).astype(np.float32)
+    ob.step(acts[0])
+    t0 = time.time(); steps = 0
+    while time.time() - t0 < seconds:
+        ob.step(acts[steps % 8]); steps += 1
+    dt = time.time() - t0
+    ob.close()
+    return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{envs} envs x {steps} steps ({dt:.1f} s), oracle/ fp64 CPU restatement with OpenMP over envs, auto-reset on"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--env-id", default="tensegrity_env-v0")
+    ap.add_argument("--donors", type=int, default=-1)
+    ap.add_argument("--gather-every", type=int, default=16)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tensegrity_rl_amd import TensegrityVecEnv
+    from tensegrity_rl_amd.sharding import RolloutGatherer, shard_range
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the HIP path is the product and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_local = args.envs_per_gpu
+    n_total = n_local * world
+    lo, hi = shard_range(rank, world, n_total)
+    env = TensegrityVecEnv(n_local, args.env_id, device=local_rank, desired_action="straight", desired_direction=1,
+                           seed=1234, first_env_id=lo, n_donors=args.donors)
+    env.reset_tensors()
+    g = torch.Generator(device=dev); g.manual_seed(rank)
+    acts = [(torch.rand((n_local, 6), device=dev, generator=g) * 0.6 - 0.45).contiguous() for _ in range(32)]
+    gather = RolloutGatherer(n_local, env.obs_dim, args.gather_every, dev, world_size=world) if world > 1 else None
+
+    def one_step(i):
+        obs, rew, term, trunc, _, _ = env.step_tensors(acts[i % 32])
+        if gather is not None:
+            gather.push(obs, rew, term, trunc)
+
+    for i in range(args.warmup):
+        one_step(i)
+    stats0 = env.stats()
+    # kernel-only timing of the dominant kernel with HIP events on the launch stream (roofline.achieved)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record()
+        one_step(args.warmup + i)
+        evs[i][1].record()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    stats1 = env.stats()
+    step_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    kern_ms = sum(step_ms) / len(step_ms)
+
+    if rank == 0:
+        value = n_total * args.steps / dt
+        launch_bytes = BYTES_PER_ENV_STEP * n_local
+        achieved = launch_bytes / (kern_ms * 1e-3) / 1e9
+        resets = stats1["donor_resets"] - stats0["donor_resets"] + stats1["settle_kernel_resets"] - stats0["settle_kernel_resets"]
+        out = {
+            "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"3-bar flat-ground {args.env_id} straight/+1, N_envs={n_local} per GPU ({n_total} total), "
+                                   "random-action rollout U[-0.45,0.15]^6, auto-reset via donor lanes, 20 sub-steps of 1 ms per step",
+                       "envs_per_gpu": n_local, "donor_lanes_per_gpu": env.cfg.n_donors if env.cfg.n_donors >= 0 else 2 * n_local,
+                       "gather_every": args.gather_every if world > 1 else None,
+                       "resets_per_step_rank0": resets / args.steps,
+                       "newton_iters_per_substep": stats1["newton_iters_per_substep"],
+                       "starved_resets_rank0": stats1["settle_kernel_resets"] - stats0["settle_kernel_resets"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None,
+                         "note": "step_kernel: 674 algorithmic B per env-step x envs per launch / mean launch duration (HIP events around "
+                                 "the step+match+settle launches of one step); the path is VALU-issue bound (~1e6 flop per env-step), "
+                                 "not HBM bound: see DESIGN.md",
+                         "kernel_ms": kern_ms, "kernel_ms_p50": step_ms[len(step_ms) // 2]},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 64)
+            except Exception as e:  # the oracle is test infrastructure; never let it break the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
