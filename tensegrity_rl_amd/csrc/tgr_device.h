@@ -89,7 +89,8 @@ enum : int {
   L_FC = L_P + 18,      // constraint wrench per bar (J^T f) == cfrc_ext
   L_EZ = L_FC + 18,     // bar axes (3 x 3)
   L_X = L_EZ + 9,       // bar COM positions (3 x 3)
-  L_TOTAL = L_X + 9     // 495
+  L_RED = L_X + 9,      // cross-wave partial sums (24)
+  L_TOTAL = L_RED + 24  // 519
 };
 constexpr __host__ __device__ int H_D(int b) { return L_H + 21 * b; }
 constexpr int H_O10 = L_H + 63, H_O20 = L_H + 99, H_O21 = L_H + 135;
@@ -629,15 +630,35 @@ TGR_DEV int pair_A(int p) { return p == 2 ? 1 : 0; }
 TGR_DEV int pair_B(int p) { return p == 0 ? 1 : 2; }
 TGR_DEV int pair_O(int p) { return p == 0 ? H_O10 : (p == 1 ? H_O20 : H_O21); }
 
-// ------------------------------------------------------------------ Newton pieces (LDS-centric)
-// evaluate every contact at the current A (in LDS): builds Hessian blocks, constraint wrench FC, gradient G.
-// returns |G|^2 ; cpl[p] = some lane of the wave couples pair p
+// ------------------------------------------------------------------ Newton pieces (LDS-centric, 4 waves per block)
+// The 64 envs of a block are worked on by FOUR wavefronts; lane i of every wave is env i, and the LDS columns are
+// shared.  All four waves hold the same per-lane registers (they run the cheap phases redundantly) and split the
+// contact solve:   wave 0,1,2 = bar 0,1,2 (own 6x6 diagonal block, own floor caps, gradient rows)
+//                  wave 3     = the off-diagonal (bar-pair) blocks and the pair slots of the line search
+// Every decision that steers control flow is computed from shared LDS data, so it is identical in the four waves and
+// the __syncthreads() below are reached uniformly.
+
+// which pairs touch bar b, and as which body:  pair p = (A,B): (0,1), (0,2), (1,2)
+TGR_DEV int bar_pair(int b, int j) { return b == 0 ? j : (b == 1 ? (j == 0 ? 0 : 2) : (j == 0 ? 1 : 2)); }
+TGR_DEV bool bar_is_B(int b, int j) { return b == 0 ? false : (b == 1 ? (j == 0) : true); }
+
 template <typename T, int LW>
-TGR_DEV T newton_assemble(const Params<T>& P, T* lds, unsigned& cpl, T& cfrc_max) {
-  cpl = 0u;
-  // ---- per bar: mass block + its two floor contacts
-#pragma unroll 1
-  for (int b = 0; b < 3; b++) {
+TGR_DEV unsigned pair_coupling(const T* lds) {
+  unsigned cpl = 0u;
+#pragma unroll
+  for (int p = 0; p < 3; p++) {
+    bool a = (lds[(L_CP + 12 * (2 * p) + 11) * LW] != T(0)) || (lds[(L_CP + 12 * (2 * p + 1) + 11) * LW] != T(0));
+    if (__any(a)) cpl |= 1u << p;
+  }
+  return cpl;
+}
+
+// evaluate the contacts at the current A (in LDS): Hessian blocks, constraint wrench FC, gradient G.
+// returns |G|^2 (all waves) ; cfrc_max = max |FC|
+template <typename T, int LW>
+TGR_DEV T newton_assemble(const Params<T>& P, T* lds, int wid, unsigned cpl, T& cfrc_max) {
+  if (wid < 3) {
+    const int b = wid;
     V3<T> ez = ld3<T, LW>(lds, L_EZ + 3 * b);
     T D[21];
 #pragma unroll
@@ -647,8 +668,9 @@ TGR_DEV T newton_assemble(const Params<T>& P, T* lds, unsigned& cpl, T& cfrc_max
     D[tri(3, 3)] = P.Ixx + dI * ez.x * ez.x;
     D[tri(4, 3)] = dI * ez.y * ez.x; D[tri(4, 4)] = P.Ixx + dI * ez.y * ez.y;
     D[tri(5, 3)] = dI * ez.z * ez.x; D[tri(5, 4)] = dI * ez.z * ez.y; D[tri(5, 5)] = P.Ixx + dI * ez.z * ez.z;
-    V3<T> yl = ld3<T, LW>(lds, L_A + 6 * b) + ld3<T, LW>(lds, L_BV + 6 * b);
-    V3<T> ya = ld3<T, LW>(lds, L_A + 6 * b + 3) + ld3<T, LW>(lds, L_BV + 6 * b + 3);
+    V3<T> al = ld3<T, LW>(lds, L_A + 6 * b), aa = ld3<T, LW>(lds, L_A + 6 * b + 3);
+    V3<T> yl = al + ld3<T, LW>(lds, L_BV + 6 * b);
+    V3<T> ya = aa + ld3<T, LW>(lds, L_BV + 6 * b + 3);
     V3<T> fl = mk(T(0), T(0), T(0)), fa = fl;
 #pragma unroll 1
     for (int e = 0; e < 2; e++) {
@@ -662,87 +684,91 @@ TGR_DEV T newton_assemble(const Params<T>& P, T* lds, unsigned& cpl, T& cfrc_max
         self_block_add(D, o, c.n, c.rB);
       }
     }
+    // pair slots that touch this bar: this wave adds its own diagonal contribution and wrench
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+      const int p = bar_pair(b, j);
+      if (!((cpl >> p) & 1u)) continue;
+      const bool isB = bar_is_B(b, j);
+      const int o_ = isB ? pair_A(p) : pair_B(p);  // the other bar
+      V3<T> ylo = ld3<T, LW>(lds, L_A + 6 * o_) + ld3<T, LW>(lds, L_BV + 6 * o_);
+      V3<T> yao = ld3<T, LW>(lds, L_A + 6 * o_ + 3) + ld3<T, LW>(lds, L_BV + 6 * o_ + 3);
+#pragma unroll 1
+      for (int s = 0; s < 2; s++) {
+        Contact<T> c = load_pair<T, LW>(lds, 2 * p + s);
+        if (!__any(c.active)) continue;
+        V3<T> r_me = isB ? c.rB : c.rA, r_ot = isB ? c.rA : c.rB;
+        V3<T> rel_l = (yl + cross(ya, r_me)) - (ylo + cross(yao, r_ot));
+        V3<T> rel_a = ya - yao;
+        T sg = isB ? T(1) : T(-1);
+        V3<T> jl = sg * rel_l + c.c0 * c.n;
+        V3<T> ja = sg * rel_a;
+        Cone<T> o = cone_eval(P, c, jl, ja);
+        fl = fl + sg * o.fl;
+        fa = fa + sg * (cross(r_me, o.fl) + o.fa);
+        self_block_add(D, o, c.n, r_me);
+      }
+    }
     st21<T, LW>(lds, H_D(b), D);
     st3<T, LW>(lds, L_FC + 6 * b, fl);
     st3<T, LW>(lds, L_FC + 6 * b + 3, fa);
-  }
-  // ---- bar pairs
-#pragma unroll 1
-  for (int p = 0; p < 3; p++) {
-    const int A = pair_A(p), B = pair_B(p);
-    Contact<T> c0 = load_pair<T, LW>(lds, 2 * p);
-    Contact<T> c1 = load_pair<T, LW>(lds, 2 * p + 1);
-    bool any0 = __any(c0.active), any1 = __any(c1.active);
-    if (!(any0 || any1)) continue;
-    cpl |= 1u << p;
-    T DA[21], DB[21], O[36];
-    ld21<T, LW>(lds, H_D(A), DA);
-    ld21<T, LW>(lds, H_D(B), DB);
-#pragma unroll
-    for (int i = 0; i < 36; i++) O[i] = T(0);
-    V3<T> ylA = ld3<T, LW>(lds, L_A + 6 * A) + ld3<T, LW>(lds, L_BV + 6 * A);
-    V3<T> yaA = ld3<T, LW>(lds, L_A + 6 * A + 3) + ld3<T, LW>(lds, L_BV + 6 * A + 3);
-    V3<T> ylB = ld3<T, LW>(lds, L_A + 6 * B) + ld3<T, LW>(lds, L_BV + 6 * B);
-    V3<T> yaB = ld3<T, LW>(lds, L_A + 6 * B + 3) + ld3<T, LW>(lds, L_BV + 6 * B + 3);
-    V3<T> flA = mk(T(0), T(0), T(0)), faA = flA, flB = flA, faB = flA;
-#pragma unroll 1
-    for (int s = 0; s < 2; s++) {
-      if (!(s == 0 ? any0 : any1)) continue;
-      Contact<T> c = s == 0 ? c0 : c1;
-      V3<T> jl = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
-      V3<T> ja = yaB - yaA;
-      Cone<T> o = cone_eval(P, c, jl, ja);
-      flB = flB + o.fl; faB = faB + cross(c.rB, o.fl) + o.fa;
-      flA = flA - o.fl; faA = faA - (cross(c.rA, o.fl) + o.fa);
-      self_block_add(DB, o, c.n, c.rB);
-      self_block_add(DA, o, c.n, c.rA);
-      cross_block_add(O, o, c.n, c.rB, c.rA);
-    }
-    st21<T, LW>(lds, H_D(A), DA);
-    st21<T, LW>(lds, H_D(B), DB);
-    st36<T, LW>(lds, pair_O(p), O);
-    st3<T, LW>(lds, L_FC + 6 * A, ld3<T, LW>(lds, L_FC + 6 * A) + flA);
-    st3<T, LW>(lds, L_FC + 6 * A + 3, ld3<T, LW>(lds, L_FC + 6 * A + 3) + faA);
-    st3<T, LW>(lds, L_FC + 6 * B, ld3<T, LW>(lds, L_FC + 6 * B) + flB);
-    st3<T, LW>(lds, L_FC + 6 * B + 3, ld3<T, LW>(lds, L_FC + 6 * B + 3) + faB);
-  }
-  // ---- gradient  G = M (a - a0) - FC
-  T gn = T(0);
-  cfrc_max = T(0);
-#pragma unroll 1
-  for (int b = 0; b < 3; b++) {
-    V3<T> ez = ld3<T, LW>(lds, L_EZ + 3 * b);
-    V3<T> dl = ld3<T, LW>(lds, L_A + 6 * b) - ld3<T, LW>(lds, L_A0 + 6 * b);
-    V3<T> da = ld3<T, LW>(lds, L_A + 6 * b + 3) - ld3<T, LW>(lds, L_A0 + 6 * b + 3);
-    V3<T> fl = ld3<T, LW>(lds, L_FC + 6 * b), fa = ld3<T, LW>(lds, L_FC + 6 * b + 3);
+    V3<T> dl = al - ld3<T, LW>(lds, L_A0 + 6 * b);
+    V3<T> da = aa - ld3<T, LW>(lds, L_A0 + 6 * b + 3);
     V3<T> gl = P.mass * dl - fl;
     V3<T> ga = inertia_mul(P, ez, da) - fa;
     st3<T, LW>(lds, L_G + 6 * b, gl);
     st3<T, LW>(lds, L_G + 6 * b + 3, ga);
-    gn += dot(gl, gl) + dot(ga, ga);
-    cfrc_max = max_(cfrc_max, max_(max_(abs_(fl.x), abs_(fl.y)), abs_(fl.z)));
-    cfrc_max = max_(cfrc_max, max_(max_(abs_(fa.x), abs_(fa.y)), abs_(fa.z)));
+    lds[(L_RED + b) * LW] = dot(gl, gl) + dot(ga, ga);
+    lds[(L_RED + 3 + b) * LW] = max_(max_(max_(abs_(fl.x), abs_(fl.y)), abs_(fl.z)), max_(max_(abs_(fa.x), abs_(fa.y)), abs_(fa.z)));
+  } else {
+    // wave 3: off-diagonal blocks
+#pragma unroll 1
+    for (int p = 0; p < 3; p++) {
+      if (!((cpl >> p) & 1u)) continue;
+      const int A = pair_A(p), B = pair_B(p);
+      T O[36];
+#pragma unroll
+      for (int i = 0; i < 36; i++) O[i] = T(0);
+      V3<T> ylA = ld3<T, LW>(lds, L_A + 6 * A) + ld3<T, LW>(lds, L_BV + 6 * A);
+      V3<T> yaA = ld3<T, LW>(lds, L_A + 6 * A + 3) + ld3<T, LW>(lds, L_BV + 6 * A + 3);
+      V3<T> ylB = ld3<T, LW>(lds, L_A + 6 * B) + ld3<T, LW>(lds, L_BV + 6 * B);
+      V3<T> yaB = ld3<T, LW>(lds, L_A + 6 * B + 3) + ld3<T, LW>(lds, L_BV + 6 * B + 3);
+#pragma unroll 1
+      for (int s = 0; s < 2; s++) {
+        Contact<T> c = load_pair<T, LW>(lds, 2 * p + s);
+        if (!__any(c.active)) continue;
+        V3<T> jl = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
+        V3<T> ja = yaB - yaA;
+        Cone<T> o = cone_eval(P, c, jl, ja);
+        cross_block_add(O, o, c.n, c.rB, c.rA);
+      }
+      st36<T, LW>(lds, pair_O(p), O);
+    }
   }
+  __syncthreads();
+  T gn = lds[L_RED * LW] + lds[(L_RED + 1) * LW] + lds[(L_RED + 2) * LW];
+  cfrc_max = max_(max_(lds[(L_RED + 3) * LW], lds[(L_RED + 4) * LW]), lds[(L_RED + 5) * LW]);
   return gn;
 }
 
-// blocked Cholesky of the Hessian in LDS, then P = -H^-1 G (P = 0 for converged lanes)
-template <typename T, int LW> TGR_DEV void newton_direction(T* lds, unsigned cpl, bool conv) {
+// blocked Cholesky of the Hessian in LDS spread over the waves, then P = -H^-1 G (P = 0 for converged lanes)
+template <typename T, int LW> TGR_DEV void newton_direction(T* lds, int wid, unsigned cpl, bool conv) {
   const bool c10 = cpl & 1u, c20 = cpl & 2u, c21in = cpl & 4u;
   const bool c21 = c21in || (c10 && c20);  // fill-in
-  T L[21];
   // column 0
-  ld21<T, LW>(lds, H_D(0), L);
-  chol6(L);
-  st21<T, LW>(lds, H_D(0), L);
-  if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); trsm6(O, L); st36<T, LW>(lds, H_O10, O); }
-  if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); trsm6(O, L); st36<T, LW>(lds, H_O20, O); }
-  // column 1
-  ld21<T, LW>(lds, H_D(1), L);
-  if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); syrk6(L, O); }
-  chol6(L);
-  st21<T, LW>(lds, H_D(1), L);
-  if (c21) {
+  if (wid == 0) { T L[21]; ld21<T, LW>(lds, H_D(0), L); chol6(L); st21<T, LW>(lds, H_D(0), L); }
+  __syncthreads();
+  if (wid == 1 && c10) { T L[21], O[36]; ld21<T, LW>(lds, H_D(0), L); ld36<T, LW>(lds, H_O10, O); trsm6(O, L); st36<T, LW>(lds, H_O10, O); }
+  if (wid == 2 && c20) { T L[21], O[36]; ld21<T, LW>(lds, H_D(0), L); ld36<T, LW>(lds, H_O20, O); trsm6(O, L); st36<T, LW>(lds, H_O20, O); }
+  if (c10 || c20) __syncthreads();
+  // column 1 (wave 1), trailing updates that only need column 0 (waves 2, 3)
+  if (wid == 1) {
+    T L[21]; ld21<T, LW>(lds, H_D(1), L);
+    if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); syrk6(L, O); }
+    chol6(L); st21<T, LW>(lds, H_D(1), L);
+  }
+  if (wid == 2 && c20) { T L[21], O[36]; ld21<T, LW>(lds, H_D(2), L); ld36<T, LW>(lds, H_O20, O); syrk6(L, O); st21<T, LW>(lds, H_D(2), L); }
+  if (wid == 3 && c21) {
     T O21[36];
     if (c21in) ld36<T, LW>(lds, H_O21, O21);
     else {
@@ -750,45 +776,54 @@ template <typename T, int LW> TGR_DEV void newton_direction(T* lds, unsigned cpl
       for (int i = 0; i < 36; i++) O21[i] = T(0);
     }
     if (c10 && c20) { T Oa[36], Ob[36]; ld36<T, LW>(lds, H_O20, Oa); ld36<T, LW>(lds, H_O10, Ob); gemm6(O21, Oa, Ob); }
-    trsm6(O21, L);
     st36<T, LW>(lds, H_O21, O21);
   }
-  // column 2
-  ld21<T, LW>(lds, H_D(2), L);
-  if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); syrk6(L, O); }
-  if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); syrk6(L, O); }
-  chol6(L);
-  st21<T, LW>(lds, H_D(2), L);
-  // ---- solve  L L^T x = G
-  T x0[6], x1[6], x2[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) { x0[i] = lds[(L_G + i) * LW]; x1[i] = lds[(L_G + 6 + i) * LW]; x2[i] = lds[(L_G + 12 + i) * LW]; }
-  ld21<T, LW>(lds, H_D(0), L); fsolve6(L, x0);
-  if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); gemv_sub(O, x0, x1); }
-  if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); gemv_sub(O, x0, x2); }
-  ld21<T, LW>(lds, H_D(1), L); fsolve6(L, x1);
-  if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); gemv_sub(O, x1, x2); }
-  ld21<T, LW>(lds, H_D(2), L); fsolve6(L, x2);
-  bsolve6(L, x2);
-  if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); gemvT_sub(O, x2, x1); }
-  ld21<T, LW>(lds, H_D(1), L); bsolve6(L, x1);
-  if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); gemvT_sub(O, x2, x0); }
-  if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); gemvT_sub(O, x1, x0); }
-  ld21<T, LW>(lds, H_D(0), L); bsolve6(L, x0);
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    lds[(L_P + i) * LW] = conv ? T(0) : -x0[i];
-    lds[(L_P + 6 + i) * LW] = conv ? T(0) : -x1[i];
-    lds[(L_P + 12 + i) * LW] = conv ? T(0) : -x2[i];
+  __syncthreads();
+  if (c21) {
+    if (wid == 2) { T L[21], O[36]; ld21<T, LW>(lds, H_D(1), L); ld36<T, LW>(lds, H_O21, O); trsm6(O, L); st36<T, LW>(lds, H_O21, O); }
+    __syncthreads();
   }
+  // column 2
+  if (wid == 2) {
+    T L[21]; ld21<T, LW>(lds, H_D(2), L);
+    if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); syrk6(L, O); }
+    chol6(L); st21<T, LW>(lds, H_D(2), L);
+  }
+  __syncthreads();
+  // ---- solve  L L^T x = G   (serial chain: wave 0)
+  if (wid == 0) {
+    T L[21];
+    T x0[6], x1[6], x2[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { x0[i] = lds[(L_G + i) * LW]; x1[i] = lds[(L_G + 6 + i) * LW]; x2[i] = lds[(L_G + 12 + i) * LW]; }
+    ld21<T, LW>(lds, H_D(0), L); fsolve6(L, x0);
+    if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); gemv_sub(O, x0, x1); }
+    if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); gemv_sub(O, x0, x2); }
+    ld21<T, LW>(lds, H_D(1), L); fsolve6(L, x1);
+    if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); gemv_sub(O, x1, x2); }
+    ld21<T, LW>(lds, H_D(2), L); fsolve6(L, x2);
+    bsolve6(L, x2);
+    if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); gemvT_sub(O, x2, x1); }
+    ld21<T, LW>(lds, H_D(1), L); bsolve6(L, x1);
+    if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); gemvT_sub(O, x2, x0); }
+    if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); gemvT_sub(O, x1, x0); }
+    ld21<T, LW>(lds, H_D(0), L); bsolve6(L, x0);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      lds[(L_P + i) * LW] = conv ? T(0) : -x0[i];
+      lds[(L_P + 6 + i) * LW] = conv ? T(0) : -x1[i];
+      lds[(L_P + 12 + i) * LW] = conv ? T(0) : -x2[i];
+    }
+  }
+  __syncthreads();
 }
 
-// derivative of the cost along A + alpha P:  phi'(alpha), phi''(alpha)
+// derivative of the cost along A + alpha P:  phi'(alpha), phi''(alpha); waves 0-2 take their bar's caps, wave 3 the pairs
 template <typename T, int LW>
-TGR_DEV void newton_dphi(const Params<T>& P, const T* lds, unsigned cpl, T alpha, T g1, T g2, T& d1, T& d2) {
-  d1 = g1 + alpha * g2; d2 = g2;
-#pragma unroll 1
-  for (int b = 0; b < 3; b++) {
+TGR_DEV void newton_dphi(const Params<T>& P, T* lds, int wid, unsigned cpl, T alpha, T g1, T g2, T& d1, T& d2) {
+  T p1 = T(0), p2 = T(0);
+  if (wid < 3) {
+    const int b = wid;
     V3<T> pl = ld3<T, LW>(lds, L_P + 6 * b), pa = ld3<T, LW>(lds, L_P + 6 * b + 3);
     V3<T> yl = ld3<T, LW>(lds, L_A + 6 * b) + ld3<T, LW>(lds, L_BV + 6 * b) + alpha * pl;
     V3<T> ya = ld3<T, LW>(lds, L_A + 6 * b + 3) + ld3<T, LW>(lds, L_BV + 6 * b + 3) + alpha * pa;
@@ -800,46 +835,55 @@ TGR_DEV void newton_dphi(const Params<T>& P, const T* lds, unsigned cpl, T alpha
         jl.z += c.c0;
         V3<T> ql = pl + cross(pa, c.rB);
         Cone<T> o = cone_eval(P, c, jl, ya);
-        d1 -= dot(o.fl, ql) + dot(o.fa, pa);
+        p1 -= dot(o.fl, ql) + dot(o.fa, pa);
         T nl = ql.z, na = pa.z;
         T gq = dot(o.gl, ql) + dot(o.ga, pa), wq = dot(o.wl, ql) + dot(o.wa, pa);
-        d2 += o.a1 * dot(ql, ql) + o.a2 * nl * nl + o.b1 * dot(pa, pa) + o.b2 * na * na + o.cg * gq * gq + o.cw * wq * wq;
+        p2 += o.a1 * dot(ql, ql) + o.a2 * nl * nl + o.b1 * dot(pa, pa) + o.b2 * na * na + o.cg * gq * gq + o.cw * wq * wq;
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int p = 0; p < 3; p++) {
+      if (!((cpl >> p) & 1u)) continue;
+      const int A = pair_A(p), B = pair_B(p);
+      V3<T> plA = ld3<T, LW>(lds, L_P + 6 * A), paA = ld3<T, LW>(lds, L_P + 6 * A + 3);
+      V3<T> plB = ld3<T, LW>(lds, L_P + 6 * B), paB = ld3<T, LW>(lds, L_P + 6 * B + 3);
+      V3<T> ylA = ld3<T, LW>(lds, L_A + 6 * A) + ld3<T, LW>(lds, L_BV + 6 * A) + alpha * plA;
+      V3<T> yaA = ld3<T, LW>(lds, L_A + 6 * A + 3) + ld3<T, LW>(lds, L_BV + 6 * A + 3) + alpha * paA;
+      V3<T> ylB = ld3<T, LW>(lds, L_A + 6 * B) + ld3<T, LW>(lds, L_BV + 6 * B) + alpha * plB;
+      V3<T> yaB = ld3<T, LW>(lds, L_A + 6 * B + 3) + ld3<T, LW>(lds, L_BV + 6 * B + 3) + alpha * paB;
+#pragma unroll 1
+      for (int s = 0; s < 2; s++) {
+        Contact<T> c = load_pair<T, LW>(lds, 2 * p + s);
+        if (!__any(c.active)) continue;
+        V3<T> jl = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
+        V3<T> ja = yaB - yaA;
+        V3<T> ql = (plB + cross(paB, c.rB)) - (plA + cross(paA, c.rA));
+        V3<T> qa = paB - paA;
+        Cone<T> o = cone_eval(P, c, jl, ja);
+        p1 -= dot(o.fl, ql) + dot(o.fa, qa);
+        T nl = dot(c.n, ql), na = dot(c.n, qa);
+        T gq = dot(o.gl, ql) + dot(o.ga, qa), wq = dot(o.wl, ql) + dot(o.wa, qa);
+        p2 += o.a1 * dot(ql, ql) + o.a2 * nl * nl + o.b1 * dot(qa, qa) + o.b2 * na * na + o.cg * gq * gq + o.cw * wq * wq;
       }
     }
   }
-#pragma unroll 1
-  for (int p = 0; p < 3; p++) {
-    if (!((cpl >> p) & 1u)) continue;
-    const int A = pair_A(p), B = pair_B(p);
-    V3<T> plA = ld3<T, LW>(lds, L_P + 6 * A), paA = ld3<T, LW>(lds, L_P + 6 * A + 3);
-    V3<T> plB = ld3<T, LW>(lds, L_P + 6 * B), paB = ld3<T, LW>(lds, L_P + 6 * B + 3);
-    V3<T> ylA = ld3<T, LW>(lds, L_A + 6 * A) + ld3<T, LW>(lds, L_BV + 6 * A) + alpha * plA;
-    V3<T> yaA = ld3<T, LW>(lds, L_A + 6 * A + 3) + ld3<T, LW>(lds, L_BV + 6 * A + 3) + alpha * paA;
-    V3<T> ylB = ld3<T, LW>(lds, L_A + 6 * B) + ld3<T, LW>(lds, L_BV + 6 * B) + alpha * plB;
-    V3<T> yaB = ld3<T, LW>(lds, L_A + 6 * B + 3) + ld3<T, LW>(lds, L_BV + 6 * B + 3) + alpha * paB;
-#pragma unroll 1
-    for (int s = 0; s < 2; s++) {
-      Contact<T> c = load_pair<T, LW>(lds, 2 * p + s);
-      if (!__any(c.active)) continue;
-      V3<T> jl = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
-      V3<T> ja = yaB - yaA;
-      V3<T> ql = (plB + cross(paB, c.rB)) - (plA + cross(paA, c.rA));
-      V3<T> qa = paB - paA;
-      Cone<T> o = cone_eval(P, c, jl, ja);
-      d1 -= dot(o.fl, ql) + dot(o.fa, qa);
-      T nl = dot(c.n, ql), na = dot(c.n, qa);
-      T gq = dot(o.gl, ql) + dot(o.ga, qa), wq = dot(o.wl, ql) + dot(o.wa, qa);
-      d2 += o.a1 * dot(ql, ql) + o.a2 * nl * nl + o.b1 * dot(qa, qa) + o.b2 * na * na + o.cg * gq * gq + o.cw * wq * wq;
-    }
-  }
+  __syncthreads();  // everyone is done reading the previous partials
+  lds[(L_RED + 6 + 2 * wid) * LW] = p1;
+  lds[(L_RED + 7 + 2 * wid) * LW] = p2;
+  __syncthreads();
+  d1 = g1 + alpha * g2; d2 = g2;
+#pragma unroll
+  for (int w = 0; w < 4; w++) { d1 += lds[(L_RED + 6 + 2 * w) * LW]; d2 += lds[(L_RED + 7 + 2 * w) * LW]; }
 }
 
 // ------------------------------------------------------------------ the sub-step
 // lds: this lane's column base (lds_block + lane); needs L_TOTAL slots of pitch LW
 template <typename T, int LW>
-TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, bool last, Lag<T>& lag) {
+TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, Lag<T>& lag) {
   const T im = rcp_(P.mass);
-  // ---- kinematics, tendons -> smooth wrench; Jacobian pieces parked in LDS
+  __syncthreads();  // every wave is done with the previous sub-step's columns
+  // ---- kinematics, tendons -> smooth wrench; Jacobian pieces parked in LDS (all four waves write the same values)
   {
     Rot<T> R[3];
 #pragma unroll
@@ -953,33 +997,37 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, bool last, Lag<T>& l
   const T scale = rcp_((T(3) * P.mass + T(2) * P.Ixx + P.Izz) * T(1.0 / 6.0) * T(18));
   bool conv = !any_contact;
   T cfrc_max = T(0);
-  unsigned cpl = 0u;
+  __syncthreads();  // the (redundantly written) columns of this sub-step are complete
+  const unsigned cpl = pair_coupling<T, LW>(lds);
   int n_it = 0, n_ls = 0;
 #pragma unroll 1
   for (int it = 0;; it++) {
-    T gn = newton_assemble<T, LW>(P, lds, cpl, cfrc_max);
+    T gn = newton_assemble<T, LW>(P, lds, wid, cpl, cfrc_max);
     conv = conv || !(scale * sqrt_(gn) >= P.tol);
     if (__all(conv) || it >= P.max_iter) break;
     n_it++;
-    newton_direction<T, LW>(lds, cpl, conv);
-    // Gauss part of the line derivative  phi_g'(alpha) = g1 + alpha g2 ;  d0 = G.P
-    T g1 = T(0), g2 = T(0), d0 = T(0);
-#pragma unroll 1
-    for (int b = 0; b < 3; b++) {
+    newton_direction<T, LW>(lds, wid, cpl, conv);
+    // Gauss part of the line derivative  phi_g'(alpha) = g1 + alpha g2 ;  d0 = G.P  (per-bar partials, then summed)
+    if (wid < 3) {
+      const int b = wid;
       V3<T> ez = ld3<T, LW>(lds, L_EZ + 3 * b);
       V3<T> pl = ld3<T, LW>(lds, L_P + 6 * b), pa = ld3<T, LW>(lds, L_P + 6 * b + 3);
       V3<T> dl = ld3<T, LW>(lds, L_A + 6 * b) - ld3<T, LW>(lds, L_A0 + 6 * b);
       V3<T> da = ld3<T, LW>(lds, L_A + 6 * b + 3) - ld3<T, LW>(lds, L_A0 + 6 * b + 3);
       V3<T> Ipa = inertia_mul(P, ez, pa);
-      g1 += P.mass * dot(pl, dl) + dot(Ipa, da);
-      g2 += P.mass * dot(pl, pl) + dot(Ipa, pa);
-      d0 += dot(pl, ld3<T, LW>(lds, L_G + 6 * b)) + dot(pa, ld3<T, LW>(lds, L_G + 6 * b + 3));
+      lds[(L_RED + 14 + 3 * b) * LW] = P.mass * dot(pl, dl) + dot(Ipa, da);
+      lds[(L_RED + 15 + 3 * b) * LW] = P.mass * dot(pl, pl) + dot(Ipa, pa);
+      lds[(L_RED + 16 + 3 * b) * LW] = dot(pl, ld3<T, LW>(lds, L_G + 6 * b)) + dot(pa, ld3<T, LW>(lds, L_G + 6 * b + 3));
     }
+    __syncthreads();
+    T g1 = T(0), g2 = T(0), d0 = T(0);
+#pragma unroll
+    for (int b = 0; b < 3; b++) { g1 += lds[(L_RED + 14 + 3 * b) * LW]; g2 += lds[(L_RED + 15 + 3 * b) * LW]; d0 += lds[(L_RED + 16 + 3 * b) * LW]; }
     // mujoco's second stopping rule: expected improvement of this step (|d0| / 2) below tolerance
     conv = conv || !(scale * T(0.5) * abs_(d0) >= P.tol);
+    conv = conv || !(d0 < T(0));  // no descent left at working precision
     // exact line search: safeguarded Newton on phi'
     T alpha = T(1), lo = T(0), hi = T(-1);
-    conv = conv || !(d0 < T(0));  // no descent left at working precision
     bool ls_done = conv;
     if (ls_done) alpha = T(0);
     T gtol = P.ls_tol * abs_(d0);
@@ -988,7 +1036,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, bool last, Lag<T>& l
       if (__all(ls_done)) break;
       T d1, d2;
       n_ls++;
-      newton_dphi<T, LW>(P, lds, cpl, alpha, g1, g2, d1, d2);
+      newton_dphi<T, LW>(P, lds, wid, cpl, alpha, g1, g2, d1, d2);
       bool ok = abs_(d1) <= gtol;
       if (!ls_done) {
         if (ok) ls_done = true;
@@ -1002,8 +1050,11 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, bool last, Lag<T>& l
         }
       }
     }
+    if (wid < 3) {
 #pragma unroll
-    for (int i = 0; i < 18; i++) lds[(L_A + i) * LW] += alpha * lds[(L_P + i) * LW];
+      for (int i = 0; i < 6; i++) lds[(L_A + 6 * wid + i) * LW] += alpha * lds[(L_P + 6 * wid + i) * LW];
+    }
+    __syncthreads();
   }
   if (last) lag.cfrc_absmax = cfrc_max;
   lag.n_it += n_it; lag.n_ls += n_ls; lag.n_unconv += conv ? 0 : 1;

@@ -364,9 +364,11 @@ TGR_DEV void store_reset_aux(const Params<T>& P, T* st, int* ist, int m, int e, 
 }
 
 // ------------------------------------------------------------------ step kernel
-template <typename T, int LW> __global__ __launch_bounds__(LW) void step_kernel(KArgs<T> k) {
+template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel(KArgs<T> k) {
   __shared__ T lds_all[L_TOTAL * LW];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 4 waves share the block's LW envs
+  if (lane >= LW) return;
   const int gid = blockIdx.x * LW + lane;
   const int n = k.n, m = k.m;
   const bool valid = gid < m;
@@ -416,17 +418,21 @@ template <typename T, int LW> __global__ __launch_bounds__(LW) void step_kernel(
   Lag<T> lag;
   lag.cfrc_absmax = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
 #pragma unroll 1
-  for (int s = 0; s < E.frame_skip; s++) substep<T, LW>(P, S, lds, s == E.frame_skip - 1, lag);
+  for (int s = 0; s < E.frame_skip; s++) substep<T, LW>(P, S, lds, wid, s == E.frame_skip - 1, lag);
 
-  if (lane == 0) {
+  const bool w0 = wid == 0;  // one wave owns every global store
+  if (lane == 0 && w0) {
     atomicAdd(&k.counters[3], (unsigned long long)lag.n_it);
     atomicAdd(&k.counters[4], (unsigned long long)lag.n_ls);
     atomicAdd(&k.counters[5], (unsigned long long)E.frame_skip);
   }
-  if (active && lag.n_unconv) atomicAdd(&k.counters[6], (unsigned long long)lag.n_unconv);
+  if (active && w0 && lag.n_unconv) atomicAdd(&k.counters[6], (unsigned long long)lag.n_unconv);
   V3<T> wb[3];
-  if (active) store_sim(k.st, m, e, S, lag, wb);
-  else {
+  if (active && w0) store_sim(k.st, m, e, S, lag, wb);
+  else if (active) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) { normalize_quat(S.q[b]); wb[b] = rot_applyT(quat_rot(S.q[b]), S.w[b]); }
+  } else {
 #pragma unroll
     for (int b = 0; b < 3; b++) wb[b] = mk(T(0), T(0), T(0));
   }
@@ -434,7 +440,7 @@ template <typename T, int LW> __global__ __launch_bounds__(LW) void step_kernel(
   T ob[48];
   if (!live) {
     // ---- donor lane: one more settle period done
-    if (active) {
+    if (active && w0) {
       const int stp = total - phase;  // 0-based index of the period just run
       if (stp == 0) { step_num = 0; }
       settle_period_done(P, E, lag, stp, ring, step_num, reset_psi);
@@ -463,7 +469,7 @@ template <typename T, int LW> __global__ __launch_bounds__(LW) void step_kernel(
     ep_ret += out.reward;
     done = out.terminated || truncated;
     make_obs(P, E, S, lag, wb, ob);
-    if (valid) {
+    if (valid && w0) {
       k.st[(F_XYLAG + 0) * m + e] = out.xy[0]; k.st[(F_XYLAG + 1) * m + e] = out.xy[1];
       k.st[F_PSILAG * m + e] = out.psi_straight;
       k.st[F_EPRET * m + e] = ep_ret;
@@ -495,13 +501,13 @@ template <typename T, int LW> __global__ __launch_bounds__(LW) void step_kernel(
   if (rows > 0) {
     __syncthreads();
     const int Dp = (D & 1) ? D : D + 1;  // odd row pitch: conflict-free
-    if (live) {
+    if (live && w0) {
 #pragma unroll
       for (int i = 0; i < 48; i++)
         if (i < D) lds_all[lane * Dp + i] = ob[i];
     }
     __syncthreads();
-    for (int f = lane; f < rows * D; f += LW) {
+    for (int f = wid * LW + lane; f < rows * D; f += 4 * LW) {
       int r = f / D, c = f - r * D;
       k.obs[(size_t)base * D + f] = lds_all[r * Dp + c];
     }
@@ -511,9 +517,11 @@ template <typename T, int LW> __global__ __launch_bounds__(LW) void step_kernel(
 // ------------------------------------------------------------------ settle kernel: reset_model() in one go
 // one lane per entry of list[]; used by tgr_reset() and for live envs that found no ready donor.
 // reproduces tensegrity_env.py:433-512 / tr_env.py:709-872.
-template <typename T, int LW> __global__ __launch_bounds__(LW) void settle_kernel(KArgs<T> k) {
+template <typename T, int LW> __global__ __launch_bounds__(256) void settle_kernel(KArgs<T> k) {
   __shared__ T lds_all[L_TOTAL * LW];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (lane >= LW) return;
   const int count = *k.list_count;
   if (blockIdx.x * LW >= count) return;
   const int li = blockIdx.x * LW + lane;
@@ -537,10 +545,10 @@ template <typename T, int LW> __global__ __launch_bounds__(LW) void settle_kerne
 #pragma unroll 1
   for (int st = 0; st < total; st++) {
 #pragma unroll 1
-    for (int s = 0; s < E.frame_skip; s++) substep<T, LW>(P, S, lds, s == E.frame_skip - 1, lag);
+    for (int s = 0; s < E.frame_skip; s++) substep<T, LW>(P, S, lds, wid, s == E.frame_skip - 1, lag);
     if (valid) settle_period_done(P, E, lag, st, ring, step_num, reset_psi);
   }
-  if (!valid) return;
+  if (!valid || wid != 0) return;
   V3<T> wb[3];
   store_sim(k.st, m, e, S, lag, wb);
   store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
@@ -899,7 +907,7 @@ template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, 
   k.obs_reset = (T*)obs;
   constexpr int LW = LaneW<T>::value;
   int blocks = (cnt + LW - 1) / LW;
-  hipLaunchKernelGGL((settle_kernel<T, LW>), dim3(blocks), dim3(LW), 0, s, k);
+  hipLaunchKernelGGL((settle_kernel<T, LW>), dim3(blocks), dim3(256), 0, s, k);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->list_count, 0, sizeof(int), s));
   return TGR_OK;
@@ -923,14 +931,14 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
   k.obs_reset = obs;
   constexpr int LW = LaneW<T>::value;
   int blocks = (h->m + LW - 1) / LW;
-  hipLaunchKernelGGL((step_kernel<T, LW>), dim3(blocks), dim3(LW), 0, s, k);
+  hipLaunchKernelGGL((step_kernel<T, LW>), dim3(blocks), dim3(256), 0, s, k);
   HIP_TRY(h, hipGetLastError());
   if (h->cfg.auto_reset) {
     hipLaunchKernelGGL((match_kernel<T>), dim3(1), dim3(1024), 0, s, k);
     HIP_TRY(h, hipGetLastError());
     // envs that found no ready donor are settled here and now (grid sized for the worst case, exits on an empty list)
     int sblocks = (h->n + LW - 1) / LW;
-    hipLaunchKernelGGL((settle_kernel<T, LW>), dim3(sblocks), dim3(LW), 0, s, k);
+    hipLaunchKernelGGL((settle_kernel<T, LW>), dim3(sblocks), dim3(256), 0, s, k);
     HIP_TRY(h, hipGetLastError());
   }
   return TGR_OK;
