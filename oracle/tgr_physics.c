@@ -606,6 +606,8 @@ static void line_eval(const tgo_model* m, tgo_data* d, const double* qacc, const
 }
 
 double tgo_debug_ls_tol = 1e-13; /* test hook: relative line-search tolerance */
+int tgo_debug_start = 0; /* test hook: 0 = better of warm/smooth (mujoco), 1 = always warm, 2 = always smooth */
+double tgo_debug_tol = 1e-12; /* test hook: gradient tolerance (scaled) */
 int tgo_debug_trace = 0;
 #include <stdio.h>
 static void newton_solve(const tgo_model* m, tgo_data* d) {
@@ -621,7 +623,10 @@ static void newton_solve(const tgo_model* m, tgo_data* d) {
   {
     double cw = total_cost(m, d, d->qacc_warmstart, NULL, NULL);
     double cs = total_cost(m, d, d->qacc_smooth, NULL, NULL);
-    memcpy(qacc, cw < cs ? d->qacc_warmstart : d->qacc_smooth, sizeof(qacc));
+    int usew = cw < cs;
+    if (tgo_debug_start == 1) usew = 1;
+    if (tgo_debug_start == 2) usew = 0;
+    memcpy(qacc, usew ? d->qacc_warmstart : d->qacc_smooth, sizeof(qacc));
   }
   /* scale as mujoco: 1/(meaninertia * nv); we iterate far below its 1e-8 tolerance so the
      restatement sits at the (unique) optimum the reference solver approaches */
@@ -633,7 +638,7 @@ static void newton_solve(const tgo_model* m, tgo_data* d) {
     double gn = 0;
     for (int k = 0; k < TGO_NV; k++) gn += grad[k] * grad[k];
     gn = sqrt(gn);
-    if (scale * gn < 1e-12) break;
+    if (scale * gn < tgo_debug_tol) break;
     if (cholesky(H, TGO_NV) != 0) { d->flags |= TGO_FLAG_NOCONV; break; }
     for (int k = 0; k < TGO_NV; k++) p[k] = -grad[k];
     chol_solve(H, TGO_NV, p);

@@ -23,6 +23,12 @@ namespace tgr {
 
 #define TGR_DEV __device__ __forceinline__
 
+#ifdef TGR_STAMPS
+#define TGR_STAMP(i) do { long long _t = clock64(); lag.stamp[i] += _t - lag.t_last; lag.t_last = _t; } while (0)
+#else
+#define TGR_STAMP(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ scalar helpers
 template <typename T> TGR_DEV T rcp_(T x);
 template <> TGR_DEV float rcp_<float>(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -116,6 +122,9 @@ template <typename T> struct Lag {
   int overflow;
   int n_it, n_ls;  // solver work of this control period (wave-uniform)
   int n_unconv;    // sub-steps this lane left the solver at the iteration cap
+#ifdef TGR_STAMPS
+  long long stamp[8]; long long t_last;  // diagnostic build only: cycles per phase
+#endif
 };
 
 template <typename T> struct Rot { V3<T> ex, ey, ez; };  // columns of the rotation matrix
@@ -818,54 +827,99 @@ template <typename T, int LW> TGR_DEV void newton_direction(T* lds, int wid, uns
   __syncthreads();
 }
 
-// derivative of the cost along A + alpha P:  phi'(alpha), phi''(alpha); waves 0-2 take their bar's caps, wave 3 the pairs
+// ---- line search.  Along a + alpha p every contact row is jar0 + alpha q, so the cone cost of a slot depends on alpha only
+// through ten scalars (norms and projections of jar0 and q).  Each wave reduces its slots to those scalars once per Newton
+// iteration (waves 0-2: the two caps of their bar, wave 3: the pair slots) and a line-search evaluation is ~50 instructions
+// per slot plus one cross-wave sum.
+template <typename T> struct LSlot { T A0, A1, A2, B0, B1, B2, jn0, qn, jo0, qo, Dn; bool act; };
+
+template <typename T> TGR_DEV LSlot<T> ls_make(const Contact<T>& c, V3<T> jl, V3<T> ja, V3<T> ql, V3<T> qa) {
+  LSlot<T> s;
+  s.A0 = dot(jl, jl); s.A1 = dot(jl, ql); s.A2 = dot(ql, ql);
+  s.B0 = dot(ja, ja); s.B1 = dot(ja, qa); s.B2 = dot(qa, qa);
+  s.jn0 = dot(c.n, jl); s.qn = dot(c.n, ql); s.jo0 = dot(c.n, ja); s.qo = dot(c.n, qa);
+  s.Dn = c.Dn; s.act = c.active;
+  return s;
+}
+// d(cost)/d(alpha) and d2(cost)/d(alpha)2 of one slot
+template <typename T> TGR_DEV void ls_slot(const Params<T>& P, const LSlot<T>& s, T alpha, T& d1, T& d2) {
+  T mu = P.f0 * rsqrt_(P.impratio);
+  T Dtf = s.Dn * P.impratio * rcp_(P.f0 * P.f0);  // D_j / f_j^2 of the friction rows (same for all five)
+  T jn = s.jn0 + alpha * s.qn, jo = s.jo0 + alpha * s.qo;
+  T jl2 = s.A0 + alpha * (T(2) * s.A1 + alpha * s.A2), ja2 = s.B0 + alpha * (T(2) * s.B1 + alpha * s.B2);
+  T jlq = s.A1 + alpha * s.A2, jaq = s.B1 + alpha * s.B2;
+  T tt = P.f1sq * (jl2 - jn * jn) + P.f3sq * jo * jo + P.f4sq * (ja2 - jo * jo);
+  T Tn = sqrt_(max_(tt, T(0)));
+  T wq = P.f1sq * (jlq - jn * s.qn) + P.f3sq * jo * s.qo + P.f4sq * (jaq - jo * s.qo);
+  T qtt = P.f1sq * (s.A2 - s.qn * s.qn) + P.f3sq * s.qo * s.qo + P.f4sq * (s.B2 - s.qo * s.qo);
+  T N = mu * jn;
+  bool top = (N >= mu * Tn) || !s.act;
+  bool bottom = !top && (mu * N + Tn <= T(0));
+  // bottom: quadratic
+  T b1 = s.Dn * jn * s.qn + Dtf * wq;
+  T b2 = s.Dn * s.qn * s.qn + Dtf * qtt;
+  // middle: 1/2 Dm (N - mu T)^2
+  T rT = rcp_(max_(Tn, T(1e-30)));
+  T Dm = s.Dn * rcp_(mu * mu * (T(1) + mu * mu));
+  T NT = N - mu * Tn;
+  T gq = mu * (s.qn - wq * rT);
+  T kap = -Dm * mu * NT * rT;
+  T m1 = Dm * NT * gq;
+  T m2 = Dm * gq * gq + kap * (qtt - wq * wq * rT * rT);
+  d1 = top ? T(0) : (bottom ? b1 : m1);
+  d2 = top ? T(0) : (bottom ? b2 : m2);
+}
+
 template <typename T, int LW>
-TGR_DEV void newton_dphi(const Params<T>& P, T* lds, int wid, unsigned cpl, T alpha, T g1, T g2, T& d1, T& d2) {
-  T p1 = T(0), p2 = T(0);
+TGR_DEV void ls_setup(const Params<T>& P, const T* lds, int wid, unsigned cpl, LSlot<T>* ls) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) { ls[k].act = false; ls[k].A0 = ls[k].A1 = ls[k].A2 = ls[k].B0 = ls[k].B1 = ls[k].B2 = T(0); ls[k].jn0 = ls[k].qn = ls[k].jo0 = ls[k].qo = T(0); ls[k].Dn = T(0); }
   if (wid < 3) {
     const int b = wid;
     V3<T> pl = ld3<T, LW>(lds, L_P + 6 * b), pa = ld3<T, LW>(lds, L_P + 6 * b + 3);
-    V3<T> yl = ld3<T, LW>(lds, L_A + 6 * b) + ld3<T, LW>(lds, L_BV + 6 * b) + alpha * pl;
-    V3<T> ya = ld3<T, LW>(lds, L_A + 6 * b + 3) + ld3<T, LW>(lds, L_BV + 6 * b + 3) + alpha * pa;
-#pragma unroll 1
+    V3<T> yl = ld3<T, LW>(lds, L_A + 6 * b) + ld3<T, LW>(lds, L_BV + 6 * b);
+    V3<T> ya = ld3<T, LW>(lds, L_A + 6 * b + 3) + ld3<T, LW>(lds, L_BV + 6 * b + 3);
+#pragma unroll
     for (int e = 0; e < 2; e++) {
       Contact<T> c = load_floor<T, LW>(lds, 2 * b + e);
-      if (__any(c.active)) {
-        V3<T> jl = yl + cross(ya, c.rB);
-        jl.z += c.c0;
-        V3<T> ql = pl + cross(pa, c.rB);
-        Cone<T> o = cone_eval(P, c, jl, ya);
-        p1 -= dot(o.fl, ql) + dot(o.fa, pa);
-        T nl = ql.z, na = pa.z;
-        T gq = dot(o.gl, ql) + dot(o.ga, pa), wq = dot(o.wl, ql) + dot(o.wa, pa);
-        p2 += o.a1 * dot(ql, ql) + o.a2 * nl * nl + o.b1 * dot(pa, pa) + o.b2 * na * na + o.cg * gq * gq + o.cw * wq * wq;
-      }
+      V3<T> jl = yl + cross(ya, c.rB);
+      jl.z += c.c0;
+      V3<T> ql = pl + cross(pa, c.rB);
+      ls[e] = ls_make(c, jl, ya, ql, pa);
     }
   } else {
-#pragma unroll 1
+#pragma unroll
     for (int p = 0; p < 3; p++) {
       if (!((cpl >> p) & 1u)) continue;
       const int A = pair_A(p), B = pair_B(p);
       V3<T> plA = ld3<T, LW>(lds, L_P + 6 * A), paA = ld3<T, LW>(lds, L_P + 6 * A + 3);
       V3<T> plB = ld3<T, LW>(lds, L_P + 6 * B), paB = ld3<T, LW>(lds, L_P + 6 * B + 3);
-      V3<T> ylA = ld3<T, LW>(lds, L_A + 6 * A) + ld3<T, LW>(lds, L_BV + 6 * A) + alpha * plA;
-      V3<T> yaA = ld3<T, LW>(lds, L_A + 6 * A + 3) + ld3<T, LW>(lds, L_BV + 6 * A + 3) + alpha * paA;
-      V3<T> ylB = ld3<T, LW>(lds, L_A + 6 * B) + ld3<T, LW>(lds, L_BV + 6 * B) + alpha * plB;
-      V3<T> yaB = ld3<T, LW>(lds, L_A + 6 * B + 3) + ld3<T, LW>(lds, L_BV + 6 * B + 3) + alpha * paB;
-#pragma unroll 1
+      V3<T> ylA = ld3<T, LW>(lds, L_A + 6 * A) + ld3<T, LW>(lds, L_BV + 6 * A);
+      V3<T> yaA = ld3<T, LW>(lds, L_A + 6 * A + 3) + ld3<T, LW>(lds, L_BV + 6 * A + 3);
+      V3<T> ylB = ld3<T, LW>(lds, L_A + 6 * B) + ld3<T, LW>(lds, L_BV + 6 * B);
+      V3<T> yaB = ld3<T, LW>(lds, L_A + 6 * B + 3) + ld3<T, LW>(lds, L_BV + 6 * B + 3);
+#pragma unroll
       for (int s = 0; s < 2; s++) {
         Contact<T> c = load_pair<T, LW>(lds, 2 * p + s);
-        if (!__any(c.active)) continue;
         V3<T> jl = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
         V3<T> ja = yaB - yaA;
         V3<T> ql = (plB + cross(paB, c.rB)) - (plA + cross(paA, c.rA));
         V3<T> qa = paB - paA;
-        Cone<T> o = cone_eval(P, c, jl, ja);
-        p1 -= dot(o.fl, ql) + dot(o.fa, qa);
-        T nl = dot(c.n, ql), na = dot(c.n, qa);
-        T gq = dot(o.gl, ql) + dot(o.ga, qa), wq = dot(o.wl, ql) + dot(o.wa, qa);
-        p2 += o.a1 * dot(ql, ql) + o.a2 * nl * nl + o.b1 * dot(qa, qa) + o.b2 * na * na + o.cg * gq * gq + o.cw * wq * wq;
+        ls[2 * p + s] = ls_make(c, jl, ja, ql, qa);
       }
+    }
+  }
+}
+
+template <typename T, int LW>
+TGR_DEV void newton_dphi(const Params<T>& P, T* lds, int wid, const LSlot<T>* ls, T alpha, T g1, T g2, T& d1, T& d2) {
+  T p1 = T(0), p2 = T(0);
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    if (__any(ls[k].act)) {
+      T a, b;
+      ls_slot(P, ls[k], alpha, a, b);
+      p1 += a; p2 += b;
     }
   }
   __syncthreads();  // everyone is done reading the previous partials
@@ -882,7 +936,9 @@ TGR_DEV void newton_dphi(const Params<T>& P, T* lds, int wid, unsigned cpl, T al
 template <typename T, int LW>
 TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, Lag<T>& lag) {
   const T im = rcp_(P.mass);
+  TGR_STAMP(7);
   __syncthreads();  // every wave is done with the previous sub-step's columns
+  TGR_STAMP(6);
   // ---- kinematics, tendons -> smooth wrench; Jacobian pieces parked in LDS (all four waves write the same values)
   {
     Rot<T> R[3];
@@ -997,16 +1053,20 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
   const T scale = rcp_((T(3) * P.mass + T(2) * P.Ixx + P.Izz) * T(1.0 / 6.0) * T(18));
   bool conv = !any_contact;
   T cfrc_max = T(0);
+  TGR_STAMP(0);
   __syncthreads();  // the (redundantly written) columns of this sub-step are complete
   const unsigned cpl = pair_coupling<T, LW>(lds);
   int n_it = 0, n_ls = 0;
 #pragma unroll 1
   for (int it = 0;; it++) {
+    TGR_STAMP(6);
     T gn = newton_assemble<T, LW>(P, lds, wid, cpl, cfrc_max);
+    TGR_STAMP(1);
     conv = conv || !(scale * sqrt_(gn) >= P.tol);
     if (__all(conv) || it >= P.max_iter) break;
     n_it++;
     newton_direction<T, LW>(lds, wid, cpl, conv);
+    TGR_STAMP(2);
     // Gauss part of the line derivative  phi_g'(alpha) = g1 + alpha g2 ;  d0 = G.P  (per-bar partials, then summed)
     if (wid < 3) {
       const int b = wid;
@@ -1031,12 +1091,15 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
     bool ls_done = conv;
     if (ls_done) alpha = T(0);
     T gtol = P.ls_tol * abs_(d0);
+    LSlot<T> lsl[6];
+    ls_setup<T, LW>(P, lds, wid, cpl, lsl);
+    TGR_STAMP(3);
 #pragma unroll 1
     for (int ls = 0; ls < P.ls_iter; ls++) {
       if (__all(ls_done)) break;
       T d1, d2;
       n_ls++;
-      newton_dphi<T, LW>(P, lds, wid, cpl, alpha, g1, g2, d1, d2);
+      newton_dphi<T, LW>(P, lds, wid, lsl, alpha, g1, g2, d1, d2);
       bool ok = abs_(d1) <= gtol;
       if (!ls_done) {
         if (ok) ls_done = true;
@@ -1050,12 +1113,14 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
         }
       }
     }
+    TGR_STAMP(4);
     if (wid < 3) {
 #pragma unroll
       for (int i = 0; i < 6; i++) lds[(L_A + 6 * wid + i) * LW] += alpha * lds[(L_P + 6 * wid + i) * LW];
     }
     __syncthreads();
   }
+  TGR_STAMP(6);
   if (last) lag.cfrc_absmax = cfrc_max;
   lag.n_it += n_it; lag.n_ls += n_ls; lag.n_unconv += conv ? 0 : 1;
 #pragma unroll

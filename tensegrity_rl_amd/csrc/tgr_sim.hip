@@ -417,9 +417,17 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
 
   Lag<T> lag;
   lag.cfrc_absmax = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
+#ifdef TGR_STAMPS
+  for (int i = 0; i < 8; i++) lag.stamp[i] = 0;
+  lag.t_last = clock64();
+#endif
 #pragma unroll 1
   for (int s = 0; s < E.frame_skip; s++) substep<T, LW>(P, S, lds, wid, s == E.frame_skip - 1, lag);
 
+#ifdef TGR_STAMPS
+  { long long _t = clock64(); lag.stamp[5] += _t - lag.t_last; lag.t_last = _t; }
+  if (lane == 0 && blockIdx.x < 64) for (int i = 0; i < 8; i++) atomicAdd(&k.counters[8 + wid * 8 + i], (unsigned long long)lag.stamp[i]);
+#endif
   const bool w0 = wid == 0;  // one wave owns every global store
   if (lane == 0 && w0) {
     atomicAdd(&k.counters[3], (unsigned long long)lag.n_it);
@@ -846,8 +854,8 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   HIP_TRY(h, hipMalloc((void**)&h->rlist, sizeof(int) * m));
   HIP_TRY(h, hipMalloc((void**)&h->doneflag, m));
   HIP_TRY(h, hipMemset(h->doneflag, 0, m));
-  HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 8));
-  HIP_TRY(h, hipMemset(h->counters, 0, sizeof(unsigned long long) * 8));
+  HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 64));
+  HIP_TRY(h, hipMemset(h->counters, 0, sizeof(unsigned long long) * 64));
   return TGR_OK;
 }
 
@@ -882,6 +890,10 @@ extern "C" int tgr_set_seed(tgr_handle* h, uint64_t seed) {
 extern "C" int tgr_stats(tgr_handle* h, uint64_t out[8]) {
   if (!h || !out) return TGR_ERR_INVALID;
   unsigned long long tmp[8];
+#ifdef TGR_STAMPS
+  { unsigned long long t2[64]; (void)hipDeviceSynchronize(); (void)hipMemcpy(t2, h->counters, sizeof(t2), hipMemcpyDeviceToHost);
+    for (int w = 0; w < 4; w++) { printf("wave %d cycles:", w); for (int i = 0; i < 8; i++) printf(" %12llu", t2[8 + w * 8 + i]); printf("\n"); } }
+#endif
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipDeviceSynchronize());
   HIP_TRY(h, hipMemcpy(tmp, h->counters, sizeof(tmp), hipMemcpyDeviceToHost));
