@@ -30,8 +30,12 @@ def cpu_baseline(seconds, envs):
     import numpy as np
     from oracle import oracle as O
     O.build()
-    cores = os.cpu_count() or 1
-    threads = min(cores, envs)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 16))  # the GPU box grants a 16-core share per GPU
+    envs = 4 * threads
     ob = O.OracleBatch(O.make_cfg("tensegrity_env", "straight"), envs, seed=1234, threads=threads)
     ob.reset()
     rng = np.random.default_rng(0)
