@@ -95,8 +95,8 @@ enum : int {
   L_FC = L_P + 18,      // constraint wrench per bar (J^T f) == cfrc_ext
   L_EZ = L_FC + 18,     // bar axes (3 x 3)
   L_X = L_EZ + 9,       // bar COM positions (3 x 3)
-  L_RED = L_X + 9,      // cross-wave partial sums (24)
-  L_TOTAL = L_RED + 24  // 519
+  L_RED = L_X + 9,      // cross-wave partial sums (32)
+  L_TOTAL = L_RED + 32  // 527
 };
 constexpr __host__ __device__ int H_D(int b) { return L_H + 21 * b; }
 constexpr int H_O10 = L_H + 63, H_O20 = L_H + 99, H_O21 = L_H + 135;
@@ -870,10 +870,32 @@ template <typename T> TGR_DEV void ls_slot(const Params<T>& P, const LSlot<T>& s
   d2 = top ? T(0) : (bottom ? b2 : m2);
 }
 
+// slot ownership in the line search: wave w < 3 takes the two caps of bar w and the first slot of pair w,
+// wave 3 takes the three second pair slots (rarely active)
+template <typename T, int LW>
+TGR_DEV LSlot<T> ls_pair_slot(const Params<T>& P, const T* lds, int p, int s) {
+  const int A = pair_A(p), B = pair_B(p);
+  Contact<T> c = load_pair<T, LW>(lds, 2 * p + s);
+  LSlot<T> r;
+  r.act = false; r.A0 = r.A1 = r.A2 = r.B0 = r.B1 = r.B2 = T(0); r.jn0 = r.qn = r.jo0 = r.qo = T(0); r.Dn = T(0);
+  if (!__any(c.active)) return r;
+  V3<T> plA = ld3<T, LW>(lds, L_P + 6 * A), paA = ld3<T, LW>(lds, L_P + 6 * A + 3);
+  V3<T> plB = ld3<T, LW>(lds, L_P + 6 * B), paB = ld3<T, LW>(lds, L_P + 6 * B + 3);
+  V3<T> ylA = ld3<T, LW>(lds, L_A + 6 * A) + ld3<T, LW>(lds, L_BV + 6 * A);
+  V3<T> yaA = ld3<T, LW>(lds, L_A + 6 * A + 3) + ld3<T, LW>(lds, L_BV + 6 * A + 3);
+  V3<T> ylB = ld3<T, LW>(lds, L_A + 6 * B) + ld3<T, LW>(lds, L_BV + 6 * B);
+  V3<T> yaB = ld3<T, LW>(lds, L_A + 6 * B + 3) + ld3<T, LW>(lds, L_BV + 6 * B + 3);
+  V3<T> jl = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
+  V3<T> ja = yaB - yaA;
+  V3<T> ql = (plB + cross(paB, c.rB)) - (plA + cross(paA, c.rA));
+  V3<T> qa = paB - paA;
+  return ls_make(c, jl, ja, ql, qa);
+}
+
 template <typename T, int LW>
 TGR_DEV void ls_setup(const Params<T>& P, const T* lds, int wid, unsigned cpl, LSlot<T>* ls) {
 #pragma unroll
-  for (int k = 0; k < 6; k++) { ls[k].act = false; ls[k].A0 = ls[k].A1 = ls[k].A2 = ls[k].B0 = ls[k].B1 = ls[k].B2 = T(0); ls[k].jn0 = ls[k].qn = ls[k].jo0 = ls[k].qo = T(0); ls[k].Dn = T(0); }
+  for (int k = 0; k < 3; k++) { ls[k].act = false; ls[k].A0 = ls[k].A1 = ls[k].A2 = ls[k].B0 = ls[k].B1 = ls[k].B2 = T(0); ls[k].jn0 = ls[k].qn = ls[k].jo0 = ls[k].qo = T(0); ls[k].Dn = T(0); }
   if (wid < 3) {
     const int b = wid;
     V3<T> pl = ld3<T, LW>(lds, L_P + 6 * b), pa = ld3<T, LW>(lds, L_P + 6 * b + 3);
@@ -887,48 +909,33 @@ TGR_DEV void ls_setup(const Params<T>& P, const T* lds, int wid, unsigned cpl, L
       V3<T> ql = pl + cross(pa, c.rB);
       ls[e] = ls_make(c, jl, ya, ql, pa);
     }
+    if ((cpl >> b) & 1u) ls[2] = ls_pair_slot<T, LW>(P, lds, b, 0);
   } else {
 #pragma unroll
-    for (int p = 0; p < 3; p++) {
-      if (!((cpl >> p) & 1u)) continue;
-      const int A = pair_A(p), B = pair_B(p);
-      V3<T> plA = ld3<T, LW>(lds, L_P + 6 * A), paA = ld3<T, LW>(lds, L_P + 6 * A + 3);
-      V3<T> plB = ld3<T, LW>(lds, L_P + 6 * B), paB = ld3<T, LW>(lds, L_P + 6 * B + 3);
-      V3<T> ylA = ld3<T, LW>(lds, L_A + 6 * A) + ld3<T, LW>(lds, L_BV + 6 * A);
-      V3<T> yaA = ld3<T, LW>(lds, L_A + 6 * A + 3) + ld3<T, LW>(lds, L_BV + 6 * A + 3);
-      V3<T> ylB = ld3<T, LW>(lds, L_A + 6 * B) + ld3<T, LW>(lds, L_BV + 6 * B);
-      V3<T> yaB = ld3<T, LW>(lds, L_A + 6 * B + 3) + ld3<T, LW>(lds, L_BV + 6 * B + 3);
-#pragma unroll
-      for (int s = 0; s < 2; s++) {
-        Contact<T> c = load_pair<T, LW>(lds, 2 * p + s);
-        V3<T> jl = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
-        V3<T> ja = yaB - yaA;
-        V3<T> ql = (plB + cross(paB, c.rB)) - (plA + cross(paA, c.rA));
-        V3<T> qa = paB - paA;
-        ls[2 * p + s] = ls_make(c, jl, ja, ql, qa);
-      }
-    }
+    for (int p = 0; p < 3; p++)
+      if ((cpl >> p) & 1u) ls[p] = ls_pair_slot<T, LW>(P, lds, p, 1);
   }
 }
 
+// one barrier per evaluation: partial sums go to alternating halves of the reduction area
 template <typename T, int LW>
-TGR_DEV void newton_dphi(const Params<T>& P, T* lds, int wid, const LSlot<T>* ls, T alpha, T g1, T g2, T& d1, T& d2) {
+TGR_DEV void newton_dphi(const Params<T>& P, T* lds, int wid, const LSlot<T>* ls, int parity, T alpha, T g1, T g2, T& d1, T& d2) {
   T p1 = T(0), p2 = T(0);
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
+  for (int k = 0; k < 3; k++) {
     if (__any(ls[k].act)) {
       T a, b;
       ls_slot(P, ls[k], alpha, a, b);
       p1 += a; p2 += b;
     }
   }
-  __syncthreads();  // everyone is done reading the previous partials
-  lds[(L_RED + 6 + 2 * wid) * LW] = p1;
-  lds[(L_RED + 7 + 2 * wid) * LW] = p2;
+  const int base = L_RED + 6 + 8 * parity;
+  lds[(base + 2 * wid) * LW] = p1;
+  lds[(base + 1 + 2 * wid) * LW] = p2;
   __syncthreads();
   d1 = g1 + alpha * g2; d2 = g2;
 #pragma unroll
-  for (int w = 0; w < 4; w++) { d1 += lds[(L_RED + 6 + 2 * w) * LW]; d2 += lds[(L_RED + 7 + 2 * w) * LW]; }
+  for (int w = 0; w < 4; w++) { d1 += lds[(base + 2 * w) * LW]; d2 += lds[(base + 1 + 2 * w) * LW]; }
 }
 
 // ------------------------------------------------------------------ the sub-step
@@ -1075,14 +1082,14 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
       V3<T> dl = ld3<T, LW>(lds, L_A + 6 * b) - ld3<T, LW>(lds, L_A0 + 6 * b);
       V3<T> da = ld3<T, LW>(lds, L_A + 6 * b + 3) - ld3<T, LW>(lds, L_A0 + 6 * b + 3);
       V3<T> Ipa = inertia_mul(P, ez, pa);
-      lds[(L_RED + 14 + 3 * b) * LW] = P.mass * dot(pl, dl) + dot(Ipa, da);
-      lds[(L_RED + 15 + 3 * b) * LW] = P.mass * dot(pl, pl) + dot(Ipa, pa);
-      lds[(L_RED + 16 + 3 * b) * LW] = dot(pl, ld3<T, LW>(lds, L_G + 6 * b)) + dot(pa, ld3<T, LW>(lds, L_G + 6 * b + 3));
+      lds[(L_RED + 22 + 3 * b) * LW] = P.mass * dot(pl, dl) + dot(Ipa, da);
+      lds[(L_RED + 23 + 3 * b) * LW] = P.mass * dot(pl, pl) + dot(Ipa, pa);
+      lds[(L_RED + 24 + 3 * b) * LW] = dot(pl, ld3<T, LW>(lds, L_G + 6 * b)) + dot(pa, ld3<T, LW>(lds, L_G + 6 * b + 3));
     }
     __syncthreads();
     T g1 = T(0), g2 = T(0), d0 = T(0);
 #pragma unroll
-    for (int b = 0; b < 3; b++) { g1 += lds[(L_RED + 14 + 3 * b) * LW]; g2 += lds[(L_RED + 15 + 3 * b) * LW]; d0 += lds[(L_RED + 16 + 3 * b) * LW]; }
+    for (int b = 0; b < 3; b++) { g1 += lds[(L_RED + 22 + 3 * b) * LW]; g2 += lds[(L_RED + 23 + 3 * b) * LW]; d0 += lds[(L_RED + 24 + 3 * b) * LW]; }
     // mujoco's second stopping rule: expected improvement of this step (|d0| / 2) below tolerance
     conv = conv || !(scale * T(0.5) * abs_(d0) >= P.tol);
     conv = conv || !(d0 < T(0));  // no descent left at working precision
@@ -1091,7 +1098,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
     bool ls_done = conv;
     if (ls_done) alpha = T(0);
     T gtol = P.ls_tol * abs_(d0);
-    LSlot<T> lsl[6];
+    LSlot<T> lsl[3];
     ls_setup<T, LW>(P, lds, wid, cpl, lsl);
     TGR_STAMP(3);
 #pragma unroll 1
@@ -1099,7 +1106,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
       if (__all(ls_done)) break;
       T d1, d2;
       n_ls++;
-      newton_dphi<T, LW>(P, lds, wid, lsl, alpha, g1, g2, d1, d2);
+      newton_dphi<T, LW>(P, lds, wid, lsl, n_ls & 1, alpha, g1, g2, d1, d2);
       bool ok = abs_(d1) <= gtol;
       if (!ls_done) {
         if (ok) ls_done = true;
