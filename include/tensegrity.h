@@ -93,6 +93,9 @@ typedef struct tgr_config {
   uint64_t first_env_id;
   double solver_tolerance; /* <=0: default for the precision */
   int32_t solver_iterations;
+  /* --- tr_env command modes (tr_env.py:164-172) */
+  double waypt_range[2], waypt_angle_range[2];
+  double ditch_reward_max, ditch_reward_stdev, waypt_reward_amplitude, waypt_reward_stdev, yaw_reward_weight;
 } tgr_config;
 
 typedef struct tgr_handle tgr_handle;

@@ -229,13 +229,20 @@ class OracleBatch:
         """qpos[N,21], qvel[N,18], ctrl[N,6], warm[N,18], aux dict of arrays (what the HIP path keeps per env)."""
         n = self.n
         qpos = np.zeros((n, NQ)); qvel = np.zeros((n, NV)); ctrl = np.zeros((n, NU)); warm = np.zeros((n, NV))
-        aux = {k: np.zeros(n) for k in ("xy_lag_x", "xy_lag_y", "psi_lag", "reset_psi", "step_num", "elapsed", "ep_return")}
+        aux = {k: np.zeros(n) for k in ("xy_lag_x", "xy_lag_y", "psi_lag", "reset_psi", "step_num", "elapsed", "ep_return",
+                                        "waypt_x", "waypt_y", "ori_x", "ori_y", "vcmd_x", "vcmd_y", "vcmd_w")}
         for i in range(n):
             e = self.env(i)
             qpos[i] = arr(e.data.qpos); qvel[i] = arr(e.data.qvel); ctrl[i] = arr(e.data.ctrl)
             warm[i] = arr(e.data.qacc_warmstart)
             xp = arr(e.data.xpos)
             aux["xy_lag_x"][i] = xp[:, 0].mean(); aux["xy_lag_y"][i] = xp[:, 1].mean()
+            cap = arr(e.data.cap_xpos)
+            l, r = cap[0::2].mean(axis=0), cap[1::2].mean(axis=0)
+            aux["psi_lag"][i] = np.arctan2(-(l[0] - r[0]), l[1] - r[1])
+            aux["waypt_x"][i], aux["waypt_y"][i] = e.waypt[0], e.waypt[1]
+            aux["ori_x"][i], aux["ori_y"][i] = e.oripoint[0], e.oripoint[1]
+            aux["vcmd_x"][i], aux["vcmd_y"][i], aux["vcmd_w"][i] = e.lin_vel_cmd[0], e.lin_vel_cmd[1], e.ang_vel_cmd
             aux["reset_psi"][i] = e.reset_psi; aux["step_num"][i] = e.step_num; aux["elapsed"][i] = e.elapsed
             aux["ep_return"][i] = e.ep_return
         return qpos, qvel, ctrl, warm, aux

@@ -68,6 +68,7 @@ template <typename T> struct Params {
   T f0, f1sq, f3sq, f4sq, impratio;       // friction (slide, slide^2, torsion^2, roll^2)
   T invweight;                            // 1/m : body_invweight0 translational
   T tol, ls_tol;
+  T cf_lo, cf_hi;                         // contact_force_range of the env (for contact_cost)
   int max_iter, ls_iter, skip_clamped;
 };
 
@@ -119,6 +120,7 @@ template <typename T> struct Lag {
   T q[3][4];
   T tenL[9];
   T cfrc_absmax;
+  T cfrc_clip_sq;  // sum over cfrc_ext of clip(., contact_force_range)^2
   int overflow;
   int n_it, n_ls;  // solver work of this control period (wave-uniform)
   int n_unconv;    // sub-steps this lane left the solver at the iteration cap
@@ -1128,7 +1130,13 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
     __syncthreads();
   }
   TGR_STAMP(6);
-  if (last) lag.cfrc_absmax = cfrc_max;
+  if (last) {
+    lag.cfrc_absmax = cfrc_max;
+    T sq = T(0);
+#pragma unroll
+    for (int i = 0; i < 18; i++) { T v = clamp_(lds[(L_FC + i) * LW], P.cf_lo, P.cf_hi); sq += v * v; }
+    lag.cfrc_clip_sq = sq;
+  }
   lag.n_it += n_it; lag.n_ls += n_ls; lag.n_unconv += conv ? 0 : 1;
 #pragma unroll
   for (int b = 0; b < 3; b++) { S.al[b] = ld3<T, LW>(lds, L_A + 6 * b); S.aa[b] = ld3<T, LW>(lds, L_A + 6 * b + 3); }

@@ -36,6 +36,8 @@ template <typename T> struct EnvCfg {
   int env_kind, action, terminate_when_unhealthy, use_contact_forces, use_cap_velocity, is_test;
   int reward_delay_steps, frame_skip, max_episode_steps, obs_dim;
   T direction, ctrl_cost_weight, contact_cost_weight, healthy_reward, contact_lo, contact_hi, dt;
+  T ditch_max, ditch_std, waypt_amp, waypt_std, yaw_weight;
+  double waypt_range[2], waypt_angle_range[2];
   double min_heading, max_heading, ten_mean, ten_std, ten_max, ten_min;
   unsigned long long seed, first_env_id;
 };
@@ -161,9 +163,10 @@ template <typename T> TGR_DEV void left_right(const V3<T>* cap, V3<T>& l, V3<T>&
   r = third * (cap[1] + cap[3] + cap[5]);
 }
 
+template <typename T> struct ModeState;
 // observation of the env into o[0..D)
 template <typename T>
-TGR_DEV void make_obs(const Params<T>& P, const EnvCfg<T>& E, const Sim<T>& S, const Lag<T>& lag, const V3<T>* wb, T* o) {
+TGR_DEV void make_obs(const Params<T>& P, const EnvCfg<T>& E, const Sim<T>& S, const Lag<T>& lag, const V3<T>* wb, const ModeState<T>& ms, T* o) {
   if (E.env_kind == TGR_ENV_TENSEGRITY) {
     // tensegrity_env.py:412-430: scipy quaternion (x,y,z,w) of the r-cylinder geom frame = body * quat(0,0,0,1)
 #pragma unroll
@@ -201,9 +204,39 @@ TGR_DEV void make_obs(const Params<T>& P, const EnvCfg<T>& E, const Sim<T>& S, c
   }
 #pragma unroll
   for (int t = 0; t < 9; t++) o[k++] = lag.tenL[t];
+  if (E.action == TGR_ACT_TRACKING || E.action == TGR_ACT_AIMING) {  // tr_env.py:626-639
+    T tx = ms.waypt[0] - c.x, ty = ms.waypt[1] - c.y;
+    T in = rsqrt_(tx * tx + ty * ty);
+    o[k++] = tx; o[k++] = ty; o[k++] = atan2_(ty * in, tx * in);
+  } else if (E.action == TGR_ACT_VEL_TRACK) {
+    o[k++] = ms.vcmd[0]; o[k++] = ms.vcmd[1]; o[k++] = ms.vcmd[2];
+  }
 }
 
 template <typename T> struct StepOut { T reward; bool terminated; T info[10]; T psi_straight; T xy[2]; };
+
+// per-env members of tr_env's command modes (tr_env.py:229-240): way-point, origin, velocity command
+template <typename T> struct ModeState { T waypt[2], ori[2], vcmd[3]; T psi_before; int step_num; };
+template <typename T> TGR_DEV T exp_(T x) { return sizeof(T) == 4 ? T(expf(float(x))) : T(exp(double(x))); }
+template <typename T> TGR_DEV T sin_(T x) { return sizeof(T) == 4 ? T(sinf(float(x))) : T(sin(double(x))); }
+template <typename T> TGR_DEV T angle_normalize(T th) {  // tr_env.py:648-654 -> (-pi, pi]
+  while (th > T(PI)) th -= T(2 * PI);
+  while (th <= T(-PI)) th += T(2 * PI);
+  return th;
+}
+template <typename T> TGR_DEV T ditch_reward(const EnvCfg<T>& E, const ModeState<T>& ms, T x, T y) {  // tr_env.py:656-667
+  T pvx = ms.waypt[0] - ms.ori[0], pvy = ms.waypt[1] - ms.ori[1];
+  T dp = sqrt_(pvx * pvx + pvy * pvy);
+  T idp = rcp_(dp);
+  T pnx = pvx * idp, pny = pvy * idp;
+  T tvx = ms.waypt[0] - x, tvy = ms.waypt[1] - y;
+  T along = tvx * pnx + tvy * pny;
+  T bx = tvx - along * pnx, by = tvy - along * pny;
+  T bias2 = bx * bx + by * by;
+  T ditch = E.ditch_max * (T(1) - abs_(along) * idp) * exp_(-bias2 * rcp_(T(2) * E.ditch_std * E.ditch_std));
+  T way = E.waypt_amp * exp_(-(tvx * tvx + tvy * tvy) * rcp_(T(2) * E.waypt_std * E.waypt_std));
+  return ditch + way;
+}
 
 // ring buffer of headings (collections.deque that is never cleared: tensegrity_env.py:243)
 template <typename T> struct RingRef { T* ring; int n, e; int len, head; };
@@ -213,7 +246,7 @@ template <typename T> TGR_DEV T ring_pop(RingRef<T>& r) { T v = r.ring[r.head * 
 // reward / termination of one env step (tensegrity_env.py:291-410, tr_env.py:327-527; straight and turn)
 template <typename T>
 TGR_DEV StepOut<T> env_epilogue(const Params<T>& P, const EnvCfg<T>& E, const Sim<T>& S, const Lag<T>& lag, const V3<T>* wb,
-                                const T* action, T xy_bx, T xy_by, T reset_psi, RingRef<T>& ring) {
+                                const T* action, T xy_bx, T xy_by, T reset_psi, RingRef<T>& ring, const ModeState<T>& ms) {
   StepOut<T> o;
   T third = T(1.0 / 3.0);
   T xa = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x), ya = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
@@ -241,7 +274,7 @@ TGR_DEV StepOut<T> env_epilogue(const Params<T>& P, const EnvCfg<T>& E, const Si
     finite = finite && isfinite(S.v[b].x + S.v[b].y + S.v[b].z + wb[b].x + wb[b].y + wb[b].z);
   }
   bool healthy;
-  if (E.action == TGR_ACT_TURN) {
+  if (E.action == TGR_ACT_TURN || (E.env_kind == TGR_ENV_TR && E.action == TGR_ACT_AIMING)) {
     bool any = false;
 #pragma unroll
     for (int b = 0; b < 3; b++)
@@ -264,20 +297,47 @@ TGR_DEV StepOut<T> env_epilogue(const Params<T>& P, const EnvCfg<T>& E, const Si
       fwd = delta * E.direction;
       ctrl_cost = cc;
     }
-  } else {
+  } else if (E.action == TGR_ACT_STRAIGHT) {
     T dx = xa - xy_bx, dy = ya - xy_by;
     T pm = atan2_(dy, dx);
     T pd = abs_(pm - reset_psi);
     fwd = E.direction * (sqrt_(dx * dx + dy * dy) * cos_(pd) * idt);
     ctrl_cost = cc;
+  } else if (E.action == TGR_ACT_AIMING) {  // tr_env.py:425-446
+    T tdx = ms.waypt[0] - xy_bx, tdy = ms.waypt[1] - xy_by;
+    T in = rsqrt_(tdx * tdx + tdy * tdy);
+    T target_psi = atan2_(tdy * in, tdx * in);
+    T np_ = angle_normalize(target_psi - psi);
+    ring_push(ring, np_);
+    if (ring.len > E.reward_delay_steps) {
+      T old = ring_pop(ring);
+      T delta = -(abs_(np_) - abs_(old)) * rcp_(E.dt * T(E.reward_delay_steps));
+      fwd = delta * E.yaw_weight;
+    }
+    ctrl_cost = cc;
+  } else if (E.action == TGR_ACT_TRACKING) {  // tr_env.py:448-460
+    fwd = ditch_reward(E, ms, xa, ya) - ditch_reward(E, ms, xy_bx, xy_by);
+    ctrl_cost = cc;
+  } else {  // vel_track, tr_env.py:462-474
+    T ang = angle_normalize(psi - ms.psi_before) * idt;
+    T ex = xv - ms.vcmd[0], ey = yv - ms.vcmd[1], ew = ang - ms.vcmd[2];
+    fwd = exp_(T(-5) * (ex * ex + ey * ey)) + T(0.5) * exp_(T(-7) * ew * ew);
+    ctrl_cost = cc;
   }
   T hr = E.terminate_when_unhealthy ? ((healthy || E.terminate_when_unhealthy) ? E.healthy_reward : T(0)) : T(0);
+  if (E.action == TGR_ACT_AIMING || E.action == TGR_ACT_TRACKING) hr = T(0);
   bool term = E.terminate_when_unhealthy ? !healthy : false;
+  if ((E.action == TGR_ACT_AIMING || E.action == TGR_ACT_TRACKING) && ms.step_num > 1000) term = true;
   if (lag.cfrc_absmax > T(1500)) term = true;
   if (!finite) term = true;  // a non-finite lane never survives the step
   T costs = ctrl_cost;
   o.info[TGR_INFO_REWARD_FORWARD] = fwd;
   o.info[TGR_INFO_REWARD_CTRL] = -ctrl_cost;
+  if (E.use_contact_forces) {  // tensegrity_env.py:401-404 (the info overwrite is the reference's)
+    T contact_cost = E.contact_cost_weight * lag.cfrc_clip_sq;
+    costs += contact_cost;
+    o.info[TGR_INFO_REWARD_CTRL] = -contact_cost;
+  }
   o.info[TGR_INFO_REWARD_SURVIVE] = hr;
   o.info[TGR_INFO_X_POSITION] = xa;
   o.info[TGR_INFO_Y_POSITION] = ya;
@@ -324,28 +384,75 @@ template <typename T> TGR_DEV void init_episode(const EnvCfg<T>& E, unsigned lon
 
 template <typename T> TGR_DEV int settle_total(const EnvCfg<T>& E) {
   // tr_env turn: reward_delay_steps extra full env steps after the 50 settle periods (tr_env.py:864-866)
-  return 50 + ((E.env_kind == TGR_ENV_TR && E.action == TGR_ACT_TURN) ? E.reward_delay_steps : 0);
+  return 50 + ((E.env_kind == TGR_ENV_TR && (E.action == TGR_ACT_TURN || E.action == TGR_ACT_AIMING)) ? E.reward_delay_steps : 0);
 }
 
-// bookkeeping after settle period `st` (0-based) of reset_model(); returns true when the episode is ready
+// bookkeeping after settle period `st` (0-based) of reset_model() (tensegrity_env.py:495-510, tr_env.py:811-866)
 template <typename T>
 TGR_DEV void settle_period_done(const Params<T>& P, const EnvCfg<T>& E, const Lag<T>& lag, int st, RingRef<T>& ring, int& step_num,
-                                T& reset_psi) {
+                                T& reset_psi, ModeState<T>& ms, T* xy_prev, unsigned long long key, unsigned long long episode) {
   V3<T> cap[6], l, r;
   caps_of(P, lag, cap);
   left_right(cap, l, r);
-  if (st == 49) reset_psi = atan2_(-(l.x - r.x), l.y - r.y);
-  const bool turn = E.action == TGR_ACT_TURN;
-  bool env_step = (E.env_kind == TGR_ENV_TENSEGRITY) || st >= 50;  // settling through self.step() vs do_simulation()
-  if (env_step && turn) {
-    T psi = E.env_kind == TGR_ENV_TENSEGRITY ? atan2_(r.y - l.y, r.x - l.x) : atan2_(-(l.x - r.x), l.y - r.y);
-    ring_push(ring, psi);
+  T psi_s = atan2_(-(l.x - r.x), l.y - r.y);
+  const bool tr = E.env_kind == TGR_ENV_TR;
+  if (st == 49) {
+    reset_psi = psi_s;
+    if (tr && (E.action == TGR_ACT_TRACKING || E.action == TGR_ACT_AIMING)) {
+      Draws dr = reset_draws(E, key, episode);
+      double len = E.waypt_range[0] + dr.u_way[0] * (E.waypt_range[1] - E.waypt_range[0]);
+      double yaw;
+      if (E.action == TGR_ACT_TRACKING) {  // tr_env.py:827-839
+        ms.ori[0] = (l.x + r.x) * T(0.5); ms.ori[1] = (l.y + r.y) * T(0.5);
+        yaw = E.waypt_angle_range[0] + dr.u_way[1] * (E.waypt_angle_range[1] - E.waypt_angle_range[0]) + (double)reset_psi;
+        if (E.is_test) { len = 0.5 * E.waypt_range[1] + 0.5 * E.waypt_range[0]; yaw = 0.5 * E.waypt_angle_range[1] + 0.5 * E.waypt_angle_range[0] + (double)reset_psi; }
+      } else {  // aiming, tr_env.py:842-855 (the reference's oripoint[0] = lx + rx/2 is kept)
+        ms.ori[0] = l.x + r.x * T(0.5); ms.ori[1] = (l.y + r.y) * T(0.5);
+        yaw = -PI + dr.u_way[1] * 2 * PI + (double)reset_psi;
+        if (E.is_test) { len = 0.5 * E.waypt_range[1] + 0.5 * E.waypt_range[0]; yaw = 0.75 * PI + 0.25 * (-PI) + (double)reset_psi; }
+      }
+      ms.waypt[0] = T((double)ms.ori[0] + len * cos(yaw)); ms.waypt[1] = T((double)ms.ori[1] + len * sin(yaw));
+      if (E.action == TGR_ACT_AIMING && E.is_test) { ms.waypt[0] = T(0); ms.waypt[1] = T(0); }
+    } else if (tr && E.action == TGR_ACT_VEL_TRACK) {
+      ms.vcmd[0] = T(0.5) * cos_(reset_psi); ms.vcmd[1] = T(0.5) * sin_(reset_psi); ms.vcmd[2] = T(0);
+    }
+  }
+  const bool ring_mode = E.action == TGR_ACT_TURN || (tr && E.action == TGR_ACT_AIMING);
+  bool env_step = (!tr) || st >= 50;  // settling through self.step() vs do_simulation()
+  if (env_step && ring_mode) {
+    T v;
+    if (!tr) v = atan2_(r.y - l.y, r.x - l.x);
+    else if (E.action == TGR_ACT_TURN) v = psi_s;
+    else {
+      T tdx = ms.waypt[0] - xy_prev[0], tdy = ms.waypt[1] - xy_prev[1];
+      T in = rsqrt_(tdx * tdx + tdy * tdy);
+      v = angle_normalize(atan2_(tdy * in, tdx * in) - psi_s);
+    }
+    ring_push(ring, v);
     if (ring.len > E.reward_delay_steps) (void)ring_pop(ring);
   }
   if (st >= 50) step_num += 1;
+  T third = T(1.0 / 3.0);
+  xy_prev[0] = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x);
+  xy_prev[1] = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
 }
 
 // what reset_model() leaves behind besides qpos/qvel
+template <typename T>
+TGR_DEV void store_modes(T* st, int m, int e, const ModeState<T>& ms) {
+  st[(F_WAYPT + 0) * m + e] = ms.waypt[0]; st[(F_WAYPT + 1) * m + e] = ms.waypt[1];
+  st[(F_ORI + 0) * m + e] = ms.ori[0]; st[(F_ORI + 1) * m + e] = ms.ori[1];
+  st[(F_VCMD + 0) * m + e] = ms.vcmd[0]; st[(F_VCMD + 1) * m + e] = ms.vcmd[1]; st[(F_VCMD + 2) * m + e] = ms.vcmd[2];
+}
+template <typename T> TGR_DEV ModeState<T> load_modes(const T* st, const int* ist, int m, int e) {
+  ModeState<T> ms;
+  ms.waypt[0] = st[(F_WAYPT + 0) * m + e]; ms.waypt[1] = st[(F_WAYPT + 1) * m + e];
+  ms.ori[0] = st[(F_ORI + 0) * m + e]; ms.ori[1] = st[(F_ORI + 1) * m + e];
+  ms.vcmd[0] = st[(F_VCMD + 0) * m + e]; ms.vcmd[1] = st[(F_VCMD + 1) * m + e]; ms.vcmd[2] = st[(F_VCMD + 2) * m + e];
+  ms.psi_before = st[F_PSILAG * m + e];
+  ms.step_num = ist[I_STEPNUM * m + e];
+  return ms;
+}
 template <typename T>
 TGR_DEV void store_reset_aux(const Params<T>& P, T* st, int* ist, int m, int e, const Lag<T>& lag, T reset_psi, int step_num,
                              const RingRef<T>& ring) {
@@ -414,9 +521,10 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
   int step_num = k.ist[I_STEPNUM * m + e], elapsed = k.ist[I_ELAPSED * m + e];
   RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
   ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
+  ModeState<T> ms = load_modes(k.st, k.ist, m, e);
 
   Lag<T> lag;
-  lag.cfrc_absmax = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
+  lag.cfrc_absmax = T(0); lag.cfrc_clip_sq = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
 #ifdef TGR_STAMPS
   for (int i = 0; i < 8; i++) lag.stamp[i] = 0;
   lag.t_last = clock64();
@@ -451,7 +559,12 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
     if (active && w0) {
       const int stp = total - phase;  // 0-based index of the period just run
       if (stp == 0) { step_num = 0; }
-      settle_period_done(P, E, lag, stp, ring, step_num, reset_psi);
+      T xy_prev[2] = {xy_bx, xy_by};
+      settle_period_done(P, E, lag, stp, ring, step_num, reset_psi, ms, xy_prev, lane_key(E, n, e),
+                         (unsigned long long)(unsigned)k.ist[I_SRCEP * m + e]);
+      k.st[(F_XYLAG + 0) * m + e] = xy_prev[0]; k.st[(F_XYLAG + 1) * m + e] = xy_prev[1];
+      store_modes(k.st, m, e, ms);
+      ms.step_num = step_num;
       phase -= 1;
       k.st[F_RESETPSI * m + e] = reset_psi;
       k.ist[I_STEPNUM * m + e] = step_num;
@@ -460,7 +573,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
       if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
       if (phase == PH_READY) {
         store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
-        make_obs(P, E, S, lag, wb, ob);
+        make_obs(P, E, S, lag, wb, ms, ob);
         T* op = k.dobs + (size_t)(e - n) * D;
         for (int i = 0; i < D; i++) op[i] = ob[i];
       }
@@ -470,13 +583,13 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
   StepOut<T> out;
   bool truncated = false, done = false;
   if (live) {
-    out = env_epilogue(P, E, S, lag, wb, action, xy_bx, xy_by, reset_psi, ring);
+    out = env_epilogue(P, E, S, lag, wb, action, xy_bx, xy_by, reset_psi, ring, ms);
     if (E.env_kind == TGR_ENV_TR) step_num += 1;
     elapsed += 1;
     truncated = elapsed >= E.max_episode_steps;
     ep_ret += out.reward;
     done = out.terminated || truncated;
-    make_obs(P, E, S, lag, wb, ob);
+    make_obs(P, E, S, lag, wb, ms, ob);
     if (valid && w0) {
       k.st[(F_XYLAG + 0) * m + e] = out.xy[0]; k.st[(F_XYLAG + 1) * m + e] = out.xy[1];
       k.st[F_PSILAG * m + e] = out.psi_straight;
@@ -548,18 +661,22 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void settle_kern
   int step_num = 0;
   const int total = settle_total(E);
   Lag<T> lag;
-  lag.cfrc_absmax = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
+  lag.cfrc_absmax = T(0); lag.cfrc_clip_sq = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
   T reset_psi = T(0);
+  ModeState<T> ms = load_modes(k.st, k.ist, m, e);
+  T xy_prev[2] = {T(0), T(0)};
 #pragma unroll 1
   for (int st = 0; st < total; st++) {
 #pragma unroll 1
     for (int s = 0; s < E.frame_skip; s++) substep<T, LW>(P, S, lds, wid, s == E.frame_skip - 1, lag);
-    if (valid) settle_period_done(P, E, lag, st, ring, step_num, reset_psi);
+    if (valid) settle_period_done(P, E, lag, st, ring, step_num, reset_psi, ms, xy_prev, lane_key(E, n, e), (unsigned long long)(unsigned)episode);
   }
   if (!valid || wid != 0) return;
   V3<T> wb[3];
   store_sim(k.st, m, e, S, lag, wb);
   store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
+  store_modes(k.st, m, e, ms);
+  ms.step_num = step_num;
   k.ist[I_SRC * m + e] = e;
   k.ist[I_SRCEP * m + e] = episode;
   k.ist[I_EPISODE * m + e] = episode + 1;
@@ -567,7 +684,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void settle_kern
   atomicAdd(&k.counters[1], 1ull);
   if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
   T ob[48];
-  make_obs(P, E, S, lag, wb, ob);
+  make_obs(P, E, S, lag, wb, ms, ob);
   T* op = e < n ? (k.obs_reset ? k.obs_reset + (size_t)e * E.obs_dim : nullptr) : k.dobs + (size_t)(e - n) * E.obs_dim;
   if (op)
     for (int i = 0; i < E.obs_dim; i++) op[i] = ob[i];
@@ -755,6 +872,10 @@ extern "C" int tgr_default_config(tgr_config* c, int env_kind, int desired_actio
   c->first_env_id = 0;
   c->solver_tolerance = 0;
   c->solver_iterations = 0;
+  c->waypt_range[0] = 2.5; c->waypt_range[1] = 3.5;  // tr_env.py:166-172
+  c->waypt_angle_range[0] = -PI / 6; c->waypt_angle_range[1] = PI / 6;
+  c->ditch_reward_max = 300; c->ditch_reward_stdev = 0.15; c->waypt_reward_amplitude = 100; c->waypt_reward_stdev = 0.10;
+  c->yaw_reward_weight = 1;
   return TGR_OK;
 }
 
@@ -803,6 +924,11 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   E.direction = T(c.desired_direction); E.ctrl_cost_weight = T(c.ctrl_cost_weight); E.contact_cost_weight = T(c.contact_cost_weight);
   E.healthy_reward = T(c.healthy_reward); E.contact_lo = T(c.contact_force_lo); E.contact_hi = T(c.contact_force_hi);
   E.dt = T(c.timestep * c.frame_skip);
+  E.ditch_max = T(c.ditch_reward_max); E.ditch_std = T(c.ditch_reward_stdev); E.waypt_amp = T(c.waypt_reward_amplitude);
+  E.waypt_std = T(c.waypt_reward_stdev); E.yaw_weight = T(c.yaw_reward_weight);
+  E.waypt_range[0] = c.waypt_range[0]; E.waypt_range[1] = c.waypt_range[1];
+  E.waypt_angle_range[0] = c.waypt_angle_range[0]; E.waypt_angle_range[1] = c.waypt_angle_range[1];
+  P.cf_lo = T(c.contact_force_lo); P.cf_hi = T(c.contact_force_hi);
   E.min_heading = c.min_reset_heading; E.max_heading = c.max_reset_heading;
   E.ten_mean = c.tendon_reset_mean; E.ten_std = c.tendon_reset_stdev; E.ten_max = c.tendon_max_length; E.ten_min = c.tendon_min_length;
   E.seed = c.seed; E.first_env_id = c.first_env_id;
@@ -816,11 +942,11 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
 
 extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_handle** out) {
   if (!cfg || !out || n_envs <= 0) { g_err = "tgr_create: bad arguments"; return TGR_ERR_INVALID; }
-  if (cfg->desired_action != TGR_ACT_STRAIGHT && cfg->desired_action != TGR_ACT_TURN) {
-    g_err = "tgr_create: desired_action must be straight or turn (aiming/tracking/vel_track: not built yet)";
+  if (cfg->desired_action < TGR_ACT_STRAIGHT || cfg->desired_action > TGR_ACT_VEL_TRACK ||
+      (cfg->env_kind == TGR_ENV_TENSEGRITY && cfg->desired_action > TGR_ACT_TURN)) {
+    g_err = "tgr_create: desired_action not supported by this env class (tensegrity_env: straight|turn; tr_env: + aiming|tracking|vel_track)";
     return TGR_ERR_UNSUPPORTED;
   }
-  if (cfg->use_contact_forces) { g_err = "tgr_create: use_contact_forces not built yet"; return TGR_ERR_UNSUPPORTED; }
   if (cfg->solimp[4] != 2.0 || cfg->solref[0] >= 0) { g_err = "tgr_create: only direct solref and power-2 solimp"; return TGR_ERR_UNSUPPORTED; }
   if (cfg->n_donors > 8 * n_envs) { g_err = "tgr_create: n_donors must be <= 8 * n_envs"; return TGR_ERR_INVALID; }
   if (cfg->reward_delay_steps >= RING - 1 || cfg->reward_delay_steps < 0) { g_err = "tgr_create: reward_delay_steps too large"; return TGR_ERR_INVALID; }

@@ -18,12 +18,12 @@ ENV_IDS = {"tensegrity_env-v0": N.ENV_TENSEGRITY, "tr_env-v0": N.ENV_TR, "tenseg
 # constructor kwargs of the reference classes that map 1:1 onto tgr_config fields
 _DIRECT = ["use_contact_forces", "use_cap_velocity", "terminate_when_unhealthy", "is_test", "desired_direction",
            "ctrl_cost_weight", "contact_cost_weight", "healthy_reward", "min_reset_heading", "max_reset_heading",
-           "tendon_reset_mean", "tendon_reset_stdev", "tendon_max_length", "tendon_min_length"]
+           "tendon_reset_mean", "tendon_reset_stdev", "tendon_max_length", "tendon_min_length", "ditch_reward_max",
+           "ditch_reward_stdev", "waypt_reward_amplitude", "waypt_reward_stdev", "yaw_reward_weight"]
 # accepted for signature compatibility, no effect on the built path (reference defaults)
 _IGNORED = ["xml_file", "render_mode", "reset_noise_scale", "contact_with_self_penalty", "use_obs_noise",
-            "use_cap_size_noise", "obs_noise_tendon_stdev", "obs_noise_cap_pos_stdev", "cap_size_noise_range", "way_pts_range",
-            "way_pts_angle_range", "threshold_waypt", "ditch_reward_max", "ditch_reward_stdev", "waypt_reward_amplitude",
-            "waypt_reward_stdev", "yaw_reward_weight", "width", "height", "camera_id", "camera_name"]
+            "use_cap_size_noise", "obs_noise_tendon_stdev", "obs_noise_cap_pos_stdev", "cap_size_noise_range",
+            "threshold_waypt", "width", "height", "camera_id", "camera_name"]
 
 
 def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision="f32", auto_reset=True, seed=1234,
@@ -40,7 +40,7 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
             setattr(cfg, k, type(getattr(cfg, k))(kwargs.pop(k)))
         elif k in _IGNORED:
             v = kwargs.pop(k)
-            if k in ("use_obs_noise", "use_cap_size_noise") and v:
+            if k in ("use_obs_noise", "use_cap_size_noise") and v:  # noqa: SIM102
                 raise NotImplementedError(f"{k}=True is not built yet (SURVEY.md 8f)")
             if k == "reset_noise_scale" and v:
                 raise NotImplementedError("reset_noise_scale != 0 is not built")
@@ -49,6 +49,10 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
         cfg.contact_force_lo, cfg.contact_force_hi = float(lo), float(hi)
         if desired_action == "turn":  # tensegrity_env.py:224-225
             cfg.contact_force_lo, cfg.contact_force_hi = -1000.0, 1000.0
+    for src, dst in (("way_pts_range", "waypt_range"), ("way_pts_angle_range", "waypt_angle_range")):
+        if src in kwargs:
+            lo, hi = kwargs.pop(src)
+            getattr(cfg, dst)[0], getattr(cfg, dst)[1] = float(lo), float(hi)
     if "reward_delay_seconds" in kwargs:
         cfg.reward_delay_steps = int(kwargs.pop("reward_delay_seconds") / (cfg.timestep * cfg.frame_skip))
     for k in ("actuator_deriv_skip_clamped", "solver_tolerance", "solver_iterations", "n_donors"):

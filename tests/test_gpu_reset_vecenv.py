@@ -7,7 +7,8 @@ from gpu_common import AUX, qfix
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind,action", [("tensegrity_env", "straight"), ("tensegrity_env", "turn"), ("tr_env", "straight"), ("tr_env", "turn")])
+@pytest.mark.parametrize("kind,action", [("tensegrity_env", "straight"), ("tensegrity_env", "turn"), ("tr_env", "straight"), ("tr_env", "turn"),
+                                         ("tr_env", "tracking"), ("tr_env", "aiming"), ("tr_env", "vel_track")])
 def test_reset_matches_oracle_fp64(oracle, kind, action):
     """same philox draws -> same start pose -> 1000 sub-steps of settling agree (fp64)"""
     from tensegrity_rl_amd import TensegrityVecEnv
@@ -23,6 +24,8 @@ def test_reset_matches_oracle_fp64(oracle, kind, action):
     assert np.abs(st["qvel"] - v).max() < 1e-5
     assert np.abs(st["ctrl"] - c).max() < 1e-12
     assert np.abs(st["aux"][:, AUX["reset_psi"]] - aux["reset_psi"]).max() < 1e-6
+    for k_ in ("waypt_x", "waypt_y", "ori_x", "ori_y", "vcmd_x", "vcmd_y", "vcmd_w"):
+        assert np.abs(st["aux"][:, AUX[k_]] - aux[k_]).max() < 1e-6, k_
     assert np.abs(obs - oobs).max() < 1e-5
     # and the first steps after the reset, including the heading ring the settle left behind (turn mode)
     rng = np.random.default_rng(3)
