@@ -114,3 +114,34 @@ def test_reset_draw_distributions(oracle):
     th = np.array(th); tend = np.array(tend)
     assert 0 <= th.min() and th.max() < 2 * np.pi and abs(th.mean() - np.pi) < 0.15
     assert tend.max() <= 0.15 and tend.min() >= -0.45 and abs(np.mean(tend >= 0.15) - 0.5) < 0.03
+
+
+@pytest.mark.parametrize("name,direction,need", [("forward", 1, 5), ("backward", -1, 6)])
+def test_mujoco_trained_policies_move_the_right_way(oracle, golden_dir, name, direction, need):
+    """Behavioural anchor: the SAC actors shipped in best_models_pretrained/ were trained against real
+    MuJoCo (weights extracted by oracle/extract_policies.py).  Rolled out deterministically in this restatement
+    (termination ignored, 250 control periods = 5 s, 8 reset seeds) most 'forward' rollouts must travel along their reset
+    heading and most 'backward' rollouts against it.  This is a plausibility check, not parity: the gaits are chaotic and
+    in this simulator the policies hit the 1500 N wrench termination after ~40 steps, far earlier than the ~1600-step
+    episodes of their training logs."""
+    import os
+    O = oracle
+    g = np.load(os.path.join(golden_dir, f"policy_{name}.npz"))
+    W = [g["latent_pi_0_weight"].astype(np.float64), g["latent_pi_2_weight"].astype(np.float64), g["mu_weight"].astype(np.float64)]
+    B = [g["latent_pi_0_bias"].astype(np.float64), g["latent_pi_2_bias"].astype(np.float64), g["mu_bias"].astype(np.float64)]
+    lo, hi = float(g["low"]), float(g["high"])
+    n = 8
+    ob = O.OracleBatch(O.make_cfg("tensegrity_env", "straight", desired_direction=direction), n, seed=1234)
+    obs = ob.reset()
+    psi0 = np.array([ob.env(i).reset_psi for i in range(n)])
+    x0 = np.array([O.arr(ob.env(i).data.xpos)[:, :2].mean(axis=0) for i in range(n)])
+    for t in range(250):
+        h = obs
+        for i in range(2):
+            h = np.maximum(h @ W[i].T + B[i], 0)
+        a = (lo + 0.5 * (np.tanh(h @ W[2].T + B[2]) + 1) * (hi - lo)).astype(np.float32)
+        obs, rew, term, trunc, tobs, info = ob.step(a, auto_reset=False)
+    d = info[:, 3:5] - x0
+    along = d[:, 0] * np.cos(psi0) + d[:, 1] * np.sin(psi0)
+    assert int(np.sum(direction * along > 0.05)) >= need, along
+    ob.close()
