@@ -1,4 +1,9 @@
-"""Build libtensegrity.so (HIP, gfx950) in-tree with hipcc."""
+"""Build libtensegrity.so (HIP, gfx950) in-tree with hipcc.
+
+Staleness is decided by a hash of the sources kept next to the library (mtimes do not survive a copy to another box);
+concurrent ranks serialise on a lock file and publish the library with an atomic rename."""
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -7,24 +12,49 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "tgr_sim.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "tgr_device.h"), os.path.join(os.path.dirname(HERE), "include", "tensegrity.h")]
 LIB = os.path.join(HERE, "libtensegrity.so")
+STAMP = LIB + ".srchash"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 
 
 def lib_path():
     return LIB
 
 
+def _src_hash():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in DEPS:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    return not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS if os.path.exists(d))
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+        return True
+    try:
+        return open(STAMP).read().strip() != _src_hash()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-o", LIB, SRC]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # another rank built it while we waited
+                return LIB
+            tmp = f"{LIB}.tmp.{os.getpid()}"
+            cmd = [hipcc] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-o", tmp, SRC]
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+            with open(STAMP + ".tmp", "w") as f:
+                f.write(_src_hash())
+            os.replace(STAMP + ".tmp", STAMP)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

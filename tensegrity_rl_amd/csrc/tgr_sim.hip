@@ -90,6 +90,7 @@ template <typename T> __device__ inline Draws reset_draws(const EnvCfg<T>& E, un
   philox(c0, c1, c2, 0, k0, k1, o);
   d.pose = (int)(o[0] % 6u);
   d.theta = E.min_heading + u53(o[1], o[2]) * (E.max_heading - E.min_heading);
+#pragma unroll
   for (int k = 0; k < 3; k++) {
     philox(c0, c1, c2, 1 + k, k0, k1, o);
     double u1 = 1.0 - u53(o[0], o[1]), u2 = u53(o[2], o[3]);
@@ -167,6 +168,7 @@ template <typename T> struct ModeState;
 // observation of the env into o[0..D)
 template <typename T>
 TGR_DEV void make_obs(const Params<T>& P, const EnvCfg<T>& E, const Sim<T>& S, const Lag<T>& lag, const V3<T>* wb, const ModeState<T>& ms, T* o) {
+  // o points into LDS (this lane's row of the block's observation tile): runtime offsets are plain address arithmetic there
   if (E.env_kind == TGR_ENV_TENSEGRITY) {
     // tensegrity_env.py:412-430: scipy quaternion (x,y,z,w) of the r-cylinder geom frame = body * quat(0,0,0,1)
 #pragma unroll
@@ -553,7 +555,9 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
     for (int b = 0; b < 3; b++) wb[b] = mk(T(0), T(0), T(0));
   }
   const int D = E.obs_dim;
-  T ob[48];
+  const int Dp = (D & 1) ? D : D + 1;  // odd row pitch of the observation tile: conflict-free
+  T* orow = lds_all + lane * Dp;       // this lane's row (the physics columns are dead after the barrier below)
+  __syncthreads();
   if (!live) {
     // ---- donor lane: one more settle period done
     if (active && w0) {
@@ -573,12 +577,11 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
       if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
       if (phase == PH_READY) {
         store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
-        make_obs(P, E, S, lag, wb, ms, ob);
+        make_obs(P, E, S, lag, wb, ms, orow);
         T* op = k.dobs + (size_t)(e - n) * D;
-        for (int i = 0; i < D; i++) op[i] = ob[i];
+        for (int i = 0; i < D; i++) op[i] = orow[i];
       }
     }
-    // donors never take part in the observation transpose below (their rows do not exist)
   }
   StepOut<T> out;
   bool truncated = false, done = false;
@@ -589,8 +592,8 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
     truncated = elapsed >= E.max_episode_steps;
     ep_ret += out.reward;
     done = out.terminated || truncated;
-    make_obs(P, E, S, lag, wb, ms, ob);
     if (valid && w0) {
+      make_obs(P, E, S, lag, wb, ms, orow);
       k.st[(F_XYLAG + 0) * m + e] = out.xy[0]; k.st[(F_XYLAG + 1) * m + e] = out.xy[1];
       k.st[F_PSILAG * m + e] = out.psi_straight;
       k.st[F_EPRET * m + e] = ep_ret;
@@ -604,29 +607,21 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
         T* ip = k.info + (size_t)e * TGR_INFO_K;
 #pragma unroll
         for (int i = 0; i < 10; i++) ip[i] = out.info[i];
-        ip[TGR_INFO_WAYPT_X] = k.st[(F_WAYPT + 0) * m + e]; ip[TGR_INFO_WAYPT_Y] = k.st[(F_WAYPT + 1) * m + e];
-        ip[TGR_INFO_ORI_X] = k.st[(F_ORI + 0) * m + e]; ip[TGR_INFO_ORI_Y] = k.st[(F_ORI + 1) * m + e];
+        ip[TGR_INFO_WAYPT_X] = ms.waypt[0]; ip[TGR_INFO_WAYPT_Y] = ms.waypt[1];
+        ip[TGR_INFO_ORI_X] = ms.ori[0]; ip[TGR_INFO_ORI_Y] = ms.ori[1];
         ip[TGR_INFO_EP_RETURN] = ep_ret; ip[TGR_INFO_EP_LENGTH] = T(elapsed);
       }
       if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
       if (done && k.terminal_obs) {
         T* tp = k.terminal_obs + (size_t)e * D;
-        for (int i = 0; i < D; i++) tp[i] = ob[i];
+        for (int i = 0; i < D; i++) tp[i] = orow[i];
       }
     }
   }
-  // observations of the live lanes of this block: transpose through LDS so the [N][D] buffer is written with
-  // coalesced stores (the physics scratch columns are dead by now)
+  // observations of the live lanes of this block leave through the LDS tile: coalesced stores into the [N][D] buffer
   const int base = blockIdx.x * LW;
   const int rows = min(LW, n - base);
   if (rows > 0) {
-    __syncthreads();
-    const int Dp = (D & 1) ? D : D + 1;  // odd row pitch: conflict-free
-    if (live && w0) {
-#pragma unroll
-      for (int i = 0; i < 48; i++)
-        if (i < D) lds_all[lane * Dp + i] = ob[i];
-    }
     __syncthreads();
     for (int f = wid * LW + lane; f < rows * D; f += 4 * LW) {
       int r = f / D, c = f - r * D;
@@ -683,11 +678,12 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void settle_kern
   k.ist[I_PHASE * m + e] = e < n ? PH_LIVE : PH_READY;
   atomicAdd(&k.counters[1], 1ull);
   if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
-  T ob[48];
-  make_obs(P, E, S, lag, wb, ms, ob);
-  T* op = e < n ? (k.obs_reset ? k.obs_reset + (size_t)e * E.obs_dim : nullptr) : k.dobs + (size_t)(e - n) * E.obs_dim;
+  const int D = E.obs_dim;
+  T* orow = lds_all + lane * ((D & 1) ? D : D + 1);  // wave 0 only from here on; the columns are dead
+  make_obs(P, E, S, lag, wb, ms, orow);
+  T* op = e < n ? (k.obs_reset ? k.obs_reset + (size_t)e * D : nullptr) : k.dobs + (size_t)(e - n) * D;
   if (op)
-    for (int i = 0; i < E.obs_dim; i++) op[i] = ob[i];
+    for (int i = 0; i < D; i++) op[i] = orow[i];
 }
 
 // ------------------------------------------------------------------ match kernel (one block)
