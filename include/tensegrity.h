@@ -96,6 +96,7 @@ typedef struct tgr_config {
   /* --- tr_env command modes (tr_env.py:164-172) */
   double waypt_range[2], waypt_angle_range[2];
   double ditch_reward_max, ditch_reward_stdev, waypt_reward_amplitude, waypt_reward_stdev, yaw_reward_weight;
+  int32_t solver_warm_start; /* 0 (default): every solve starts from the unconstrained acceleration; 1: from the previous solution */
 } tgr_config;
 
 typedef struct tgr_handle tgr_handle;

@@ -69,7 +69,7 @@ template <typename T> struct Params {
   T invweight;                            // 1/m : body_invweight0 translational
   T tol, ls_tol;
   T cf_lo, cf_hi;                         // contact_force_range of the env (for contact_cost)
-  int max_iter, ls_iter, skip_clamped;
+  int max_iter, ls_iter, skip_clamped, warm_start;
 };
 
 // static model tables (3prism_jonathan_steady_side.xml:82-87,127-164)
@@ -96,8 +96,8 @@ enum : int {
   L_FC = L_P + 18,      // constraint wrench per bar (J^T f) == cfrc_ext
   L_EZ = L_FC + 18,     // bar axes (3 x 3)
   L_X = L_EZ + 9,       // bar COM positions (3 x 3)
-  L_RED = L_X + 9,      // cross-wave partial sums (32)
-  L_TOTAL = L_RED + 32  // 527
+  L_RED = L_X + 9,      // cross-wave partial sums and exchange slots (50)
+  L_TOTAL = L_RED + 50  // 545
 };
 constexpr __host__ __device__ int H_D(int b) { return L_H + 21 * b; }
 constexpr int H_O10 = L_H + 63, H_O20 = L_H + 99, H_O21 = L_H + 135;
@@ -125,7 +125,7 @@ template <typename T> struct Lag {
   int n_it, n_ls;  // solver work of this control period (wave-uniform)
   int n_unconv;    // sub-steps this lane left the solver at the iteration cap
 #ifdef TGR_STAMPS
-  long long stamp[8]; long long t_last;  // diagnostic build only: cycles per phase
+  long long stamp[32]; long long t_last;  // diagnostic build only: cycles per phase
 #endif
 };
 
@@ -354,13 +354,22 @@ template <typename T> TGR_DEV void cross_block_add(T* O, const Cone<T>& o, V3<T>
 }
 
 // in-place Cholesky of a packed lower 6x6; diagonal stores 1/L_jj
-template <typename T> TGR_DEV void chol6(T* D) {
+// ref[j]: the diagonal of the Hessian block before any Schur update.  Pivots are floored relative to it: a Schur
+// complement that loses positivity to rounding must cost accuracy of one Newton direction (the line search copes),
+// never produce inf.
+template <typename T> TGR_DEV void diag6(const T* D, T* ref) {
+#pragma unroll
+  for (int j = 0; j < 6; j++) ref[j] = D[tri(j, j)];
+}
+template <typename T> TGR_DEV void chol6(T* D, const T* ref) {
+  const T rel = sizeof(T) == 4 ? T(1e-6) : T(1e-13);
 #pragma unroll
   for (int j = 0; j < 6; j++) {
+    T d0 = ref[j];
     T s = D[tri(j, j)];
 #pragma unroll
     for (int k = 0; k < j; k++) s -= D[tri(j, k)] * D[tri(j, k)];
-    s = max_(s, T(1e-30));
+    s = max_(s, max_(rel * abs_(d0), T(1e-30)));
     T il = rsqrt_(s);
     D[tri(j, j)] = il;
 #pragma unroll
@@ -762,71 +771,167 @@ TGR_DEV T newton_assemble(const Params<T>& P, T* lds, int wid, unsigned cpl, T& 
   return gn;
 }
 
-// blocked Cholesky of the Hessian in LDS spread over the waves, then P = -H^-1 G (P = 0 for converged lanes)
-template <typename T, int LW> TGR_DEV void newton_direction(T* lds, int wid, unsigned cpl, bool conv) {
+// Blocked Cholesky of the Hessian spread over the waves, with the triangular solves folded into the same pipeline:
+//   L = [[L00,0,0],[L10,L11,0],[L20,L21,L22]],  y = L^-1 G,  x = L^-T y,  P = -x   (P = 0 for converged lanes)
+// Each wave keeps the factors it produced in registers, so the back-substitution needs no block reloads:
+//   wave 0: L00, y0 ........................................... finally x0 = L00^-T (y0 - t1 - t2)
+//   wave 1: L10 = O10 L00^-T, L11, y1 .......................... x1 = L11^-T (y1 - s),  t1 = L10^T x1
+//   wave 2: L20 = O20 L00^-T, L22, y2, x2 ...................... s = L21^T x2,  t2 = L20^T x2
+//   wave 3: L21 = (O21 - L20 L10^T) L11^-T
+template <typename T> TGR_DEV void gemvT6(const T* O, const T* x, T* y) {  // y = O^T x
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    T s = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; k++) s += O[k * 6 + i] * x[k];
+    y[i] = s;
+  }
+}
+template <typename T, int LW> TGR_DEV void newton_direction(T* lds, int wid, unsigned cpl, bool conv, Lag<T>& lag) {
   const bool c10 = cpl & 1u, c20 = cpl & 2u, c21in = cpl & 4u;
   const bool c21 = c21in || (c10 && c20);  // fill-in
-  // column 0
-  if (wid == 0) { T L[21]; ld21<T, LW>(lds, H_D(0), L); chol6(L); st21<T, LW>(lds, H_D(0), L); }
-  __syncthreads();
-  if (wid == 1 && c10) { T L[21], O[36]; ld21<T, LW>(lds, H_D(0), L); ld36<T, LW>(lds, H_O10, O); trsm6(O, L); st36<T, LW>(lds, H_O10, O); }
-  if (wid == 2 && c20) { T L[21], O[36]; ld21<T, LW>(lds, H_D(0), L); ld36<T, LW>(lds, H_O20, O); trsm6(O, L); st36<T, LW>(lds, H_O20, O); }
-  if (c10 || c20) __syncthreads();
-  // column 1 (wave 1), trailing updates that only need column 0 (waves 2, 3)
-  if (wid == 1) {
-    T L[21]; ld21<T, LW>(lds, H_D(1), L);
-    if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); syrk6(L, O); }
-    chol6(L); st21<T, LW>(lds, H_D(1), L);
-  }
-  if (wid == 2 && c20) { T L[21], O[36]; ld21<T, LW>(lds, H_D(2), L); ld36<T, LW>(lds, H_O20, O); syrk6(L, O); st21<T, LW>(lds, H_D(2), L); }
-  if (wid == 3 && c21) {
-    T O21[36];
-    if (c21in) ld36<T, LW>(lds, H_O21, O21);
-    else {
+  constexpr int TS = L_RED + 32, T1 = L_RED + 38, T2 = L_RED + 44;  // s, t1, t2 exchange slots
+  T La[21];   // wave 0: L00   wave 1: L11   wave 2: L22
+  T Lb[36];   // wave 1: L10   wave 2: L20
+  T yv[6];    // this wave's y block
+  T dref[6];  // diagonal of this wave's block before the Schur updates
 #pragma unroll
-      for (int i = 0; i < 36; i++) O21[i] = T(0);
+  for (int i = 0; i < 36; i++) Lb[i] = T(0);
+  if (cpl == 0u) {
+    // no lane of the block couples two bars: three independent 6x6 solves
+    if (wid < 3) {
+      ld21<T, LW>(lds, H_D(wid), La);
+      diag6(La, dref);
+      chol6(La, dref);
+#pragma unroll
+      for (int i = 0; i < 6; i++) yv[i] = lds[(L_G + 6 * wid + i) * LW];
+      fsolve6(La, yv);
+      bsolve6(La, yv);
+#pragma unroll
+      for (int i = 0; i < 6; i++) lds[(L_P + 6 * wid + i) * LW] = conv ? T(0) : -yv[i];
     }
-    if (c10 && c20) { T Oa[36], Ob[36]; ld36<T, LW>(lds, H_O20, Oa); ld36<T, LW>(lds, H_O10, Ob); gemm6(O21, Oa, Ob); }
-    st36<T, LW>(lds, H_O21, O21);
+    TGR_STAMP(8); __syncthreads(); TGR_STAMP(9);
+    return;
   }
-  __syncthreads();
-  if (c21) {
-    if (wid == 2) { T L[21], O[36]; ld21<T, LW>(lds, H_D(1), L); ld36<T, LW>(lds, H_O21, O); trsm6(O, L); st36<T, LW>(lds, H_O21, O); }
-    __syncthreads();
-  }
-  // column 2
-  if (wid == 2) {
-    T L[21]; ld21<T, LW>(lds, H_D(2), L);
-    if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); syrk6(L, O); }
-    chol6(L); st21<T, LW>(lds, H_D(2), L);
-  }
-  __syncthreads();
-  // ---- solve  L L^T x = G   (serial chain: wave 0)
+  // ---- stage 1: column 0
   if (wid == 0) {
-    T L[21];
-    T x0[6], x1[6], x2[6];
+    ld21<T, LW>(lds, H_D(0), La);
+    diag6(La, dref);
+    chol6(La, dref);
+    st21<T, LW>(lds, H_D(0), La);
 #pragma unroll
-    for (int i = 0; i < 6; i++) { x0[i] = lds[(L_G + i) * LW]; x1[i] = lds[(L_G + 6 + i) * LW]; x2[i] = lds[(L_G + 12 + i) * LW]; }
-    ld21<T, LW>(lds, H_D(0), L); fsolve6(L, x0);
-    if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); gemv_sub(O, x0, x1); }
-    if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); gemv_sub(O, x0, x2); }
-    ld21<T, LW>(lds, H_D(1), L); fsolve6(L, x1);
-    if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); gemv_sub(O, x1, x2); }
-    ld21<T, LW>(lds, H_D(2), L); fsolve6(L, x2);
-    bsolve6(L, x2);
-    if (c21) { T O[36]; ld36<T, LW>(lds, H_O21, O); gemvT_sub(O, x2, x1); }
-    ld21<T, LW>(lds, H_D(1), L); bsolve6(L, x1);
-    if (c20) { T O[36]; ld36<T, LW>(lds, H_O20, O); gemvT_sub(O, x2, x0); }
-    if (c10) { T O[36]; ld36<T, LW>(lds, H_O10, O); gemvT_sub(O, x1, x0); }
-    ld21<T, LW>(lds, H_D(0), L); bsolve6(L, x0);
+    for (int i = 0; i < 6; i++) yv[i] = lds[(L_G + i) * LW];
+    fsolve6(La, yv);
+#pragma unroll
+    for (int i = 0; i < 6; i++) lds[(L_P + i) * LW] = yv[i];  // y0 parked in P's slots
+  }
+  TGR_STAMP(10); __syncthreads(); TGR_STAMP(11);
+  // ---- stage 2: L10, L11, y1 (wave 1) ; L20, trailing update of D2, partial y2 (wave 2)
+  if (wid == 1) {
+    T y0[6];
+    if (c10) {
+      T L0[21];
+      ld21<T, LW>(lds, H_D(0), L0);
+      ld36<T, LW>(lds, H_O10, Lb);
+      trsm6(Lb, L0);
+      st36<T, LW>(lds, H_O10, Lb);
+#pragma unroll
+      for (int i = 0; i < 6; i++) y0[i] = lds[(L_P + i) * LW];
+    }
+    ld21<T, LW>(lds, H_D(1), La);
+    diag6(La, dref);
+#pragma unroll
+    for (int i = 0; i < 6; i++) yv[i] = lds[(L_G + 6 + i) * LW];
+    if (c10) { syrk6(La, Lb); gemv_sub(Lb, y0, yv); }
+    chol6(La, dref);
+    st21<T, LW>(lds, H_D(1), La);
+    fsolve6(La, yv);
+#pragma unroll
+    for (int i = 0; i < 6; i++) lds[(L_P + 6 + i) * LW] = yv[i];  // y1
+  }
+  if (wid == 2) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) yv[i] = lds[(L_G + 12 + i) * LW];
+    ld21<T, LW>(lds, H_D(2), La);
+    if (c20) {
+      T L0[21], y0[6];
+      ld21<T, LW>(lds, H_D(0), L0);
+      ld36<T, LW>(lds, H_O20, Lb);
+      trsm6(Lb, L0);
+      st36<T, LW>(lds, H_O20, Lb);
+#pragma unroll
+      for (int i = 0; i < 6; i++) y0[i] = lds[(L_P + i) * LW];
+      syrk6(La, Lb);
+      gemv_sub(Lb, y0, yv);
+    }
+  }
+  TGR_STAMP(12); __syncthreads(); TGR_STAMP(13);
+  // ---- stage 3: L21 (wave 3)
+  if (c21) {
+    if (wid == 3) {
+      T O21[36], L1[21];
+      if (c21in) ld36<T, LW>(lds, H_O21, O21);
+      else {
+#pragma unroll
+        for (int i = 0; i < 36; i++) O21[i] = T(0);
+      }
+      if (c10 && c20) { T Oa[36], Ob[36]; ld36<T, LW>(lds, H_O20, Oa); ld36<T, LW>(lds, H_O10, Ob); gemm6(O21, Oa, Ob); }
+      ld21<T, LW>(lds, H_D(1), L1);
+      trsm6(O21, L1);
+      st36<T, LW>(lds, H_O21, O21);
+    }
+    TGR_STAMP(14); __syncthreads(); TGR_STAMP(15);
+  }
+  // ---- stage 4: column 2, x2, and what the other back-substitutions need from it (wave 2)
+  if (wid == 2) {
+    T L21[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) L21[i] = T(0);
+    if (c21) {
+      T y1[6];
+      ld36<T, LW>(lds, H_O21, L21);
+#pragma unroll
+      for (int i = 0; i < 6; i++) y1[i] = lds[(L_P + 6 + i) * LW];
+      syrk6(La, L21);
+      gemv_sub(L21, y1, yv);
+    }
+    chol6(La, dref);
+    fsolve6(La, yv);
+    bsolve6(La, yv);  // x2
+    T sv[6], tv[6];
+    gemvT6(L21, yv, sv);
+    gemvT6(Lb, yv, tv);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      lds[(L_P + i) * LW] = conv ? T(0) : -x0[i];
-      lds[(L_P + 6 + i) * LW] = conv ? T(0) : -x1[i];
-      lds[(L_P + 12 + i) * LW] = conv ? T(0) : -x2[i];
+      lds[(TS + i) * LW] = sv[i];
+      lds[(T2 + i) * LW] = tv[i];
+      lds[(L_P + 12 + i) * LW] = conv ? T(0) : -yv[i];
     }
   }
-  __syncthreads();
+  TGR_STAMP(16); __syncthreads(); TGR_STAMP(17);
+  // ---- stage 5: x1 (wave 1)
+  if (wid == 1) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) yv[i] -= lds[(TS + i) * LW];
+    bsolve6(La, yv);  // x1
+    T tv[6];
+    gemvT6(Lb, yv, tv);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      lds[(T1 + i) * LW] = tv[i];
+      lds[(L_P + 6 + i) * LW] = conv ? T(0) : -yv[i];
+    }
+  }
+  TGR_STAMP(18); __syncthreads(); TGR_STAMP(19);
+  // ---- stage 6: x0 (wave 0)
+  if (wid == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) yv[i] -= lds[(T1 + i) * LW] + lds[(T2 + i) * LW];
+    bsolve6(La, yv);
+#pragma unroll
+    for (int i = 0; i < 6; i++) lds[(L_P + i) * LW] = conv ? T(0) : -yv[i];
+  }
+  TGR_STAMP(20); __syncthreads(); TGR_STAMP(21);
 }
 
 // ---- line search.  Along a + alpha p every contact row is jar0 + alpha q, so the cone cost of a slot depends on alpha only
@@ -1052,12 +1157,15 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
   if (last) lag.overflow = dropped;
 
   // ---- Newton on  1/2 (a-a0)^T M (a-a0) + sum_c s_c( J (a + B v) + c0 n )
-  // start from last sub-step's solution where there are contacts, from a0 otherwise (the optimum is unique)
 #pragma unroll
   for (int b = 0; b < 3; b++) {
     V3<T> l0 = ld3<T, LW>(lds, L_A0 + 6 * b), a0 = ld3<T, LW>(lds, L_A0 + 6 * b + 3);
-    st3<T, LW>(lds, L_A + 6 * b, sel(any_contact, S.al[b], l0));
-    st3<T, LW>(lds, L_A + 6 * b + 3, sel(any_contact, S.aa[b], a0));
+    // Start every solve from the unconstrained acceleration.  The optimum is unique, so this changes nothing but the
+    // path: measured on MI355X it needs fewer line-search evaluations in the slowest lane of a block than mujoco's
+    // "better of warm start and a0" (the 1.9 ms contact time constant makes last sub-step's solution a poor guess).
+    const bool warm = P.warm_start && any_contact;
+    st3<T, LW>(lds, L_A + 6 * b, sel(warm, S.al[b], l0));
+    st3<T, LW>(lds, L_A + 6 * b + 3, sel(warm, S.aa[b], a0));
   }
   const T scale = rcp_((T(3) * P.mass + T(2) * P.Ixx + P.Izz) * T(1.0 / 6.0) * T(18));
   bool conv = !any_contact;
@@ -1074,7 +1182,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
     conv = conv || !(scale * sqrt_(gn) >= P.tol);
     if (__all(conv) || it >= P.max_iter) break;
     n_it++;
-    newton_direction<T, LW>(lds, wid, cpl, conv);
+    newton_direction<T, LW>(lds, wid, cpl, conv, lag);
     TGR_STAMP(2);
     // Gauss part of the line derivative  phi_g'(alpha) = g1 + alpha g2 ;  d0 = G.P  (per-bar partials, then summed)
     if (wid < 3) {
@@ -1122,10 +1230,15 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
         }
       }
     }
+#ifdef TGR_DEBUG_ENV
+    if (wid == 0 && (int)(blockIdx.x * LW + (threadIdx.x & 63)) == TGR_DEBUG_ENV)
+      printf("it %d cpl %u gn %.4e d0 %.4e g1 %.3e g2 %.3e alpha %.5f conv %d P0 %.4e P6 %.4e P12 %.4e\n", it, cpl, (double)gn, (double)d0, (double)g1, (double)g2,
+             (double)alpha, (int)conv, (double)lds[L_P * LW], (double)lds[(L_P + 6) * LW], (double)lds[(L_P + 12) * LW]);
+#endif
     TGR_STAMP(4);
     if (wid < 3) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) lds[(L_A + 6 * wid + i) * LW] += alpha * lds[(L_P + 6 * wid + i) * LW];
+      for (int i = 0; i < 6; i++) { T pi = lds[(L_P + 6 * wid + i) * LW]; if (alpha != T(0)) lds[(L_A + 6 * wid + i) * LW] += alpha * pi; }
     }
     __syncthreads();
   }

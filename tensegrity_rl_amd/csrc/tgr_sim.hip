@@ -528,7 +528,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
   Lag<T> lag;
   lag.cfrc_absmax = T(0); lag.cfrc_clip_sq = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
 #ifdef TGR_STAMPS
-  for (int i = 0; i < 8; i++) lag.stamp[i] = 0;
+  for (int i = 0; i < 32; i++) lag.stamp[i] = 0;
   lag.t_last = clock64();
 #endif
 #pragma unroll 1
@@ -536,7 +536,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
 
 #ifdef TGR_STAMPS
   { long long _t = clock64(); lag.stamp[5] += _t - lag.t_last; lag.t_last = _t; }
-  if (lane == 0 && blockIdx.x < 64) for (int i = 0; i < 8; i++) atomicAdd(&k.counters[8 + wid * 8 + i], (unsigned long long)lag.stamp[i]);
+  if (lane == 0 && blockIdx.x < 64) for (int i = 0; i < 32; i++) atomicAdd(&k.counters[8 + wid * 32 + i], (unsigned long long)lag.stamp[i]);
 #endif
   const bool w0 = wid == 0;  // one wave owns every global store
   if (lane == 0 && w0) {
@@ -872,6 +872,7 @@ extern "C" int tgr_default_config(tgr_config* c, int env_kind, int desired_actio
   c->waypt_angle_range[0] = -PI / 6; c->waypt_angle_range[1] = PI / 6;
   c->ditch_reward_max = 300; c->ditch_reward_stdev = 0.15; c->waypt_reward_amplitude = 100; c->waypt_reward_stdev = 0.10;
   c->yaw_reward_weight = 1;
+  c->solver_warm_start = 0;
   return TGR_OK;
 }
 
@@ -912,6 +913,7 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   P.max_iter = c.solver_iterations > 0 ? c.solver_iterations : (sizeof(T) == 4 ? 8 : 40);
   P.ls_iter = sizeof(T) == 4 ? 6 : 50;
   P.skip_clamped = c.actuator_deriv_skip_clamped;
+  P.warm_start = c.solver_warm_start;
   EnvCfg<T>& E = k.E;
   E.env_kind = c.env_kind; E.action = c.desired_action; E.terminate_when_unhealthy = c.terminate_when_unhealthy;
   E.use_contact_forces = c.use_contact_forces; E.use_cap_velocity = c.use_cap_velocity; E.is_test = c.is_test;
@@ -976,8 +978,8 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   HIP_TRY(h, hipMalloc((void**)&h->rlist, sizeof(int) * m));
   HIP_TRY(h, hipMalloc((void**)&h->doneflag, m));
   HIP_TRY(h, hipMemset(h->doneflag, 0, m));
-  HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 64));
-  HIP_TRY(h, hipMemset(h->counters, 0, sizeof(unsigned long long) * 64));
+  HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 160));
+  HIP_TRY(h, hipMemset(h->counters, 0, sizeof(unsigned long long) * 160));
   return TGR_OK;
 }
 
@@ -1013,8 +1015,8 @@ extern "C" int tgr_stats(tgr_handle* h, uint64_t out[8]) {
   if (!h || !out) return TGR_ERR_INVALID;
   unsigned long long tmp[8];
 #ifdef TGR_STAMPS
-  { unsigned long long t2[64]; (void)hipDeviceSynchronize(); (void)hipMemcpy(t2, h->counters, sizeof(t2), hipMemcpyDeviceToHost);
-    for (int w = 0; w < 4; w++) { printf("wave %d cycles:", w); for (int i = 0; i < 8; i++) printf(" %12llu", t2[8 + w * 8 + i]); printf("\n"); } }
+  { unsigned long long t2[160]; (void)hipDeviceSynchronize(); (void)hipMemcpy(t2, h->counters, sizeof(t2), hipMemcpyDeviceToHost);
+    for (int w = 0; w < 4; w++) { printf("wave %d Mcycles:", w); for (int i = 0; i < 32; i++) printf(" %6llu", t2[8 + w * 32 + i] / 1000000ull); printf("\n"); } }
 #endif
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipDeviceSynchronize());

@@ -25,7 +25,7 @@ def qpos_close(a, b, atol):
 
 
 def load_cases(golden_dir):
-    return sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "helpers" not in f)
+    return sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "helpers" not in f and not os.path.basename(f).startswith("policy_"))
 
 
 def cfg_from_fixture(O, g):
