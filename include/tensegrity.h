@@ -53,14 +53,18 @@ extern "C" {
 #define TGR_NQ 21
 #define TGR_NV 18
 #define TGR_NU 6
-#define TGR_INFO_K 16
+#define TGR_INFO_K 26
 /* info row layout (float/double [N][TGR_INFO_K]); the first ten are the reference's info dict
- * (tensegrity_env.py:388-400), then tr_env's waypt/oripoint, then Monitor-style episode stats */
+ * (tensegrity_env.py:388-400), then tr_env's waypt/oripoint (tr_env.py:509-510), Monitor-style episode stats,
+ * tr_env's info["tendon_length"] (tr_env.py:506) and the bar-bar contact force the reference's test harness logs
+ * (run.py:149-155: sum over contacts between two bars of |mj_contactForce[0:3]|) */
 enum {
   TGR_INFO_REWARD_FORWARD = 0, TGR_INFO_REWARD_CTRL, TGR_INFO_REWARD_SURVIVE, TGR_INFO_X_POSITION,
   TGR_INFO_Y_POSITION, TGR_INFO_PSI, TGR_INFO_DISTANCE, TGR_INFO_X_VELOCITY, TGR_INFO_Y_VELOCITY,
   TGR_INFO_FORWARD_REWARD, TGR_INFO_WAYPT_X, TGR_INFO_WAYPT_Y, TGR_INFO_ORI_X, TGR_INFO_ORI_Y,
-  TGR_INFO_EP_RETURN, TGR_INFO_EP_LENGTH
+  TGR_INFO_EP_RETURN, TGR_INFO_EP_LENGTH,
+  TGR_INFO_TENDON_LENGTH = 16, /* ..24 */
+  TGR_INFO_BAR_CONTACT = 25
 };
 
 typedef struct tgr_config {

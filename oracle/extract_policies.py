@@ -11,14 +11,18 @@ import zipfile
 import numpy as np
 import torch
 
-REF = "/root/reference/best_models_pretrained"
+REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
-for name, path in (("forward", "forward/SAC_5500000.zip"), ("backward", "backward/SAC_4700000.zip")):
+# (fixture name, checkpoint, action box the checkpoint's JSON `data` member records)
+#   forward/backward: tensegrity_env, 39-dim obs, trained with the older [-0.45, -0.15] box (README.md:30)
+#   tracking: tr_env "tracking", 48-dim obs, trained with the current XML's [-0.45, 0.15] box
+for name, path, low, high in (("forward", "best_models_pretrained/forward/SAC_5500000.zip", -0.45, -0.15),
+                              ("backward", "best_models_pretrained/backward/SAC_4700000.zip", -0.45, -0.15),
+                              ("tracking", "models_tracking/SAC_16525000.zip", -0.45, 0.15)):
     z = zipfile.ZipFile(os.path.join(REF, path))
     sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
     arrs = {k.replace("actor.", "").replace(".", "_"): v.numpy().astype(np.float32) for k, v in sd.items()
-            if k.startswith("actor.latent_pi") or k.startswith("actor.mu")}
-    # action box the checkpoint was trained with (README.md:30 / SURVEY.md App. C.8): [-0.45, -0.15]
-    np.savez_compressed(os.path.join(OUT, f"policy_{name}.npz"), low=np.float32(-0.45), high=np.float32(-0.15), **arrs)
+            if k.startswith("actor.latent_pi") or k.startswith("actor.mu") or k.startswith("actor.log_std")}
+    np.savez_compressed(os.path.join(OUT, f"policy_{name}.npz"), low=np.float32(low), high=np.float32(high), **arrs)
     print(name, {k: v.shape for k, v in arrs.items()})

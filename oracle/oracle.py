@@ -10,14 +10,14 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-NQ, NV, NU, NTEN, NBAR, MAXCON, RING, INFO_K = 21, 18, 6, 9, 3, 32, 32, 16
+NQ, NV, NU, NTEN, NBAR, MAXCON, RING, INFO_K = 21, 18, 6, 9, 3, 32, 32, 26
 
 ENV_TENSEGRITY, ENV_TR = 0, 1
 ACT_STRAIGHT, ACT_TURN, ACT_AIMING, ACT_TRACKING, ACT_VEL_TRACK = range(5)
 ACTIONS = {"straight": 0, "turn": 1, "aiming": 2, "tracking": 3, "vel_track": 4}
 INFO_KEYS = ["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
              "distance_from_origin", "x_velocity", "y_velocity", "forward_reward", "waypt_x", "waypt_y",
-             "ori_x", "ori_y", "ep_return", "ep_length"]
+             "ori_x", "ori_y", "ep_return", "ep_length"] + [f"tendon_length_{i}" for i in range(9)] + ["bar_contact"]
 
 d = C.c_double
 

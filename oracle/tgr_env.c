@@ -345,6 +345,13 @@ static void env_step_inner(tgo_env* e, const double* action, double* reward, int
     info[TGO_INFO_FORWARD_REWARD] = forward_reward;
     info[TGO_INFO_WAYPT_X] = e->waypt[0]; info[TGO_INFO_WAYPT_Y] = e->waypt[1];
     info[TGO_INFO_ORI_X] = e->oripoint[0]; info[TGO_INFO_ORI_Y] = e->oripoint[1];
+    for (int t = 0; t < TGO_NTEN; t++) info[TGO_INFO_TENDON_LENGTH + t] = d->ten_length[t]; /* tr_env.py:506 */
+    double bar = 0; /* run.py:149-155: contacts with neither geom the floor, |mj_contactForce[0:3]| summed */
+    for (int ci = 0; ci < d->ncon; ci++) {
+      const tgo_contact* k = &d->con[ci];
+      if (k->body1 >= 0 && k->body2 >= 0) bar += sqrt(k->force[0] * k->force[0] + k->force[1] * k->force[1] + k->force[2] * k->force[2]);
+    }
+    info[TGO_INFO_BAR_CONTACT] = bar;
   }
   if (c->use_contact_forces) {
     double s = 0;

@@ -10,7 +10,8 @@ i32, f64, u64 = C.c_int32, C.c_double, C.c_uint64
 ENV_TENSEGRITY, ENV_TR = 0, 1
 ACTIONS = {"straight": 0, "turn": 1, "aiming": 2, "tracking": 3, "vel_track": 4}
 PRECISION = {"f32": 0, "f64": 1, "float32": 0, "float64": 1}
-INFO_K, AUX_K, NQ, NV, NU = 16, 17, 21, 18, 6
+INFO_K, AUX_K, NQ, NV, NU = 26, 17, 21, 18, 6
+INFO_TENDON_LENGTH, INFO_BAR_CONTACT = 16, 25
 INFO_KEYS = ["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
              "distance_from_origin", "x_velocity", "y_velocity", "forward_reward"]
 AUX_KEYS = ["xy_lag_x", "xy_lag_y", "psi_lag", "reset_psi", "ep_return", "step_num", "elapsed", "episode", "ring_len",

@@ -121,6 +121,7 @@ template <typename T> struct Lag {
   T tenL[9];
   T cfrc_absmax;
   T cfrc_clip_sq;  // sum over cfrc_ext of clip(., contact_force_range)^2
+  T bar_contact;   // sum over bar-bar contacts of |linear contact force| (what run.py:149-155 logs)
   int overflow;
   int n_it, n_ls;  // solver work of this control period (wave-uniform)
   int n_unconv;    // sub-steps this lane left the solver at the iteration cap
@@ -742,6 +743,7 @@ TGR_DEV T newton_assemble(const Params<T>& P, T* lds, int wid, unsigned cpl, T& 
     lds[(L_RED + 3 + b) * LW] = max_(max_(max_(abs_(fl.x), abs_(fl.y)), abs_(fl.z)), max_(max_(abs_(fa.x), abs_(fa.y)), abs_(fa.z)));
   } else {
     // wave 3: off-diagonal blocks
+    T barsum = T(0);
 #pragma unroll 1
     for (int p = 0; p < 3; p++) {
       if (!((cpl >> p) & 1u)) continue;
@@ -761,9 +763,11 @@ TGR_DEV T newton_assemble(const Params<T>& P, T* lds, int wid, unsigned cpl, T& 
         V3<T> ja = yaB - yaA;
         Cone<T> o = cone_eval(P, c, jl, ja);
         cross_block_add(O, o, c.n, c.rB, c.rA);
+        barsum += sqrt_(dot(o.fl, o.fl));
       }
       st36<T, LW>(lds, pair_O(p), O);
     }
+    lds[(L_RED + 31) * LW] = barsum;
   }
   __syncthreads();
   T gn = lds[L_RED * LW] + lds[(L_RED + 1) * LW] + lds[(L_RED + 2) * LW];
@@ -1249,6 +1253,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
 #pragma unroll
     for (int i = 0; i < 18; i++) { T v = clamp_(lds[(L_FC + i) * LW], P.cf_lo, P.cf_hi); sq += v * v; }
     lag.cfrc_clip_sq = sq;
+    lag.bar_contact = lds[(L_RED + 31) * LW];
   }
   lag.n_it += n_it; lag.n_ls += n_ls; lag.n_unconv += conv ? 0 : 1;
 #pragma unroll

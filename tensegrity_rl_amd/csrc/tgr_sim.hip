@@ -610,6 +610,9 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
         ip[TGR_INFO_WAYPT_X] = ms.waypt[0]; ip[TGR_INFO_WAYPT_Y] = ms.waypt[1];
         ip[TGR_INFO_ORI_X] = ms.ori[0]; ip[TGR_INFO_ORI_Y] = ms.ori[1];
         ip[TGR_INFO_EP_RETURN] = ep_ret; ip[TGR_INFO_EP_LENGTH] = T(elapsed);
+#pragma unroll
+        for (int i = 0; i < 9; i++) ip[TGR_INFO_TENDON_LENGTH + i] = lag.tenL[i];
+        ip[TGR_INFO_BAR_CONTACT] = lag.bar_contact;
       }
       if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
       if (done && k.terminal_obs) {

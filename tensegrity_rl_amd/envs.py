@@ -49,6 +49,8 @@ class _GymEnvBase:
         if self._env_id == "tr_env-v0":
             d["waypt"] = ih[10:12].copy()
             d["oripoint"] = ih[12:14].copy()
+            d["tendon_length"] = ih[N.INFO_TENDON_LENGTH:N.INFO_TENDON_LENGTH + 9].copy()
+        d["total_bar_contact"] = float(ih[N.INFO_BAR_CONTACT])  # what run.py:149-155 computes from data.contact
         return (obs.cpu().numpy().astype(np.float64)[0], float(rew.cpu().numpy()[0]), bool(term.cpu().numpy()[0]),
                 bool(trunc.cpu().numpy()[0]), d)
 

@@ -38,7 +38,9 @@ def _run(oracle, kind, action, prec, n, steps, seed=0, **kw):
         q2, v2, _, _, _ = ob.get_state()
         rows.append(dict(qpos=rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3), qvel=rel_env(st["qvel"] - v2, v2, 1e-2),
                          obs=np.abs(g_obs - o_obs).max(axis=1), rew=np.abs(g_rew - o_rew), term=(g_term.astype(bool) != o_term),
-                         info=np.abs(g_info[:, :10] - o_info[:, :10]).max(axis=1), oterm=o_term))
+                         info=np.abs(g_info[:, :10] - o_info[:, :10]).max(axis=1), oterm=o_term,
+                         ten=np.abs(g_info[:, 16:25] - o_info[:, 16:25]).max(axis=1),
+                         bar=np.abs(g_info[:, 25] - o_info[:, 25]) / np.maximum(1.0, np.abs(o_info[:, 25])), obar=o_info[:, 25]))
     stats = env.stats()
     env.close(); ob.close()
     return rows, stats
@@ -54,7 +56,9 @@ def test_fp64_matches_oracle(oracle, kind, action):
         assert r["qvel"].max() < 1e-5, r["qvel"].max()
         assert r["obs"].max() < 1e-5 and r["rew"].max() < 1e-6 and r["info"].max() < 1e-5
         assert not r["term"].any()
+        assert r["ten"].max() < 1e-7 and r["bar"].max() < 1e-4, (r["ten"].max(), r["bar"].max())  # info["tendon_length"], run.py's bar-bar force
     assert stats["dropped_contacts"] == 0
+    assert max(r["obar"].max() for r in rows) > 1.0  # the random actions do produce bar-bar contacts to compare
 
 
 def test_fp64_contact_cost_matches_oracle(oracle):

@@ -145,3 +145,39 @@ def test_mujoco_trained_policies_move_the_right_way(oracle, golden_dir, name, di
     along = d[:, 0] * np.cos(psi0) + d[:, 1] * np.sin(psi0)
     assert int(np.sum(direction * along > 0.05)) >= need, along
     ob.close()
+
+
+def test_mujoco_trained_tracking_policy_closes_in_on_its_waypoint(oracle, golden_dir):
+    """Behavioural anchor on the *current* XML: models_tracking/SAC_16525000.zip (tr_env "tracking", 48-dim obs, action box
+    [-0.45, 0.15], 16.5 M MuJoCo steps) rolled deterministically in this restatement.  is_test puts the waypoint 3 m
+    straight ahead of the reset heading (tr_env.py:833-838).  In this simulator the policy never trips the 1500 N rule
+    (tr_env.py:480) in 300 control periods and walks at least three of eight robots more than a metre towards the waypoint,
+    one of them onto it.  Not parity (a gait is chaotic and pose dependent) but a simulator with wrong tendon, actuator
+    or contact scaling does not get a MuJoCo-trained gait to walk at all."""
+    import os
+    O = oracle
+    g = np.load(os.path.join(golden_dir, "policy_tracking.npz"))
+    W = [g[k].astype(np.float64) for k in ("latent_pi_0_weight", "latent_pi_2_weight", "mu_weight")]
+    B = [g[k].astype(np.float64) for k in ("latent_pi_0_bias", "latent_pi_2_bias", "mu_bias")]
+    lo, hi = float(g["low"]), float(g["high"])
+    n = 8
+    ob = O.OracleBatch(O.make_cfg("tr_env", "tracking", is_test=1), n, seed=1234)
+    obs = ob.reset()
+    d0 = dmin = None
+    wrench_trip = np.zeros(n, bool)
+    for t in range(300):
+        h = obs
+        for i in range(2):
+            h = np.maximum(h @ W[i].T + B[i], 0)
+        a = (lo + 0.5 * (np.tanh(h @ W[2].T + B[2]) + 1) * (hi - lo)).astype(np.float32)
+        obs, rew, term, trunc, tobs, info = ob.step(a, auto_reset=False)
+        d = np.linalg.norm(info[:, 10:12] - info[:, 3:5], axis=1)
+        if d0 is None:
+            d0, dmin = d.copy(), d.copy()
+        dmin = np.minimum(dmin, d)
+        for i in range(n):
+            wrench_trip[i] |= bool(np.abs(O.arr(ob.env(i).data.cfrc_ext)).max() > 1500)
+    assert np.all(np.abs(d0 - 3.0) < 0.1)
+    assert not wrench_trip.any()
+    assert int(np.sum(d0 - dmin > 1.0)) >= 3 and dmin.min() < 0.5, (d0 - dmin)
+    ob.close()
