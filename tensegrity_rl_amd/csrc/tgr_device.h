@@ -746,11 +746,14 @@ TGR_DEV T newton_assemble(const Params<T>& P, T* lds, int wid, unsigned cpl, T& 
     T barsum = T(0);
 #pragma unroll 1
     for (int p = 0; p < 3; p++) {
-      if (!((cpl >> p) & 1u)) continue;
-      const int A = pair_A(p), B = pair_B(p);
       T O[36];
 #pragma unroll
       for (int i = 0; i < 36; i++) O[i] = T(0);
+      if (!((cpl >> p) & 1u)) {
+        if (cpl != 0u) st36<T, LW>(lds, pair_O(p), O);  // the dense factorisation reads every block
+        continue;
+      }
+      const int A = pair_A(p), B = pair_B(p);
       V3<T> ylA = ld3<T, LW>(lds, L_A + 6 * A) + ld3<T, LW>(lds, L_BV + 6 * A);
       V3<T> yaA = ld3<T, LW>(lds, L_A + 6 * A + 3) + ld3<T, LW>(lds, L_BV + 6 * A + 3);
       V3<T> ylB = ld3<T, LW>(lds, L_A + 6 * B) + ld3<T, LW>(lds, L_BV + 6 * B);
@@ -775,35 +778,79 @@ TGR_DEV T newton_assemble(const Params<T>& P, T* lds, int wid, unsigned cpl, T& 
   return gn;
 }
 
-// Blocked Cholesky of the Hessian spread over the waves, with the triangular solves folded into the same pipeline:
-//   L = [[L00,0,0],[L10,L11,0],[L20,L21,L22]],  y = L^-1 G,  x = L^-T y,  P = -x   (P = 0 for converged lanes)
-// Each wave keeps the factors it produced in registers, so the back-substitution needs no block reloads:
-//   wave 0: L00, y0 ........................................... finally x0 = L00^-T (y0 - t1 - t2)
-//   wave 1: L10 = O10 L00^-T, L11, y1 .......................... x1 = L11^-T (y1 - s),  t1 = L10^T x1
-//   wave 2: L20 = O20 L00^-T, L22, y2, x2 ...................... s = L21^T x2,  t2 = L20^T x2
-//   wave 3: L21 = (O21 - L20 L10^T) L11^-T
-template <typename T> TGR_DEV void gemvT6(const T* O, const T* x, T* y) {  // y = O^T x
+// Newton direction  P = -H^-1 G.
+// The Hessian is 18x18: three 6x6 diagonal blocks (packed lower, H_D) and three 6x6 off-diagonal blocks (row = dof of
+// the higher bar, H_O*).  Under contact-rich rollouts every block of 64 envs has all three bar pairs coupled in >99.9 %
+// of the sub-steps (measured), so the coupled case is one dense factorisation.  A Cholesky is a dependency chain: spread
+// over the four waves as a blocked pipeline it spent more time in hand-offs through LDS and barriers than in arithmetic
+// (12.4 k cycles per call).  Here ONE wave does it register-resident, as row pairs so that the updates issue as
+// v_pk_fma_f32 (two fp32 FMAs per lane per instruction): ~1.3 k instructions, one barrier.
+// Storage: column k of the lower triangle as row pairs p = k/2 .. 8 (the entry above the diagonal inside a pair is
+// don't-care).  Pivots are floored relative to the original diagonal: a pivot that loses positivity to rounding must cost
+// accuracy of one Newton direction (the line search copes), never produce inf.
+template <typename T> struct Pk2 { typedef T type __attribute__((ext_vector_type(2))); };
+constexpr __host__ __device__ int dcoff(int k) { int o = 0; for (int c = 0; c < k; c++) o += 9 - c / 2; return o; }
+constexpr __host__ __device__ int dcidx(int k, int p) { return dcoff(k) + (p - k / 2); }
+constexpr int DENSE_NC = dcoff(18);  // 90 pairs
+// LDS slot of Hessian entry (i, k), i >= k
+constexpr __host__ __device__ int hslot(int i, int k) {
+  const int bi = i / 6, bk = k / 6, r = i % 6, c = k % 6;
+  return bi == bk ? H_D(bi) + tri(r, c) : (bi == 1 ? H_O10 : (bk == 0 ? H_O20 : H_O21)) + r * 6 + c;
+}
+template <typename T> TGR_DEV void dense_chol18(typename Pk2<T>::type* C, T* dinv) {
+  typedef typename Pk2<T>::type T2;
+  const T rel = sizeof(T) == 4 ? T(1e-6) : T(1e-13);
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    T s = T(0);
+  for (int j = 0; j < 18; j++) {
+    const int pj = j / 2;
+    T d = (j & 1) ? C[dcidx(j, pj)].y : C[dcidx(j, pj)].x;
+    d = max_(d, max_(rel * abs_(dinv[j]), T(1e-30)));
+    const T il = rsqrt_(d);
+    dinv[j] = il;
+    const T2 ilv = {il, il};
 #pragma unroll
-    for (int k = 0; k < 6; k++) s += O[k * 6 + i] * x[k];
-    y[i] = s;
+    for (int p = pj; p < 9; p++) C[dcidx(j, p)] = C[dcidx(j, p)] * ilv;
+#pragma unroll
+    for (int k = j + 1; k < 18; k++) {
+      const int pk = k / 2;
+      const T lkj = (k & 1) ? C[dcidx(j, pk)].y : C[dcidx(j, pk)].x;
+      const T2 lv = {lkj, lkj};
+#pragma unroll
+      for (int p = pk; p < 9; p++) C[dcidx(k, p)] = C[dcidx(k, p)] - C[dcidx(j, p)] * lv;
+    }
+  }
+}
+// x (9 row pairs) <- L^-T L^-1 x ; L = scaled columns of C, 1/L_jj in dinv
+template <typename T> TGR_DEV void dense_solve18(const typename Pk2<T>::type* C, const T* dinv, typename Pk2<T>::type* x) {
+  typedef typename Pk2<T>::type T2;
+#pragma unroll
+  for (int j = 0; j < 18; j++) {  // forward, column oriented
+    const int pj = j / 2;
+    const T xj = ((j & 1) ? x[pj].y : x[pj].x) * dinv[j];
+    if (j & 1) x[pj].y = xj; else x[pj].x = xj;
+    if (!(j & 1)) x[pj].y -= C[dcidx(j, pj)].y * xj;  // partner row of the same pair
+    const T2 xv = {xj, xj};
+#pragma unroll
+    for (int p = pj + 1; p < 9; p++) x[p] = x[p] - C[dcidx(j, p)] * xv;
+  }
+#pragma unroll
+  for (int i = 17; i >= 0; i--) {  // backward, row oriented
+    const int pi = i / 2;
+    T2 acc = {T(0), T(0)};
+#pragma unroll
+    for (int p = pi + 1; p < 9; p++) acc = acc + C[dcidx(i, p)] * x[p];
+    T s = ((i & 1) ? x[pi].y : x[pi].x) - (acc.x + acc.y);
+    if (!(i & 1)) s -= C[dcidx(i, pi)].y * x[pi].y;
+    s *= dinv[i];
+    if (i & 1) x[pi].y = s; else x[pi].x = s;
   }
 }
 template <typename T, int LW> TGR_DEV void newton_direction(T* lds, int wid, unsigned cpl, bool conv, Lag<T>& lag) {
-  const bool c10 = cpl & 1u, c20 = cpl & 2u, c21in = cpl & 4u;
-  const bool c21 = c21in || (c10 && c20);  // fill-in
-  constexpr int TS = L_RED + 32, T1 = L_RED + 38, T2 = L_RED + 44;  // s, t1, t2 exchange slots
-  T La[21];   // wave 0: L00   wave 1: L11   wave 2: L22
-  T Lb[36];   // wave 1: L10   wave 2: L20
-  T yv[6];    // this wave's y block
-  T dref[6];  // diagonal of this wave's block before the Schur updates
-#pragma unroll
-  for (int i = 0; i < 36; i++) Lb[i] = T(0);
+  typedef typename Pk2<T>::type T2;
   if (cpl == 0u) {
-    // no lane of the block couples two bars: three independent 6x6 solves
+    // no lane of the block couples two bars: three independent 6x6 solves, one per wave
     if (wid < 3) {
+      T La[21], yv[6], dref[6];
       ld21<T, LW>(lds, H_D(wid), La);
       diag6(La, dref);
       chol6(La, dref);
@@ -817,126 +864,35 @@ template <typename T, int LW> TGR_DEV void newton_direction(T* lds, int wid, uns
     TGR_STAMP(8); __syncthreads(); TGR_STAMP(9);
     return;
   }
-  // ---- stage 1: column 0
   if (wid == 0) {
-    ld21<T, LW>(lds, H_D(0), La);
-    diag6(La, dref);
-    chol6(La, dref);
-    st21<T, LW>(lds, H_D(0), La);
+    T2 C[DENSE_NC];
+    T dinv[18];
+    T2 x[9];
 #pragma unroll
-    for (int i = 0; i < 6; i++) yv[i] = lds[(L_G + i) * LW];
-    fsolve6(La, yv);
+    for (int k = 0; k < 18; k++)
 #pragma unroll
-    for (int i = 0; i < 6; i++) lds[(L_P + i) * LW] = yv[i];  // y0 parked in P's slots
+      for (int p = k / 2; p < 9; p++) {
+        const int i0 = 2 * p, i1 = 2 * p + 1;
+        const T a = i0 >= k ? lds[hslot(i0, k) * LW] : T(0);
+        C[dcidx(k, p)] = T2{a, lds[hslot(i1, k) * LW]};
+      }
+#pragma unroll
+    for (int j = 0; j < 18; j++) dinv[j] = lds[hslot(j, j) * LW];
+#pragma unroll
+    for (int p = 0; p < 9; p++) x[p] = T2{lds[(L_G + 2 * p) * LW], lds[(L_G + 2 * p + 1) * LW]};
+    // a lone wave cannot hide LDS latency behind other waves: have all ~100 reads in flight before the first FMA
+    __builtin_amdgcn_sched_barrier(0);
+    dense_chol18<T>(C, dinv);
+    dense_solve18<T>(C, dinv, x);
+#pragma unroll
+    for (int p = 0; p < 9; p++) {
+      lds[(L_P + 2 * p) * LW] = conv ? T(0) : -x[p].x;
+      lds[(L_P + 2 * p + 1) * LW] = conv ? T(0) : -x[p].y;
+    }
   }
   TGR_STAMP(10); __syncthreads(); TGR_STAMP(11);
-  // ---- stage 2: L10, L11, y1 (wave 1) ; L20, trailing update of D2, partial y2 (wave 2)
-  if (wid == 1) {
-    T y0[6];
-    if (c10) {
-      T L0[21];
-      ld21<T, LW>(lds, H_D(0), L0);
-      ld36<T, LW>(lds, H_O10, Lb);
-      trsm6(Lb, L0);
-      st36<T, LW>(lds, H_O10, Lb);
-#pragma unroll
-      for (int i = 0; i < 6; i++) y0[i] = lds[(L_P + i) * LW];
-    }
-    ld21<T, LW>(lds, H_D(1), La);
-    diag6(La, dref);
-#pragma unroll
-    for (int i = 0; i < 6; i++) yv[i] = lds[(L_G + 6 + i) * LW];
-    if (c10) { syrk6(La, Lb); gemv_sub(Lb, y0, yv); }
-    chol6(La, dref);
-    st21<T, LW>(lds, H_D(1), La);
-    fsolve6(La, yv);
-#pragma unroll
-    for (int i = 0; i < 6; i++) lds[(L_P + 6 + i) * LW] = yv[i];  // y1
-  }
-  if (wid == 2) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) yv[i] = lds[(L_G + 12 + i) * LW];
-    ld21<T, LW>(lds, H_D(2), La);
-    if (c20) {
-      T L0[21], y0[6];
-      ld21<T, LW>(lds, H_D(0), L0);
-      ld36<T, LW>(lds, H_O20, Lb);
-      trsm6(Lb, L0);
-      st36<T, LW>(lds, H_O20, Lb);
-#pragma unroll
-      for (int i = 0; i < 6; i++) y0[i] = lds[(L_P + i) * LW];
-      syrk6(La, Lb);
-      gemv_sub(Lb, y0, yv);
-    }
-  }
-  TGR_STAMP(12); __syncthreads(); TGR_STAMP(13);
-  // ---- stage 3: L21 (wave 3)
-  if (c21) {
-    if (wid == 3) {
-      T O21[36], L1[21];
-      if (c21in) ld36<T, LW>(lds, H_O21, O21);
-      else {
-#pragma unroll
-        for (int i = 0; i < 36; i++) O21[i] = T(0);
-      }
-      if (c10 && c20) { T Oa[36], Ob[36]; ld36<T, LW>(lds, H_O20, Oa); ld36<T, LW>(lds, H_O10, Ob); gemm6(O21, Oa, Ob); }
-      ld21<T, LW>(lds, H_D(1), L1);
-      trsm6(O21, L1);
-      st36<T, LW>(lds, H_O21, O21);
-    }
-    TGR_STAMP(14); __syncthreads(); TGR_STAMP(15);
-  }
-  // ---- stage 4: column 2, x2, and what the other back-substitutions need from it (wave 2)
-  if (wid == 2) {
-    T L21[36];
-#pragma unroll
-    for (int i = 0; i < 36; i++) L21[i] = T(0);
-    if (c21) {
-      T y1[6];
-      ld36<T, LW>(lds, H_O21, L21);
-#pragma unroll
-      for (int i = 0; i < 6; i++) y1[i] = lds[(L_P + 6 + i) * LW];
-      syrk6(La, L21);
-      gemv_sub(L21, y1, yv);
-    }
-    chol6(La, dref);
-    fsolve6(La, yv);
-    bsolve6(La, yv);  // x2
-    T sv[6], tv[6];
-    gemvT6(L21, yv, sv);
-    gemvT6(Lb, yv, tv);
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      lds[(TS + i) * LW] = sv[i];
-      lds[(T2 + i) * LW] = tv[i];
-      lds[(L_P + 12 + i) * LW] = conv ? T(0) : -yv[i];
-    }
-  }
-  TGR_STAMP(16); __syncthreads(); TGR_STAMP(17);
-  // ---- stage 5: x1 (wave 1)
-  if (wid == 1) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) yv[i] -= lds[(TS + i) * LW];
-    bsolve6(La, yv);  // x1
-    T tv[6];
-    gemvT6(Lb, yv, tv);
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      lds[(T1 + i) * LW] = tv[i];
-      lds[(L_P + 6 + i) * LW] = conv ? T(0) : -yv[i];
-    }
-  }
-  TGR_STAMP(18); __syncthreads(); TGR_STAMP(19);
-  // ---- stage 6: x0 (wave 0)
-  if (wid == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) yv[i] -= lds[(T1 + i) * LW] + lds[(T2 + i) * LW];
-    bsolve6(La, yv);
-#pragma unroll
-    for (int i = 0; i < 6; i++) lds[(L_P + i) * LW] = conv ? T(0) : -yv[i];
-  }
-  TGR_STAMP(20); __syncthreads(); TGR_STAMP(21);
 }
+
 
 // ---- line search.  Along a + alpha p every contact row is jar0 + alpha q, so the cone cost of a slot depends on alpha only
 // through ten scalars (norms and projections of jar0 and q).  Each wave reduces its slots to those scalars once per Newton
@@ -1049,6 +1005,91 @@ TGR_DEV void newton_dphi(const Params<T>& P, T* lds, int wid, const LSlot<T>* ls
   for (int w = 0; w < 4; w++) { d1 += lds[(base + 2 * w) * LW]; d2 += lds[(base + 1 + 2 * w) * LW]; }
 }
 
+// base phase of bar B (see substep): kinematic columns, attached tendons, a0, floor caps, bar pair B
+template <typename T, int LW, int B>
+TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* lds, bool last, Lag<T>& lag) {
+  const T im = rcp_(P.mass);
+  st3<T, LW>(lds, L_EZ + 3 * B, R[B].ez);
+  st3<T, LW>(lds, L_X + 3 * B, S.x[B]);
+  st3<T, LW>(lds, L_BV + 6 * B, P.B * S.v[B]);
+  st3<T, LW>(lds, L_BV + 6 * B + 3, P.B * S.w[B]);
+  V3<T> F = mk(T(0), T(0), -P.mass * P.grav);
+  // gyroscopic: -w x (I w) = -(Izz-Ixx)(z.w)(w x z)
+  V3<T> Tq = (-(P.Izz - P.Ixx) * dot(R[B].ez, S.w[B])) * cross(S.w[B], R[B].ez);
+#pragma unroll
+  for (int t = 0; t < 9; t++) {
+    const int ba = Tab::TEN[t][0], sa = Tab::TEN[t][1], bb = Tab::TEN[t][2], sb = Tab::TEN[t][3];
+    const bool mine = (ba == B) || (bb == B);
+    // the observation and tr_env's control cost need all nine lengths: in the last sub-step also the three foreign ones
+    if (!mine && !last) continue;
+    V3<T> ra = rot_apply(R[ba], mk(T(Tab::S[sa][0]) * P.site_off, T(Tab::S[sa][1]) * P.site_off, T(Tab::S[sa][2]) * P.site_z));
+    V3<T> rb = rot_apply(R[bb], mk(T(Tab::S[sb][0]) * P.site_off, T(Tab::S[sb][1]) * P.site_off, T(Tab::S[sb][2]) * P.site_z));
+    V3<T> dif = (S.x[bb] + rb) - (S.x[ba] + ra);
+    T L2 = dot(dif, dif);
+    T iL = rsqrt_(max_(L2, T(1e-30)));
+    T L = L2 * iL;
+    if (last) lag.tenL[t] = L;
+    if (!mine) continue;
+    V3<T> u = iL * dif;
+    V3<T> va = S.v[ba] + cross(S.w[ba], ra), vb = S.v[bb] + cross(S.w[bb], rb);
+    T Ld = dot(u, vb - va);
+    T f, damp;
+    if (t < 6) {
+      T cc = clamp_(S.ctrl[t], P.ctrl_lo, P.ctrl_hi);
+      T fr = P.gain * cc + P.bias0 + P.bias1 * L + P.bias2 * Ld;
+      f = clamp_(fr, P.force_lo, P.force_hi);
+      bool clamped = (f <= P.force_lo) || (f >= P.force_hi);
+      damp = -P.bias2;
+      if (P.skip_clamped && clamped) damp = T(0);
+      // passive part of an actuated tendon (zero in the flat model)
+      f += -P.ten_k[t] * (L - P.ten_L0[t]) - P.ten_b[t] * Ld;
+      damp += P.ten_b[t];
+    } else {
+      f = -P.ten_k[t] * (L - P.ten_L0[t]) - P.ten_b[t] * Ld;
+      damp = P.ten_b[t];
+    }
+    V3<T> ma = cross(ra, u), mb = cross(rb, u);
+    if (bb == B) { F = F + f * u; Tq = Tq + f * mb; }
+    else { F = F - f * u; Tq = Tq - f * ma; }
+    if (ba == B) {  // one writer per column: the two instantiations may round differently, a race would not be benign
+      st3<T, LW>(lds, L_TEN + 10 * t, u);
+      st3<T, LW>(lds, L_TEN + 10 * t + 3, ma);
+      st3<T, LW>(lds, L_TEN + 10 * t + 6, mb);
+      lds[(L_TEN + 10 * t + 9) * LW] = sqrt_(P.h * damp);
+    }
+  }
+  // unconstrained acceleration; the Newton iteration starts from it.  The optimum is unique, so the start changes nothing
+  // but the path: measured on MI355X it needs fewer line-search evaluations in the slowest lane of a block than mujoco's
+  // "better of warm start and a0" (the 1.9 ms contact time constant makes last sub-step's solution a poor guess).
+  V3<T> l0 = im * F, a0 = inv_inertia(P, R[B].ez, Tq);
+  st3<T, LW>(lds, L_A0 + 6 * B, l0);
+  st3<T, LW>(lds, L_A0 + 6 * B + 3, a0);
+  st3<T, LW>(lds, L_A + 6 * B, l0);
+  st3<T, LW>(lds, L_A + 6 * B + 3, a0);
+  // floor contacts: caps 2B, 2B+1
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    T sg = e == 0 ? P.bar_half : -P.bar_half;
+    V3<T> arm = sg * R[B].ez;
+    T dist = S.x[B].z + arm.z - P.cap_r;
+    Contact<T> c;
+    contact_params(P, dist, 1, c);
+    const int s = L_CF + 6 * (2 * B + e);
+    lds[s * LW] = arm.x; lds[(s + 1) * LW] = arm.y; lds[(s + 2) * LW] = arm.z - (P.cap_r + T(0.5) * dist);
+    lds[(s + 3) * LW] = c.c0; lds[(s + 4) * LW] = c.Dn; lds[(s + 5) * LW] = dist < T(0) ? T(1) : T(0);
+  }
+  // bar pair B = (pA, pB)
+  {
+    constexpr int pA = B == 2 ? 1 : 0, pB = B == 0 ? 1 : 2;
+    Contact<T> c0, c1;
+    int dropped = 0;
+    bar_pair_contacts(P, S.x[pA], R[pA].ez, S.x[pB], R[pB].ez, c0, c1, dropped);
+    store_pair<T, LW>(lds, 2 * B, c0);
+    store_pair<T, LW>(lds, 2 * B + 1, c1);
+    lds[(L_RED + 32 + B) * LW] = T(dropped);
+  }
+}
+
 // ------------------------------------------------------------------ the sub-step
 // lds: this lane's column base (lds_block + lane); needs L_TOTAL slots of pitch LW
 template <typename T, int LW>
@@ -1057,126 +1098,49 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
   TGR_STAMP(7);
   __syncthreads();  // every wave is done with the previous sub-step's columns
   TGR_STAMP(6);
-  // ---- kinematics, tendons -> smooth wrench; Jacobian pieces parked in LDS (all four waves write the same values)
-  {
-    Rot<T> R[3];
+  // ---- base phase, split over the waves (every wave holds the full state S in registers, so nothing has to be
+  // exchanged before the work): wave B = bar B: its kinematic columns, the six tendons attached to it (a tendon is
+  // evaluated by both of its bars' waves; the wave of its first bar writes the Jacobian columns), its unconstrained acceleration, its two
+  // floor caps, and the bar pair with index B.  Wave 3 has nothing to do here.
+  Rot<T> R[3];
+#pragma unroll
+  for (int b = 0; b < 3; b++) { normalize_quat(S.q[b]); R[b] = quat_rot(S.q[b]); }
+  if (last) {
 #pragma unroll
     for (int b = 0; b < 3; b++) {
-      normalize_quat(S.q[b]);
-      R[b] = quat_rot(S.q[b]);
-      st3<T, LW>(lds, L_EZ + 3 * b, R[b].ez);
-      st3<T, LW>(lds, L_X + 3 * b, S.x[b]);
-      st3<T, LW>(lds, L_BV + 6 * b, P.B * S.v[b]);
-      st3<T, LW>(lds, L_BV + 6 * b + 3, P.B * S.w[b]);
-    }
-    if (last) {
+      lag.x[b] = S.x[b];
+      lag.z[b] = R[b].ez;
 #pragma unroll
-      for (int b = 0; b < 3; b++) {
-        lag.x[b] = S.x[b];
-        lag.z[b] = R[b].ez;
-#pragma unroll
-        for (int i = 0; i < 4; i++) lag.q[b][i] = S.q[b][i];
-      }
-    }
-    V3<T> F[3], Tq[3];
-#pragma unroll
-    for (int b = 0; b < 3; b++) {
-      F[b] = mk(T(0), T(0), -P.mass * P.grav);
-      // gyroscopic: -w x (I w) = -(Izz-Ixx)(z.w)(w x z)
-      T zw = dot(R[b].ez, S.w[b]);
-      Tq[b] = (-(P.Izz - P.Ixx) * zw) * cross(S.w[b], R[b].ez);
-    }
-#pragma unroll
-    for (int t = 0; t < 9; t++) {
-      const int ba = Tab::TEN[t][0], sa = Tab::TEN[t][1], bb = Tab::TEN[t][2], sb = Tab::TEN[t][3];
-      V3<T> ra = rot_apply(R[ba], mk(T(Tab::S[sa][0]) * P.site_off, T(Tab::S[sa][1]) * P.site_off, T(Tab::S[sa][2]) * P.site_z));
-      V3<T> rb = rot_apply(R[bb], mk(T(Tab::S[sb][0]) * P.site_off, T(Tab::S[sb][1]) * P.site_off, T(Tab::S[sb][2]) * P.site_z));
-      V3<T> dif = (S.x[bb] + rb) - (S.x[ba] + ra);
-      T L2 = dot(dif, dif);
-      T iL = rsqrt_(max_(L2, T(1e-30)));
-      T L = L2 * iL;
-      V3<T> u = iL * dif;
-      V3<T> va = S.v[ba] + cross(S.w[ba], ra), vb = S.v[bb] + cross(S.w[bb], rb);
-      T Ld = dot(u, vb - va);
-      T f, damp;
-      if (t < 6) {
-        T cc = clamp_(S.ctrl[t], P.ctrl_lo, P.ctrl_hi);
-        T fr = P.gain * cc + P.bias0 + P.bias1 * L + P.bias2 * Ld;
-        f = clamp_(fr, P.force_lo, P.force_hi);
-        bool clamped = (f <= P.force_lo) || (f >= P.force_hi);
-        damp = -P.bias2;
-        if (P.skip_clamped && clamped) damp = T(0);
-        // passive part of an actuated tendon (zero in the flat model)
-        f += -P.ten_k[t] * (L - P.ten_L0[t]) - P.ten_b[t] * Ld;
-        damp += P.ten_b[t];
-      } else {
-        f = -P.ten_k[t] * (L - P.ten_L0[t]) - P.ten_b[t] * Ld;
-        damp = P.ten_b[t];
-      }
-      if (last) lag.tenL[t] = L;
-      V3<T> fu = f * u;
-      V3<T> ma = cross(ra, u), mb = cross(rb, u);
-      F[bb] = F[bb] + fu; Tq[bb] = Tq[bb] + f * mb;
-      F[ba] = F[ba] - fu; Tq[ba] = Tq[ba] - f * ma;
-      st3<T, LW>(lds, L_TEN + 10 * t, u);
-      st3<T, LW>(lds, L_TEN + 10 * t + 3, ma);
-      st3<T, LW>(lds, L_TEN + 10 * t + 6, mb);
-      lds[(L_TEN + 10 * t + 9) * LW] = sqrt_(P.h * damp);
-    }
-    // unconstrained acceleration
-#pragma unroll
-    for (int b = 0; b < 3; b++) {
-      st3<T, LW>(lds, L_A0 + 6 * b, im * F[b]);
-      st3<T, LW>(lds, L_A0 + 6 * b + 3, inv_inertia(P, R[b].ez, Tq[b]));
-    }
-    // floor contacts: cap k of bar k/2
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const int b = k / 2;
-      T sg = (k % 2 == 0) ? P.bar_half : -P.bar_half;
-      V3<T> arm = sg * R[b].ez;
-      T dist = S.x[b].z + arm.z - P.cap_r;
-      Contact<T> c;
-      contact_params(P, dist, 1, c);
-      const int s = L_CF + 6 * k;
-      lds[s * LW] = arm.x; lds[(s + 1) * LW] = arm.y; lds[(s + 2) * LW] = arm.z - (P.cap_r + T(0.5) * dist);
-      lds[(s + 3) * LW] = c.c0; lds[(s + 4) * LW] = c.Dn; lds[(s + 5) * LW] = dist < T(0) ? T(1) : T(0);
+      for (int i = 0; i < 4; i++) lag.q[b][i] = S.q[b][i];
     }
   }
-  // ---- bar-bar contacts
-  int dropped = 0;
+  if (wid == 0) base_bar<T, LW, 0>(P, S, R, lds, last, lag);
+  else if (wid == 1) base_bar<T, LW, 1>(P, S, R, lds, last, lag);
+  else if (wid == 2) base_bar<T, LW, 2>(P, S, R, lds, last, lag);
+  TGR_STAMP(0);
+  __syncthreads();  // the columns of this sub-step are complete
   bool any_contact = false;
 #pragma unroll
-  for (int k = 0; k < 6; k++) any_contact = any_contact || (lds[(L_CF + 6 * k + 5) * LW] != T(0));
-#pragma unroll 1
-  for (int p = 0; p < 3; p++) {
-    const int A = pair_A(p), B = pair_B(p);
-    Contact<T> c0, c1;
-    bar_pair_contacts(P, ld3<T, LW>(lds, L_X + 3 * A), ld3<T, LW>(lds, L_EZ + 3 * A), ld3<T, LW>(lds, L_X + 3 * B),
-                      ld3<T, LW>(lds, L_EZ + 3 * B), c0, c1, dropped);
-    store_pair<T, LW>(lds, 2 * p, c0);
-    store_pair<T, LW>(lds, 2 * p + 1, c1);
-    any_contact = any_contact || c0.active || c1.active;
-  }
-  if (last) lag.overflow = dropped;
-
-  // ---- Newton on  1/2 (a-a0)^T M (a-a0) + sum_c s_c( J (a + B v) + c0 n )
+  for (int k = 0; k < 6; k++)
+    any_contact = any_contact || (lds[(L_CF + 6 * k + 5) * LW] != T(0)) || (lds[(L_CP + 12 * k + 11) * LW] != T(0));
+  if (last) lag.overflow = (int)(lds[(L_RED + 32) * LW] + lds[(L_RED + 33) * LW] + lds[(L_RED + 34) * LW]);
+  if (P.warm_start && wid < 3) {
+    // mujoco's warm start (optional): last sub-step's acceleration where there is a contact.  A lane without contacts
+    // must start (and stay) at a0; its rows of L_A are only read by this wave until the next barrier.
 #pragma unroll
-  for (int b = 0; b < 3; b++) {
-    V3<T> l0 = ld3<T, LW>(lds, L_A0 + 6 * b), a0 = ld3<T, LW>(lds, L_A0 + 6 * b + 3);
-    // Start every solve from the unconstrained acceleration.  The optimum is unique, so this changes nothing but the
-    // path: measured on MI355X it needs fewer line-search evaluations in the slowest lane of a block than mujoco's
-    // "better of warm start and a0" (the 1.9 ms contact time constant makes last sub-step's solution a poor guess).
-    const bool warm = P.warm_start && any_contact;
-    st3<T, LW>(lds, L_A + 6 * b, sel(warm, S.al[b], l0));
-    st3<T, LW>(lds, L_A + 6 * b + 3, sel(warm, S.aa[b], a0));
+    for (int b = 0; b < 3; b++)
+      if (b == wid && any_contact) { st3<T, LW>(lds, L_A + 6 * b, S.al[b]); st3<T, LW>(lds, L_A + 6 * b + 3, S.aa[b]); }
+    __syncthreads();
+  } else if (P.warm_start) {
+    __syncthreads();
   }
   const T scale = rcp_((T(3) * P.mass + T(2) * P.Ixx + P.Izz) * T(1.0 / 6.0) * T(18));
   bool conv = !any_contact;
   T cfrc_max = T(0);
-  TGR_STAMP(0);
-  __syncthreads();  // the (redundantly written) columns of this sub-step are complete
   const unsigned cpl = pair_coupling<T, LW>(lds);
+#ifdef TGR_STAMPS
+  lag.stamp[24 + cpl] += 1000000;  // histogram of the block-level coupling pattern (diagnostic build)
+#endif
   int n_it = 0, n_ls = 0;
 #pragma unroll 1
   for (int it = 0;; it++) {

@@ -527,6 +527,9 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
 
   Lag<T> lag;
   lag.cfrc_absmax = T(0); lag.cfrc_clip_sq = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
+  lag.bar_contact = T(0);
+#pragma unroll
+  for (int i = 0; i < 9; i++) lag.tenL[i] = T(0);  // wave 3 never evaluates tendons
 #ifdef TGR_STAMPS
   for (int i = 0; i < 32; i++) lag.stamp[i] = 0;
   lag.t_last = clock64();
@@ -660,6 +663,9 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void settle_kern
   const int total = settle_total(E);
   Lag<T> lag;
   lag.cfrc_absmax = T(0); lag.cfrc_clip_sq = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
+  lag.bar_contact = T(0);
+#pragma unroll
+  for (int i = 0; i < 9; i++) lag.tenL[i] = T(0);  // wave 3 never evaluates tendons
   T reset_psi = T(0);
   ModeState<T> ms = load_modes(k.st, k.ist, m, e);
   T xy_prev[2] = {T(0), T(0)};
