@@ -305,19 +305,33 @@ template <typename T> TGR_DEV void self_block_add(T* D, const Cone<T>& o, V3<T> 
   D[tri(5, 3)] += -o.a1 * r.z * r.x;
   D[tri(5, 4)] += -o.a1 * r.z * r.y;
   D[tri(5, 5)] += o.a1 * (rr - r.z * r.z) + o.b1;
-  // four rank-1 terms
-  V3<T> z3 = mk(T(0), T(0), T(0));
-  const V3<T> cls[4] = {n, z3, o.gl, o.wl};
-  const V3<T> cas[4] = {z3, n, o.ga, o.wa};
-  const T cf[4] = {o.a2, o.b2, o.cg, o.cw};
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
+  // rank-1 terms.  a2 (n, 0), b2 (0, n) always; the two cone terms (g, w) only where some lane of the wave sits on the
+  // cone surface (cg = cw = 0 in the quadratic zone)
+  {
     T u[6];
-    body_vec(cls[k], cas[k], r, u);
+    body_vec(n, mk(T(0), T(0), T(0)), r, u);
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-      for (int j = 0; j <= i; j++) D[tri(i, j)] += cf[k] * u[i] * u[j];
+      for (int j = 0; j <= i; j++) D[tri(i, j)] += o.a2 * u[i] * u[j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) D[tri(3 + i, 3 + j)] += o.b2 * comp(n, i) * comp(n, j);
+  }
+  if (__any(o.cg != T(0))) {
+    const V3<T> cls[2] = {o.gl, o.wl};
+    const V3<T> cas[2] = {o.ga, o.wa};
+    const T cf[2] = {o.cg, o.cw};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      T u[6];
+      body_vec(cls[k], cas[k], r, u);
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) D[tri(i, j)] += cf[k] * u[i] * u[j];
+    }
   }
 }
 // O (full 6x6, rows = body B dofs, cols = body A dofs) += J_B^T C J_A  (J_A carries the minus sign)
@@ -338,19 +352,34 @@ template <typename T> TGR_DEV void cross_block_add(T* O, const Cone<T>& o, V3<T>
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) O[(3 + i) * 6 + 3 + j] += a * ((i == j ? d : T(0)) - comp(rA, i) * comp(rB, j)) + (i == j ? b : T(0));
-  V3<T> z3 = mk(T(0), T(0), T(0));
-  const V3<T> cls[4] = {n, z3, o.gl, o.wl};
-  const V3<T> cas[4] = {z3, n, o.ga, o.wa};
-  const T cf[4] = {o.a2, o.b2, o.cg, o.cw};
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
+  {
     T uB[6], uA[6];
-    body_vec(cls[k], cas[k], rB, uB);
-    body_vec(cls[k], cas[k], rA, uA);
+    const V3<T> z3 = mk(T(0), T(0), T(0));
+    body_vec(n, z3, rB, uB);
+    body_vec(n, z3, rA, uA);
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-      for (int j = 0; j < 6; j++) O[i * 6 + j] -= cf[k] * uB[i] * uA[j];
+      for (int j = 0; j < 6; j++) O[i * 6 + j] -= o.a2 * uB[i] * uA[j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) O[(3 + i) * 6 + 3 + j] -= o.b2 * comp(n, i) * comp(n, j);
+  }
+  if (__any(o.cg != T(0))) {
+    const V3<T> cls[2] = {o.gl, o.wl};
+    const V3<T> cas[2] = {o.ga, o.wa};
+    const T cf[2] = {o.cg, o.cw};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      T uB[6], uA[6];
+      body_vec(cls[k], cas[k], rB, uB);
+      body_vec(cls[k], cas[k], rA, uA);
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) O[i * 6 + j] -= cf[k] * uB[i] * uA[j];
+    }
   }
 }
 
@@ -668,7 +697,7 @@ TGR_DEV unsigned pair_coupling(const T* lds) {
   unsigned cpl = 0u;
 #pragma unroll
   for (int p = 0; p < 3; p++) {
-    bool a = (lds[(L_CP + 12 * (2 * p) + 11) * LW] != T(0)) || (lds[(L_CP + 12 * (2 * p + 1) + 11) * LW] != T(0));
+    bool a = (lds[(L_CP + 12 * (2 * p) + 11) * LW] + lds[(L_CP + 12 * (2 * p + 1) + 11) * LW]) != T(0);
     if (__any(a)) cpl |= 1u << p;
   }
   return cpl;
@@ -1119,10 +1148,10 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
   else if (wid == 2) base_bar<T, LW, 2>(P, S, R, lds, last, lag);
   TGR_STAMP(0);
   __syncthreads();  // the columns of this sub-step are complete
-  bool any_contact = false;
+  T nact = T(0);  // the flags are 0/1: one batch of reads and a sum (a short-circuit `||` would expose twelve LDS round trips)
 #pragma unroll
-  for (int k = 0; k < 6; k++)
-    any_contact = any_contact || (lds[(L_CF + 6 * k + 5) * LW] != T(0)) || (lds[(L_CP + 12 * k + 11) * LW] != T(0));
+  for (int k = 0; k < 6; k++) nact += lds[(L_CF + 6 * k + 5) * LW] + lds[(L_CP + 12 * k + 11) * LW];
+  const bool any_contact = nact != T(0);
   if (last) lag.overflow = (int)(lds[(L_RED + 32) * LW] + lds[(L_RED + 33) * LW] + lds[(L_RED + 34) * LW]);
   if (P.warm_start && wid < 3) {
     // mujoco's warm start (optional): last sub-step's acceleration where there is a contact.  A lane without contacts
@@ -1139,7 +1168,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
   T cfrc_max = T(0);
   const unsigned cpl = pair_coupling<T, LW>(lds);
 #ifdef TGR_STAMPS
-  lag.stamp[24 + cpl] += 1000000;  // histogram of the block-level coupling pattern (diagnostic build)
+  int n_lane = 0;
 #endif
   int n_it = 0, n_ls = 0;
 #pragma unroll 1
@@ -1150,6 +1179,11 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
     conv = conv || !(scale * sqrt_(gn) >= P.tol);
     if (__all(conv) || it >= P.max_iter) break;
     n_it++;
+#ifdef TGR_STAMPS
+    lag.stamp[22] += conv ? 0 : 1000000;  // iterations this lane itself still needed (diagnostic build)
+    lag.stamp[23] += 1000000;             // iterations the block ran
+    n_lane += conv ? 0 : 1;
+#endif
     newton_direction<T, LW>(lds, wid, cpl, conv, lag);
     TGR_STAMP(2);
     // Gauss part of the line derivative  phi_g'(alpha) = g1 + alpha g2 ;  d0 = G.P  (per-bar partials, then summed)
@@ -1211,6 +1245,10 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
     __syncthreads();
   }
   TGR_STAMP(6);
+#ifdef TGR_STAMPS
+  lag.stamp[12 + (n_lane > 9 ? 9 : n_lane)] += 1000000;  // histogram: iterations this lane needed
+  lag.stamp[24 + (n_it > 7 ? 7 : n_it)] += 1000000;      // histogram: iterations the block ran (7 = 7 or 8)
+#endif
   if (last) {
     lag.cfrc_absmax = cfrc_max;
     T sq = T(0);
