@@ -21,6 +21,20 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def profiled_traffic():
+    """HBM bytes per step_kernel launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/round1_bench_rocprofv3_summary_v2.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB per
+    dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).  None when the profile is not there."""
+    import json as _j, os as _o
+    f = _o.path.join(_o.path.dirname(_o.path.abspath(__file__)), "profiles", "round1_bench_rocprofv3_summary_v2.json")
+    try:
+        d = _j.load(open(f))
+        fe, wr = d["fetch"]["tgr::step_kernel"], d["write"]["tgr::step_kernel"]
+        return (2.0 * fe["FETCH_SIZE"] / fe["dispatches"] + wr["WRITE_SIZE"] / wr["dispatches"]) * 1024.0
+    except Exception:
+        return None
+
+
 BYTES_PER_ENV_STEP = 674  # fp32: 61 state words in + 6 action words in, 61 state words + 39 obs words + reward + 2 flags out
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate 6290
 
@@ -138,7 +152,7 @@ def main():
                        "newton_iters_per_substep": stats1["newton_iters_per_substep"],
                        "starved_resets_rank0": stats1["settle_kernel_resets"] - stats0["settle_kernel_resets"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None,
+                         "traffic": profiled_traffic(),
                          "note": "step_kernel: 674 algorithmic B per env-step x envs per launch / mean launch duration (HIP events around "
                                  "the step+match+settle launches of one step); the path is VALU-issue bound (~1e6 flop per env-step), "
                                  "not HBM bound: see DESIGN.md",

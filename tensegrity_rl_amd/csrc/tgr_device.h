@@ -1034,6 +1034,18 @@ TGR_DEV void newton_dphi(const Params<T>& P, T* lds, int wid, const LSlot<T>* ls
   for (int w = 0; w < 4; w++) { d1 += lds[(base + 2 * w) * LW]; d2 += lds[(base + 1 + 2 * w) * LW]; }
 }
 
+// qacc_warmstart lives in the L_A columns between sub-steps (not in registers): park it there when a kernel starts ...
+template <typename T, int LW> TGR_DEV void warm_to_lds(const Sim<T>& S, T* lds, int wid) {
+#pragma unroll
+  for (int b = 0; b < 3; b++)
+    if (b == wid) { st3<T, LW>(lds, L_A + 6 * b, S.al[b]); st3<T, LW>(lds, L_A + 6 * b + 3, S.aa[b]); }
+}
+// ... and fetch it back for store_sim when the last sub-step is done
+template <typename T, int LW> TGR_DEV void warm_from_lds(Sim<T>& S, const T* lds) {
+#pragma unroll
+  for (int b = 0; b < 3; b++) { S.al[b] = ld3<T, LW>(lds, L_A + 6 * b); S.aa[b] = ld3<T, LW>(lds, L_A + 6 * b + 3); }
+}
+
 // base phase of bar B (see substep): kinematic columns, attached tendons, a0, floor caps, bar pair B
 template <typename T, int LW, int B>
 TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* lds, bool last, Lag<T>& lag) {
@@ -1093,8 +1105,10 @@ TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* l
   V3<T> l0 = im * F, a0 = inv_inertia(P, R[B].ez, Tq);
   st3<T, LW>(lds, L_A0 + 6 * B, l0);
   st3<T, LW>(lds, L_A0 + 6 * B + 3, a0);
-  st3<T, LW>(lds, L_A + 6 * B, l0);
-  st3<T, LW>(lds, L_A + 6 * B + 3, a0);
+  if (!P.warm_start) {  // with mujoco's warm start the previous solution simply stays in L_A
+    st3<T, LW>(lds, L_A + 6 * B, l0);
+    st3<T, LW>(lds, L_A + 6 * B + 3, a0);
+  }
   // floor contacts: caps 2B, 2B+1
 #pragma unroll
   for (int e = 0; e < 2; e++) {
@@ -1153,15 +1167,12 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
   for (int k = 0; k < 6; k++) nact += lds[(L_CF + 6 * k + 5) * LW] + lds[(L_CP + 12 * k + 11) * LW];
   const bool any_contact = nact != T(0);
   if (last) lag.overflow = (int)(lds[(L_RED + 32) * LW] + lds[(L_RED + 33) * LW] + lds[(L_RED + 34) * LW]);
-  if (P.warm_start && wid < 3) {
-    // mujoco's warm start (optional): last sub-step's acceleration where there is a contact.  A lane without contacts
-    // must start (and stay) at a0; its rows of L_A are only read by this wave until the next barrier.
-#pragma unroll
-    for (int b = 0; b < 3; b++)
-      if (b == wid && any_contact) { st3<T, LW>(lds, L_A + 6 * b, S.al[b]); st3<T, LW>(lds, L_A + 6 * b + 3, S.aa[b]); }
-    __syncthreads();
-  } else if (P.warm_start) {
-    __syncthreads();
+  if (P.warm_start && wid < 3 && !any_contact) {
+    // mujoco's warm start (optional): L_A still holds last sub-step's solution.  A lane without contacts must start (and
+    // stay) at a0; nobody else looks at its rows of L_A (all its contact slots are inactive), so no barrier is needed.
+    const int b = wid;
+    st3<T, LW>(lds, L_A + 6 * b, ld3<T, LW>(lds, L_A0 + 6 * b));
+    st3<T, LW>(lds, L_A + 6 * b + 3, ld3<T, LW>(lds, L_A0 + 6 * b + 3));
   }
   const T scale = rcp_((T(3) * P.mass + T(2) * P.Ixx + P.Izz) * T(1.0 / 6.0) * T(18));
   bool conv = !any_contact;
@@ -1258,8 +1269,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
     lag.bar_contact = lds[(L_RED + 31) * LW];
   }
   lag.n_it += n_it; lag.n_ls += n_ls; lag.n_unconv += conv ? 0 : 1;
-#pragma unroll
-  for (int b = 0; b < 3; b++) { S.al[b] = ld3<T, LW>(lds, L_A + 6 * b); S.aa[b] = ld3<T, LW>(lds, L_A + 6 * b + 3); }
+  // (the solution stays in L_A: it is next sub-step's warm start and, after the last sub-step, qacc_warmstart)
 
   // ---- implicitfast: (M + h sum_t b_t J_t J_t^T) a_new = F_smooth + F_constraint   (Woodbury over 9 tendons)
   V3<T> yl[3], ya[3], ez[3];

@@ -534,6 +534,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
   for (int i = 0; i < 32; i++) lag.stamp[i] = 0;
   lag.t_last = clock64();
 #endif
+  warm_to_lds<T, LW>(S, lds, wid);
 #pragma unroll 1
   for (int s = 0; s < E.frame_skip; s++) substep<T, LW>(P, S, lds, wid, s == E.frame_skip - 1, lag);
 
@@ -549,7 +550,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
   }
   if (active && w0 && lag.n_unconv) atomicAdd(&k.counters[6], (unsigned long long)lag.n_unconv);
   V3<T> wb[3];
-  if (active && w0) store_sim(k.st, m, e, S, lag, wb);
+  if (active && w0) { warm_from_lds<T, LW>(S, lds); store_sim(k.st, m, e, S, lag, wb); }
   else if (active) {
 #pragma unroll
     for (int b = 0; b < 3; b++) { normalize_quat(S.q[b]); wb[b] = rot_applyT(quat_rot(S.q[b]), S.w[b]); }
@@ -669,6 +670,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void settle_kern
   T reset_psi = T(0);
   ModeState<T> ms = load_modes(k.st, k.ist, m, e);
   T xy_prev[2] = {T(0), T(0)};
+  warm_to_lds<T, LW>(S, lds, wid);
 #pragma unroll 1
   for (int st = 0; st < total; st++) {
 #pragma unroll 1
@@ -677,6 +679,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void settle_kern
   }
   if (!valid || wid != 0) return;
   V3<T> wb[3];
+  warm_from_lds<T, LW>(S, lds);
   store_sim(k.st, m, e, S, lag, wb);
   store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
   store_modes(k.st, m, e, ms);
