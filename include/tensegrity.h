@@ -101,6 +101,11 @@ typedef struct tgr_config {
   double waypt_range[2], waypt_angle_range[2];
   double ditch_reward_max, ditch_reward_stdev, waypt_reward_amplitude, waypt_reward_stdev, yaw_reward_weight;
   int32_t solver_warm_start; /* 0 (default): every solve starts from the unconstrained acceleration; 1: from the previous solution */
+  /* tr_env observation noise (tr_env.py:142,161-162,549-646): step()/reset() return observation_with_noise.  The
+   * reference draws from an unseeded generator; here the standard normals are philox draws keyed (seed; lane key, episode,
+   * observation index within the episode), i.e. same distribution, reproducible */
+  int32_t use_obs_noise;
+  double obs_noise_tendon_stdev, obs_noise_cap_pos_stdev; /* 0.02, 0.05 */
 } tgr_config;
 
 typedef struct tgr_handle tgr_handle;

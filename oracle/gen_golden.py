@@ -241,6 +241,34 @@ def helper_vectors():
     return dict(ditch_xy=xs, ditch=ditch, ang_in=ang_in, ang=ang, vel_track=vt, filt=filt)
 
 
+def noise_vectors():
+    """tr_env.py:549-646 with use_obs_noise=True: the reference's own (clean, noisy) observation pairs together with the
+    standard-normal draws it consumed (its unseeded default_rng() is patched to a seeded one and replayed here)."""
+    from tr_env.envs.tr_env import tr_env as cls
+    clean, noisy, zs, acts, capv = [], [], [], [], []
+    for ci, (action, kw) in enumerate([("straight", {}), ("straight", {"use_cap_velocity": False}), ("tracking", {}),
+                                       ("aiming", {}), ("vel_track", {})]):
+        ss = 900 + ci
+        np.random.default_rng = (lambda q: (lambda *a, **k: _real_default_rng(q) if not a and not k else _real_default_rng(*a, **k)))(ss)
+        np.random.seed(ss)
+        env = cls(xml_file="unused.xml", desired_action=action, use_obs_noise=True, **kw)
+        env.reset()
+        arng = _real_default_rng(ss)
+        for t in range(3):
+            obs, r, term, trunc, info = env.step(arng.uniform(-0.45, 0.15, size=6).astype(np.float32))
+            g = _real_default_rng(ss)
+            z = np.zeros(45)
+            z[:18] = np.concatenate([g.standard_normal(size=3) for _ in range(6)])
+            z[18:27] = g.standard_normal(size=9)
+            if kw.get("use_cap_velocity", True):
+                z[27:45] = np.concatenate([g.standard_normal(size=3) for _ in range(6)])
+            c = np.zeros(48); n = np.zeros(48)
+            c[:len(obs)] = info["real_observation"]; n[:len(obs)] = obs
+            clean.append(c); noisy.append(n); zs.append(z); acts.append(action); capv.append(int(kw.get("use_cap_velocity", True)))
+    return dict(clean=np.array(clean), noisy=np.array(noisy), z=np.array(zs), action=np.array(acts, dtype="U16"), use_cap_velocity=np.array(capv),
+                tendon_stdev=0.02, cap_pos_stdev=0.05)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference not present; fixtures can only be regenerated in the build container")
@@ -256,6 +284,7 @@ def main():
         np.savez_compressed(os.path.join(outdir, name), **res)
         print(name, "obs", res["obs"].shape, "reward[:3]", res["reward"][:3], "term any", res["terminated"].any())
     np.savez_compressed(os.path.join(outdir, "tr_env_helpers.npz"), **helper_vectors())
+    np.savez_compressed(os.path.join(outdir, "tr_env_obs_noise.npz"), **noise_vectors())
     np.random.default_rng = _real_default_rng
 
 

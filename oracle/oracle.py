@@ -57,14 +57,16 @@ class EnvCfg(C.Structure):
                 ("tendon_min_length", d), ("reward_delay_steps", C.c_int), ("waypt_range", d * 2),
                 ("waypt_angle_range", d * 2), ("ditch_reward_max", d), ("ditch_reward_stdev", d),
                 ("waypt_reward_amplitude", d), ("waypt_reward_stdev", d), ("yaw_reward_weight", d),
-                ("frame_skip", C.c_int), ("max_episode_steps", C.c_int)]
+                ("frame_skip", C.c_int), ("max_episode_steps", C.c_int), ("use_obs_noise", C.c_int),
+                ("obs_noise_tendon_stdev", d), ("obs_noise_cap_pos_stdev", d)]
 
 
 class Env(C.Structure):
     _fields_ = [("cfg", EnvCfg), ("model", Model), ("data", Data), ("x_velocity", d), ("y_velocity", d),
                 ("reset_psi", d), ("ring", d * RING), ("ring_len", C.c_int), ("ring_head", C.c_int),
                 ("step_num", C.c_int), ("elapsed", C.c_int), ("waypt", d * 2), ("oripoint", d * 2),
-                ("lin_vel_cmd", d * 2), ("ang_vel_cmd", d), ("ep_return", d), ("obs_dim", C.c_int)]
+                ("lin_vel_cmd", d * 2), ("ang_vel_cmd", d), ("ep_return", d), ("obs_dim", C.c_int),
+                ("rng_seed", C.c_uint64), ("rng_key", C.c_uint64), ("rng_episode", C.c_uint64)]
 
 
 _lib = None

@@ -64,6 +64,41 @@ void tgo_rng_draws(uint64_t seed, uint64_t env_id, uint64_t episode, int env_kin
   u_way[1] = u53(o[2], o[3]);
 }
 
+/* ------------------------------------------------------------------ observation noise */
+void tgo_obs_noise_draws(uint64_t seed, uint64_t key, uint64_t episode, int elapsed, double z[48]) {
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  for (int j = 0; j < 12; j++) {
+    uint32_t ctr[4] = {(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)episode, 0x80000000u + ((uint32_t)elapsed << 4) + (uint32_t)j};
+    uint32_t o[4];
+    tgo_philox4x32(ctr, k, o);
+    for (int h = 0; h < 2; h++) { /* Box-Muller on 32-bit uniforms: u1 in (0,1], u2 in [0,1) */
+      double u1 = ((double)o[2 * h] + 1.0) / 4294967296.0, u2 = (double)o[2 * h + 1] / 4294967296.0;
+      double r = sqrt(-2.0 * log(u1));
+      z[4 * j + 2 * h] = r * cos(2 * PI * u2);
+      z[4 * j + 2 * h + 1] = r * sin(2 * PI * u2);
+    }
+  }
+}
+
+void tgo_apply_obs_noise(const tgo_env_cfg* c, const double z[45], double* obs) {
+  /* layout [cap pos 18][cap vel 18 if use_cap_velocity][tendons 9][tail]; draws: pos, tendons, vel (tr_env.py:549-610) */
+  int nv = c->use_cap_velocity ? 18 : 0;
+  double sx = 0, sy = 0;
+  for (int i = 0; i < 18; i++) {
+    obs[i] = z[i] * c->obs_noise_cap_pos_stdev + obs[i];
+    if (i % 3 == 0) sx += obs[i];
+    if (i % 3 == 1) sy += obs[i];
+  }
+  for (int t = 0; t < 9; t++) obs[18 + nv + t] = z[18 + t] * c->obs_noise_tendon_stdev + obs[18 + nv + t];
+  for (int i = 0; i < nv; i++) obs[18 + i] = z[27 + i] * c->obs_noise_cap_pos_stdev + obs[18 + i]; /* cap_pos stdev, tr_env.py:604 */
+  if (c->desired_action == TGO_ACT_TRACKING || c->desired_action == TGO_ACT_AIMING) { /* tr_env.py:626-639 */
+    int k = 18 + nv + 9;
+    double tx = obs[k] - sx / 6, ty = obs[k + 1] - sy / 6;
+    double n = sqrt(tx * tx + ty * ty);
+    obs[k] = tx; obs[k + 1] = ty; obs[k + 2] = atan2(ty / n, tx / n);
+  }
+}
+
 /* ------------------------------------------------------------------ config */
 void tgo_env_default_cfg(tgo_env_cfg* c, int env_kind, int desired_action) {
   memset(c, 0, sizeof(*c));
@@ -73,6 +108,9 @@ void tgo_env_default_cfg(tgo_env_cfg* c, int env_kind, int desired_action) {
   c->terminate_when_unhealthy = 1;
   c->use_contact_forces = 0;
   c->use_cap_velocity = 1;
+  c->use_obs_noise = 0;
+  c->obs_noise_tendon_stdev = 0.02;
+  c->obs_noise_cap_pos_stdev = 0.05;
   c->is_test = 0;
   c->contact_cost_weight = 5e-4;
   c->healthy_reward = 0.1;
@@ -238,6 +276,11 @@ void tgo_env_get_obs(const tgo_env* e, double* obs) {
   } else if (act == TGO_ACT_VEL_TRACK) {
     obs[o++] = e->lin_vel_cmd[0]; obs[o++] = e->lin_vel_cmd[1]; obs[o++] = e->ang_vel_cmd;
   }
+  if (e->cfg.use_obs_noise) { /* tr_env.py:524-527,869-872: step() and reset() return observation_with_noise */
+    double z[48];
+    tgo_obs_noise_draws(e->rng_seed, e->rng_key, e->rng_episode, e->elapsed, z);
+    tgo_apply_obs_noise(&e->cfg, z, obs);
+  }
 }
 
 /* ------------------------------------------------------------------ step */
@@ -374,8 +417,8 @@ void tgo_env_step(tgo_env* e, const float action[6], double* obs, double* reward
   double a[6];
   for (int i = 0; i < 6; i++) a[i] = (double)action[i];
   env_step_inner(e, a, reward, terminated, info);
-  tgo_env_get_obs(e, obs);
   e->elapsed += 1;
+  tgo_env_get_obs(e, obs); /* observation k of the episode (0 = reset) keys the observation noise */
   *truncated = e->elapsed >= e->cfg.max_episode_steps; /* gym TimeLimit */
   e->ep_return += *reward;
   if (info) { info[TGO_INFO_EP_RETURN] = e->ep_return; info[TGO_INFO_EP_LENGTH] = e->elapsed; }
@@ -455,5 +498,6 @@ void tgo_env_reset_seeded(tgo_env* e, uint64_t seed, uint64_t env_id, uint64_t e
   int pose; double theta, tendons[6], uw[2];
   tgo_rng_draws(seed, env_id, episode, c->env_kind, c->tendon_reset_mean, c->tendon_reset_stdev, c->tendon_min_length,
                 c->tendon_max_length, c->min_reset_heading, c->max_reset_heading, &pose, &theta, tendons, uw);
+  e->rng_seed = seed; e->rng_key = env_id; e->rng_episode = episode;
   tgo_env_reset(e, pose, theta, tendons, uw, obs);
 }

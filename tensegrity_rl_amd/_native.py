@@ -32,6 +32,7 @@ class Config(C.Structure):
         ("n_donors", i32), ("seed", u64), ("first_env_id", u64), ("solver_tolerance", f64), ("solver_iterations", i32),
         ("waypt_range", f64 * 2), ("waypt_angle_range", f64 * 2), ("ditch_reward_max", f64), ("ditch_reward_stdev", f64),
         ("waypt_reward_amplitude", f64), ("waypt_reward_stdev", f64), ("yaw_reward_weight", f64), ("solver_warm_start", i32),
+        ("use_obs_noise", i32), ("obs_noise_tendon_stdev", f64), ("obs_noise_cap_pos_stdev", f64),
     ]
 
 

@@ -34,7 +34,8 @@ constexpr double PI = 3.14159265358979323846;
 
 template <typename T> struct EnvCfg {
   int env_kind, action, terminate_when_unhealthy, use_contact_forces, use_cap_velocity, is_test;
-  int reward_delay_steps, frame_skip, max_episode_steps, obs_dim;
+  int reward_delay_steps, frame_skip, max_episode_steps, obs_dim, use_obs_noise;
+  T noise_tendon, noise_cap;
   T direction, ctrl_cost_weight, contact_cost_weight, healthy_reward, contact_lo, contact_hi, dt;
   T ditch_max, ditch_std, waypt_amp, waypt_std, yaw_weight;
   double waypt_range[2], waypt_angle_range[2];
@@ -212,6 +213,54 @@ TGR_DEV void make_obs(const Params<T>& P, const EnvCfg<T>& E, const Sim<T>& S, c
     o[k++] = tx; o[k++] = ty; o[k++] = atan2_(ty * in, tx * in);
   } else if (E.action == TGR_ACT_VEL_TRACK) {
     o[k++] = ms.vcmd[0]; o[k++] = ms.vcmd[1]; o[k++] = ms.vcmd[2];
+  }
+}
+
+// tr_env.py:549-646, use_obs_noise: what step()/reset() return is observation_with_noise.  o: this lane's observation row
+// (noise-free, in LDS).  45 standard normals in the reference's order -- cap positions (18), tendon lengths (9), cap velocities
+// (18) -- from philox keyed (seed; key, episode, 0x80000000 + 16 * k + j), k = index of the observation within the episode.
+template <typename T> TGR_DEV void apply_obs_noise(const EnvCfg<T>& E, unsigned long long key, unsigned episode, int kobs, T* o) {
+  T z[48];
+  const unsigned k0 = (unsigned)E.seed, k1 = (unsigned)(E.seed >> 32);
+#pragma unroll 1
+  for (int j = 0; j < 12; j++) {
+    unsigned w[4];
+    philox((unsigned)key, (unsigned)(key >> 32), episode, 0x80000000u + ((unsigned)kobs << 4) + (unsigned)j, k0, k1, w);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      // Box-Muller on 32-bit uniforms: u1 in (0,1], u2 in [0,1)
+      if (sizeof(T) == 4) {
+        float u1 = ((float)w[2 * h] + 1.0f) * 2.3283064365386963e-10f, u2 = (float)w[2 * h + 1] * 2.3283064365386963e-10f;
+        float r = sqrtf(-2.0f * logf(u1)), sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        z[4 * j + 2 * h] = T(r * cs); z[4 * j + 2 * h + 1] = T(r * sn);
+      } else {
+        double u1 = ((double)w[2 * h] + 1.0) / 4294967296.0, u2 = (double)w[2 * h + 1] / 4294967296.0;
+        double r = sqrt(-2.0 * log(u1));
+        z[4 * j + 2 * h] = T(r * cos(2 * PI * u2)); z[4 * j + 2 * h + 1] = T(r * sin(2 * PI * u2));
+      }
+    }
+  }
+  const int nv = E.use_cap_velocity ? 18 : 0;
+  T sx = T(0), sy = T(0);
+#pragma unroll
+  for (int i = 0; i < 18; i++) {
+    T v = z[i] * E.noise_cap + o[i];
+    o[i] = v;
+    if (i % 3 == 0) sx += v;
+    if (i % 3 == 1) sy += v;
+  }
+#pragma unroll
+  for (int t = 0; t < 9; t++) o[18 + nv + t] = z[18 + t] * E.noise_tendon + o[18 + nv + t];
+  if (nv) {
+#pragma unroll
+    for (int i = 0; i < 18; i++) o[18 + i] = z[27 + i] * E.noise_cap + o[18 + i];  // cap_pos stdev (tr_env.py:604)
+  }
+  if (E.action == TGR_ACT_TRACKING || E.action == TGR_ACT_AIMING) {  // tr_env.py:626-639
+    const int k = 18 + nv + 9;
+    T tx = o[k] - sx * T(1.0 / 6.0), ty = o[k + 1] - sy * T(1.0 / 6.0);
+    T in = rsqrt_(tx * tx + ty * ty);
+    o[k] = tx; o[k + 1] = ty; o[k + 2] = atan2_(ty * in, tx * in);
   }
 }
 
@@ -582,6 +631,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
       if (phase == PH_READY) {
         store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
         make_obs(P, E, S, lag, wb, ms, orow);
+        if (E.use_obs_noise) apply_obs_noise(E, lane_key(E, n, e), (unsigned)k.ist[I_SRCEP * m + e], 0, orow);
         T* op = k.dobs + (size_t)(e - n) * D;
         for (int i = 0; i < D; i++) op[i] = orow[i];
       }
@@ -598,6 +648,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
     done = out.terminated || truncated;
     if (valid && w0) {
       make_obs(P, E, S, lag, wb, ms, orow);
+      if (E.use_obs_noise) apply_obs_noise(E, lane_key(E, n, k.ist[I_SRC * m + e]), (unsigned)k.ist[I_SRCEP * m + e], elapsed, orow);
       k.st[(F_XYLAG + 0) * m + e] = out.xy[0]; k.st[(F_XYLAG + 1) * m + e] = out.xy[1];
       k.st[F_PSILAG * m + e] = out.psi_straight;
       k.st[F_EPRET * m + e] = ep_ret;
@@ -693,6 +744,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void settle_kern
   const int D = E.obs_dim;
   T* orow = lds_all + lane * ((D & 1) ? D : D + 1);  // wave 0 only from here on; the columns are dead
   make_obs(P, E, S, lag, wb, ms, orow);
+  if (E.use_obs_noise) apply_obs_noise(E, lane_key(E, n, e), (unsigned)episode, 0, orow);
   T* op = e < n ? (k.obs_reset ? k.obs_reset + (size_t)e * D : nullptr) : k.dobs + (size_t)(e - n) * D;
   if (op)
     for (int i = 0; i < D; i++) op[i] = orow[i];
@@ -885,6 +937,7 @@ extern "C" int tgr_default_config(tgr_config* c, int env_kind, int desired_actio
   c->ditch_reward_max = 300; c->ditch_reward_stdev = 0.15; c->waypt_reward_amplitude = 100; c->waypt_reward_stdev = 0.10;
   c->yaw_reward_weight = 1;
   c->solver_warm_start = 0;
+  c->use_obs_noise = 0; c->obs_noise_tendon_stdev = 0.02; c->obs_noise_cap_pos_stdev = 0.05;
   return TGR_OK;
 }
 
@@ -931,6 +984,8 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   E.use_contact_forces = c.use_contact_forces; E.use_cap_velocity = c.use_cap_velocity; E.is_test = c.is_test;
   E.reward_delay_steps = c.reward_delay_steps; E.frame_skip = c.frame_skip; E.max_episode_steps = c.max_episode_steps;
   E.obs_dim = h->obs_dim;
+  E.use_obs_noise = (c.use_obs_noise && c.env_kind == TGR_ENV_TR) ? 1 : 0;
+  E.noise_tendon = T(c.obs_noise_tendon_stdev); E.noise_cap = T(c.obs_noise_cap_pos_stdev);
   E.direction = T(c.desired_direction); E.ctrl_cost_weight = T(c.ctrl_cost_weight); E.contact_cost_weight = T(c.contact_cost_weight);
   E.healthy_reward = T(c.healthy_reward); E.contact_lo = T(c.contact_force_lo); E.contact_hi = T(c.contact_force_hi);
   E.dt = T(c.timestep * c.frame_skip);

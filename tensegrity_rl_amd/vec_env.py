@@ -19,10 +19,11 @@ ENV_IDS = {"tensegrity_env-v0": N.ENV_TENSEGRITY, "tr_env-v0": N.ENV_TR, "tenseg
 _DIRECT = ["use_contact_forces", "use_cap_velocity", "terminate_when_unhealthy", "is_test", "desired_direction",
            "ctrl_cost_weight", "contact_cost_weight", "healthy_reward", "min_reset_heading", "max_reset_heading",
            "tendon_reset_mean", "tendon_reset_stdev", "tendon_max_length", "tendon_min_length", "ditch_reward_max",
-           "ditch_reward_stdev", "waypt_reward_amplitude", "waypt_reward_stdev", "yaw_reward_weight"]
+           "ditch_reward_stdev", "waypt_reward_amplitude", "waypt_reward_stdev", "yaw_reward_weight", "use_obs_noise",
+           "obs_noise_tendon_stdev", "obs_noise_cap_pos_stdev"]
 # accepted for signature compatibility, no effect on the built path (reference defaults)
-_IGNORED = ["xml_file", "render_mode", "reset_noise_scale", "contact_with_self_penalty", "use_obs_noise",
-            "use_cap_size_noise", "obs_noise_tendon_stdev", "obs_noise_cap_pos_stdev", "cap_size_noise_range",
+_IGNORED = ["xml_file", "render_mode", "reset_noise_scale", "contact_with_self_penalty",
+            "use_cap_size_noise", "cap_size_noise_range",
             "threshold_waypt", "width", "height", "camera_id", "camera_name"]
 
 
@@ -40,8 +41,9 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
             setattr(cfg, k, type(getattr(cfg, k))(kwargs.pop(k)))
         elif k in _IGNORED:
             v = kwargs.pop(k)
-            if k in ("use_obs_noise", "use_cap_size_noise") and v:  # noqa: SIM102
-                raise NotImplementedError(f"{k}=True is not built yet (SURVEY.md 8f)")
+            if k == "use_cap_size_noise" and v:
+                # tr_env.py:685-706 calls model.geom_names, which the mujoco bindings do not have: it raises in the reference too
+                raise NotImplementedError("use_cap_size_noise=True is dead code in the reference (AttributeError) and is not built")
             if k == "reset_noise_scale" and v:
                 raise NotImplementedError("reset_noise_scale != 0 is not built")
     if "contact_force_range" in kwargs:

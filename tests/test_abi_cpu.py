@@ -63,8 +63,10 @@ def test_make_config_kwargs_follow_reference_signatures():
         make_config("tensegrity_env-v0", bogus=1)
     with pytest.raises(ValueError):
         make_config("nope-v0")
+    c = make_config("tr_env-v0", use_obs_noise=True, obs_noise_tendon_stdev=0.03)
+    assert c.use_obs_noise == 1 and c.obs_noise_tendon_stdev == 0.03 and c.obs_noise_cap_pos_stdev == 0.05
     with pytest.raises(NotImplementedError):
-        make_config("tr_env-v0", use_obs_noise=True)
+        make_config("tr_env-v0", use_cap_size_noise=True)
 
 
 def test_product_package_never_imports_the_oracle():

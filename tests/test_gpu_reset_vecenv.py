@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from gpu_common import AUX, qfix
+from gpu_common import AUX, qfix, oracle_to_gpu_state
 
 pytestmark = pytest.mark.gpu
 
@@ -160,3 +160,40 @@ def test_full_size_properties():
     assert env.get_state()["aux"][trh, 6].max() == 0 and env.stats()["donor_resets"] >= int(trh.sum())
     assert env.stats()["settle_kernel_resets"] == 3 * n  # the initial reset of envs + donors only: nobody was starved
     env.close()
+
+
+@pytest.mark.parametrize("action,capv", [("straight", 1), ("straight", 0), ("tracking", 1), ("vel_track", 1)])
+def test_obs_noise_matches_oracle(oracle, action, capv):
+    """tr_env use_obs_noise=True (tr_env.py:524-527,549-646,869-872): reset and step observations carry noise from philox
+    draws keyed (seed, lane key, episode, observation index); the fp64 HIP path and the oracle agree on every noisy entry, and
+    the noise has the reference's scale (sigma 0.05 on cap positions/velocities, 0.02 on tendon lengths)."""
+    from tensegrity_rl_amd import TensegrityVecEnv
+    O = oracle
+    n = 32
+    kw = dict(use_obs_noise=1, use_cap_velocity=capv)
+    ob = O.OracleBatch(O.make_cfg("tr_env", action, **kw), n, seed=77)
+    env = TensegrityVecEnv(n, "tr_env-v0", desired_action=action, precision="f64", auto_reset=False, seed=77, **kw)
+    clean = TensegrityVecEnv(n, "tr_env-v0", desired_action=action, precision="f64", auto_reset=False, seed=77, use_cap_velocity=capv)
+    o_obs = ob.reset()
+    g_obs = env.reset()
+    c_obs = clean.reset()
+    np.testing.assert_allclose(g_obs, o_obs, atol=5e-4)  # 50 settling periods: solver paths differ at the 1e-4 level
+    nv = 18 if capv else 0
+    rng = np.random.default_rng(3)
+    diffs = []
+    for t in range(4):
+        oracle_to_gpu_state(ob, env)
+        oracle_to_gpu_state(ob, clean)
+        a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+        o_obs = ob.step(a, auto_reset=False)[0]
+        g_obs = env.step(a)[0]
+        c_obs = clean.step(a)[0]
+        np.testing.assert_allclose(g_obs, o_obs, atol=2e-6)
+        diffs.append(g_obs - c_obs)
+    d = np.concatenate(diffs)
+    pos, ten = d[:, :18], d[:, 18 + nv:27 + nv]
+    assert abs(pos.std() - 0.05) < 0.006 and abs(ten.std() - 0.02) < 0.003 and abs(pos.mean()) < 0.01
+    if nv:
+        assert abs(d[:, 18:36].std() - 0.05) < 0.006
+    assert not np.allclose(diffs[0], diffs[1])  # fresh draws every observation
+    env.close(); clean.close(); ob.close()

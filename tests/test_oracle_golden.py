@@ -25,7 +25,7 @@ def qpos_close(a, b, atol):
 
 
 def load_cases(golden_dir):
-    return sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "helpers" not in f and not os.path.basename(f).startswith("policy_"))
+    return sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "helpers" not in f and "obs_noise" not in f and not os.path.basename(f).startswith("policy_"))
 
 
 def cfg_from_fixture(O, g):
@@ -70,3 +70,33 @@ def test_helper_known_answers(oracle, golden_dir):
     assert abs(g["vel_track"][0] - 1.396163535868496) < 1e-12
     assert abs(g["ang"][0] - (-2.2831853071795862)) < 1e-12
     np.testing.assert_allclose(g["filt"], 0.002, atol=1e-15)
+
+
+def test_obs_noise_application_matches_reference(oracle, golden_dir):
+    """tr_env.py:549-646 with use_obs_noise=True: (clean, noisy) observation pairs produced by the reference class itself and
+    the standard-normal draws it consumed; the restatement applies the same draws to the clean observation."""
+    import ctypes as C
+    O = oracle
+    g = np.load(os.path.join(golden_dir, "tr_env_obs_noise.npz"))
+    for k in range(len(g["clean"])):
+        cfg = O.make_cfg("tr_env", str(g["action"][k]), use_cap_velocity=int(g["use_cap_velocity"][k]), use_obs_noise=1)
+        assert cfg.obs_noise_tendon_stdev == float(g["tendon_stdev"]) and cfg.obs_noise_cap_pos_stdev == float(g["cap_pos_stdev"])
+        obs = g["clean"][k].copy()
+        z = np.ascontiguousarray(g["z"][k])
+        O.lib().tgo_apply_obs_noise(C.byref(cfg), O.dptr(z), O.dptr(obs))
+        D = O.lib().tgo_env_obs_dim(C.byref(cfg))
+        np.testing.assert_allclose(obs[:D], g["noisy"][k][:D], atol=1e-12)
+        assert np.abs(g["noisy"][k][:D] - g["clean"][k][:D]).max() > 1e-3
+
+
+def test_obs_noise_draws_are_standard_normal_and_keyed(oracle):
+    import ctypes as C
+    O = oracle
+    z = np.zeros(48); zs = []
+    for key in range(1500):
+        O.lib().tgo_obs_noise_draws(C.c_uint64(7), C.c_uint64(key), C.c_uint64(2), 5, O.dptr(z)); zs.append(z[:45].copy())
+    zs = np.array(zs)
+    assert abs(zs.mean()) < 0.01 and abs(zs.std() - 1) < 0.01 and abs(((zs - zs.mean()) ** 4).mean() / zs.var() ** 2 - 3) < 0.1
+    a = zs[3].copy()
+    O.lib().tgo_obs_noise_draws(C.c_uint64(7), C.c_uint64(3), C.c_uint64(2), 5, O.dptr(z)); assert np.array_equal(z[:45], a)
+    O.lib().tgo_obs_noise_draws(C.c_uint64(7), C.c_uint64(3), C.c_uint64(2), 6, O.dptr(z)); assert not np.allclose(z[:45], a)
