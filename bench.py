@@ -89,11 +89,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the HIP path is the product and there is no CPU fallback")
+    # TGR_BENCH_REHEARSAL=1: all ranks share cuda:0 and talk over gloo -- exercises the N>1 code path on a one-GPU box
+    # (numbers from it mean nothing); the real thing is one rank per GPU over RCCL
+    rehearsal = os.environ.get("TGR_BENCH_REHEARSAL") == "1"
+    local_rank = 0 if rehearsal else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n_local = args.envs_per_gpu
     n_total = n_local * world

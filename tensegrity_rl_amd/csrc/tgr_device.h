@@ -1209,30 +1209,47 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
       lds[(L_RED + 23 + 3 * b) * LW] = P.mass * dot(pl, pl) + dot(Ipa, pa);
       lds[(L_RED + 24 + 3 * b) * LW] = dot(pl, ld3<T, LW>(lds, L_G + 6 * b)) + dot(pa, ld3<T, LW>(lds, L_G + 6 * b + 3));
     }
+    // the line-search slots, and their contribution at the first trial point alpha = 1, ride on the same barrier
+    LSlot<T> lsl[3];
+    ls_setup<T, LW>(P, lds, wid, cpl, lsl);
+    n_ls++;
+    {
+      T p1 = T(0), p2 = T(0);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if (__any(lsl[k].act)) {
+          T a, b;
+          ls_slot(P, lsl[k], T(1), a, b);
+          p1 += a; p2 += b;
+        }
+      }
+      const int base = L_RED + 6 + 8 * (n_ls & 1);
+      lds[(base + 2 * wid) * LW] = p1;
+      lds[(base + 1 + 2 * wid) * LW] = p2;
+    }
+    TGR_STAMP(3);
     __syncthreads();
     T g1 = T(0), g2 = T(0), d0 = T(0);
 #pragma unroll
     for (int b = 0; b < 3; b++) { g1 += lds[(L_RED + 22 + 3 * b) * LW]; g2 += lds[(L_RED + 23 + 3 * b) * LW]; d0 += lds[(L_RED + 24 + 3 * b) * LW]; }
+    T d1 = g1 + g2, d2 = g2;
+    {
+      const int base = L_RED + 6 + 8 * (n_ls & 1);
+#pragma unroll
+      for (int w = 0; w < 4; w++) { d1 += lds[(base + 2 * w) * LW]; d2 += lds[(base + 1 + 2 * w) * LW]; }
+    }
     // mujoco's second stopping rule: expected improvement of this step (|d0| / 2) below tolerance
     conv = conv || !(scale * T(0.5) * abs_(d0) >= P.tol);
     conv = conv || !(d0 < T(0));  // no descent left at working precision
-    // exact line search: safeguarded Newton on phi'
+    // exact line search: safeguarded Newton on phi'; (d1, d2) is phi', phi'' at the current alpha
     T alpha = T(1), lo = T(0), hi = T(-1);
     bool ls_done = conv;
     if (ls_done) alpha = T(0);
-    T gtol = P.ls_tol * abs_(d0);
-    LSlot<T> lsl[3];
-    ls_setup<T, LW>(P, lds, wid, cpl, lsl);
-    TGR_STAMP(3);
+    const T gtol = P.ls_tol * abs_(d0);
 #pragma unroll 1
-    for (int ls = 0; ls < P.ls_iter; ls++) {
-      if (__all(ls_done)) break;
-      T d1, d2;
-      n_ls++;
-      newton_dphi<T, LW>(P, lds, wid, lsl, n_ls & 1, alpha, g1, g2, d1, d2);
-      bool ok = abs_(d1) <= gtol;
+    for (int ls = 0;; ls++) {
       if (!ls_done) {
-        if (ok) ls_done = true;
+        if (abs_(d1) <= gtol) ls_done = true;
         else {
           if (d1 < T(0)) lo = alpha; else hi = alpha;
           T na = d2 > T(0) ? alpha - d1 * rcp_(d2) : T(-1);
@@ -1242,6 +1259,9 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
           alpha = na;
         }
       }
+      if (__all(ls_done) || ls + 1 >= P.ls_iter) break;
+      n_ls++;
+      newton_dphi<T, LW>(P, lds, wid, lsl, n_ls & 1, alpha, g1, g2, d1, d2);
     }
 #ifdef TGR_DEBUG_ENV
     if (wid == 0 && (int)(blockIdx.x * LW + (threadIdx.x & 63)) == TGR_DEBUG_ENV)

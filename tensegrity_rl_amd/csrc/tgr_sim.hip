@@ -21,6 +21,9 @@
 #include "../../include/tensegrity.h"
 #include "tgr_device.h"
 
+#ifndef TGR_STAMP_BLOCKS
+#define TGR_STAMP_BLOCKS (blockIdx.x < 64)  // diagnostic build: which blocks report their phase cycles
+#endif
 namespace tgr {
 
 // ------------------------------------------------------------------ state layout
@@ -589,7 +592,7 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
 
 #ifdef TGR_STAMPS
   { long long _t = clock64(); lag.stamp[5] += _t - lag.t_last; lag.t_last = _t; }
-  if (lane == 0 && blockIdx.x < 64) for (int i = 0; i < 32; i++) atomicAdd(&k.counters[8 + wid * 32 + i], (unsigned long long)lag.stamp[i]);
+  if (lane == 0 && TGR_STAMP_BLOCKS) for (int i = 0; i < 32; i++) atomicAdd(&k.counters[8 + wid * 32 + i], (unsigned long long)lag.stamp[i]);
 #endif
   const bool w0 = wid == 0;  // one wave owns every global store
   if (lane == 0 && w0) {
