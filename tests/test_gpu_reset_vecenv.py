@@ -197,3 +197,54 @@ def test_obs_noise_matches_oracle(oracle, action, capv):
         assert abs(d[:, 18:36].std() - 0.05) < 0.006
     assert not np.allclose(diffs[0], diffs[1])  # fresh draws every observation
     env.close(); clean.close(); ob.close()
+
+
+def test_edge_cases_ragged_sizes_masks_and_bad_inputs(oracle):
+    """N = 1 and N not a multiple of the 64-env block, masked resets, wrong shapes, non-finite actions (the reference turns a
+    non-finite state into `terminated`, tensegrity_env.py:276-288; a lane never raises)."""
+    import torch
+    from tensegrity_rl_amd import TensegrityVecEnv
+    O = oracle
+    # ragged block: 65 envs = one full block + one lane; every env must equal the oracle's env with the same key
+    n = 65
+    env = TensegrityVecEnv(n, "tensegrity_env-v0", precision="f64", auto_reset=False, seed=5)
+    obs = env.reset()
+    ob = O.OracleBatch(O.make_cfg("tensegrity_env", "straight"), n, seed=5)
+    oobs = ob.reset()
+    assert np.abs(obs - oobs).max() < 2e-3
+    a = np.random.default_rng(1).uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+    oracle_to_gpu_state(ob, env)
+    o1 = env.step(a)[0]; o2 = ob.step(a, auto_reset=False)[0]
+    assert np.abs(o1 - o2).max() < 1e-5
+    # masked reset: only the chosen envs restart (new episode under their key), the others keep their state
+    st0 = env.get_state()
+    mask = np.zeros(n, dtype=np.uint8); mask[[0, 64]] = 1
+    env.reset_tensors(mask)
+    st1 = env.get_state()
+    keep = mask == 0
+    assert np.array_equal(st0["qpos"][keep], st1["qpos"][keep]) and not np.allclose(st0["qpos"][~keep], st1["qpos"][~keep])
+    assert (st1["aux"][~keep, AUX["elapsed"]] == 0).all() and (st1["aux"][~keep, AUX["episode"]] == 1).all()
+    with pytest.raises(ValueError):
+        env.reset_tensors(np.zeros(n + 1, dtype=np.uint8))
+    with pytest.raises(ValueError):
+        env.step(np.zeros((n, 5), dtype=np.float32))
+    with pytest.raises(ValueError):
+        env.step(np.zeros((n - 1, 6), dtype=np.float32))
+    env.close(); ob.close()
+    # a single env, fp32, auto-reset: non-finite actions poison the state -> terminated, restarted, finite again
+    e1 = TensegrityVecEnv(1, "tensegrity_env-v0", seed=2)
+    e1.reset()
+    bad = np.full((1, 6), np.nan, dtype=np.float32)
+    obs, rew, dones, infos = e1.step(bad)
+    assert dones[0] and "terminal_observation" in infos[0] and np.isfinite(obs).all()
+    obs, rew, dones, infos = e1.step(np.full((1, 6), -0.2, dtype=np.float32))
+    assert np.isfinite(obs).all() and np.isfinite(rew).all()
+    e1.close()
+    # device-tensor API rejects tensors of the wrong shape as well
+    e2 = TensegrityVecEnv(3, "tr_env-v0", seed=2)
+    e2.reset_tensors()
+    with pytest.raises(ValueError):
+        e2.step_tensors(torch.zeros((3, 7), device="cuda"))
+    out = e2.step_tensors(torch.zeros((3, 6), device="cuda", dtype=torch.float64))  # wrong dtype is converted, not rejected
+    assert torch.isfinite(out[0]).all()
+    e2.close()
