@@ -49,6 +49,16 @@ def cpu_baseline(seconds, envs):
     except AttributeError:
         cores = os.cpu_count() or 1
     threads = max(1, min(cores, 16))  # the GPU box grants a 16-core share per GPU
+    try:  # the real engine when the box has it (it does not this round), else the CPU restatement below
+        from oracle import mujoco_check
+        if mujoco_check.available():
+            import mujoco
+            rate = mujoco_check.mujoco_rate(seconds, threads)
+            return {"value": rate, "unit": "env-steps/s", "cores": threads, "kind": "reference",
+                    "sample": f"mujoco {mujoco.__version__}, MJCF generated from the constants table (oracle/mjcf.py), {threads} processes x "
+                              f"{seconds:.0f} s of mj_step(nstep=20) + mj_rnePostConstraint with random actions"}
+    except Exception:
+        pass
     envs = 4 * threads
     ob = O.OracleBatch(O.make_cfg("tensegrity_env", "straight"), envs, seed=1234, threads=threads)
     ob.reset()

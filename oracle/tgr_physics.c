@@ -73,6 +73,10 @@ static const int TEN[TGO_NTEN][4] = {
     {1, 2, 2, 3}, /* td_8 h25-h52 */
 };
 
+/* table access for tooling (oracle/mjcf.py emits an MJCF from these constants) */
+void tgo_site_sign(int s, double out[3]) { for (int i = 0; i < 3; i++) out[i] = SITE_SGN[s][i]; }
+void tgo_tendon_ends(int t, int out[4]) { for (int i = 0; i < 4; i++) out[i] = TEN[t][i]; }
+
 void tgo_default_model(tgo_model* m) {
   memset(m, 0, sizeof(*m));
   m->timestep = 0.001;

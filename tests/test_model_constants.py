@@ -1,0 +1,116 @@
+"""Model constants: every number of the MJCF generated from the oracle's constants table (oracle/mjcf.py) is
+compared with the reference's own XML.  The reference is only present in the build container -- the test skips elsewhere;
+the constants themselves are what the HIP kernels and the oracle share (tests/test_abi_cpu.py checks tgr_default_config
+against the oracle's table)."""
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+
+REF_XML = "/root/reference/3prism_jonathan_steady_side.xml"
+
+
+def nums(s):
+    return np.array([float(v) for v in s.split()])
+
+
+@pytest.mark.skipif(not os.path.exists(REF_XML), reason="reference XML only exists in the build container")
+def test_generated_mjcf_matches_reference_xml(oracle):
+    from oracle import mjcf
+    mine = ET.fromstring(mjcf.emit_mjcf())
+    ref = ET.parse(REF_XML).getroot()
+    # options
+    mo, ro = mine.find("option"), ref.find("option")
+    for k in ("cone", "solver", "integrator", "iterations"):
+        assert mo.get(k) == ro.get(k), k
+    for k in ("timestep", "gravity", "impratio"):
+        np.testing.assert_allclose(nums(mo.get(k)), nums(ro.get(k)), atol=0)
+    assert ro.find("flag").get("frictionloss") == mo.find("flag").get("frictionloss") == "disable"
+    # geom / actuator defaults
+    mg, rg = mine.find("default/geom"), ref.find("default/geom")
+    for k in ("solref", "friction"):
+        np.testing.assert_allclose(nums(mg.get(k)), nums(rg.get(k)), atol=0)
+    assert mg.get("condim") == rg.get("condim") == "6" and rg.get("solimp") is None  # mujoco default (0.9 0.95 0.001 0.5 2)
+    np.testing.assert_allclose(nums(mg.get("solimp")), [0.9, 0.95, 0.001, 0.5, 2])
+    ma, ra = mine.find("default/general"), ref.find("default/general")
+    for k in ("ctrlrange", "gainprm", "biasprm", "forcerange"):
+        np.testing.assert_allclose(nums(ma.get(k)), nums(ra.get(k)), atol=0)
+    for k in ("dyntype", "biastype", "ctrllimited", "forcelimited"):
+        assert ma.get(k) == ra.get(k), k
+    # floor
+    assert [g.get("type") for g in ref.find("worldbody").findall("geom")] == ["plane"]
+    # bodies: pose, geoms (as sets of (type, size, placement, mass)), tendon anchor sites by name -> (body, local pos)
+    def geomkey(g):
+        place = tuple(np.round(nums(g.get("fromto")), 9)) if g.get("fromto") else tuple(np.round(nums(g.get("pos", "0 0 0")), 9))
+        return (g.get("type"), tuple(np.round(nums(g.get("size")), 9)), place, float(g.get("mass")))
+    rsites, msites = {}, {}
+    mb, rb = mine.find("worldbody").findall("body"), ref.find("worldbody").findall("body")
+    assert len(mb) == len(rb) == 3
+    for i, (a, b) in enumerate(zip(mb, rb)):
+        np.testing.assert_allclose(nums(a.get("pos")), nums(b.get("pos")), atol=0)
+        np.testing.assert_allclose(nums(a.get("quat")), nums(b.get("quat")), atol=0)
+        assert sorted(map(geomkey, a.findall("geom"))) == sorted(map(geomkey, b.findall("geom")))
+        assert b.find("freejoint") is not None and a.find("freejoint") is not None
+        for s in b.findall("site"):
+            rsites[s.get("name")] = (i, tuple(np.round(nums(s.get("pos")), 9)))
+        for s in a.findall("site"):
+            msites[s.get("name")] = (i, tuple(np.round(nums(s.get("pos")), 9)))
+    # tendons: same bars and anchor points, in the same order; passive parameters
+    mt, rt = mine.find("tendon").findall("spatial"), ref.find("tendon").findall("spatial")
+    assert len(mt) == len(rt) == 9
+    for a, b in zip(mt, rt):
+        ea = [msites[s.get("site")] for s in a.findall("site")]
+        eb = [rsites[s.get("site")] for s in b.findall("site")]
+        assert ea == eb, (a.get("name"), ea, eb)
+        for k in ("springlength", "stiffness", "damping"):
+            assert (a.get(k) is None) == (b.get(k) is None), (a.get("name"), k)
+            if a.get(k) is not None:
+                assert float(a.get(k)) == float(b.get(k))
+    # actuators: six `general` on td_0..td_5, in order
+    assert [x.get("tendon") for x in mine.find("actuator").findall("general")] == [x.get("tendon") for x in ref.find("actuator").findall("general")]
+    assert [x.get("tendon") for x in mine.find("actuator").findall("general")] == [f"td_{i}" for i in range(6)]
+
+
+def test_generated_mjcf_is_consistent_with_the_oracle_model(oracle):
+    """runs everywhere: the document is well formed and carries the derived mass / inertia the oracle integrates with"""
+    from oracle import mjcf
+    O = oracle
+    m = O.default_model()
+    root = ET.fromstring(mjcf.emit_mjcf(m))
+    body = root.find("worldbody").findall("body")[0]
+    mass = sum(float(g.get("mass")) for g in body.findall("geom"))
+    assert abs(mass - m.mass) < 1e-12
+    # inertia of the same geoms about the body origin (solid cylinder / sphere formulas), as mujoco's inertiafromgeom does
+    Ixx = Izz = 0.0
+    for g in body.findall("geom"):
+        mg = float(g.get("mass")); size = nums(g.get("size"))
+        if g.get("type") == "sphere":
+            z = nums(g.get("pos"))[2]; I = 0.4 * mg * size[0] ** 2
+            Ixx += I + mg * z * z; Izz += I
+        else:
+            if g.get("fromto"):
+                ft = nums(g.get("fromto")); half = abs(ft[5] - ft[2]) / 2; z = (ft[5] + ft[2]) / 2; r = size[0]
+            else:
+                r, half, z = size[0], size[1], 0.0
+            Ixx += mg * (3 * r * r + (2 * half) ** 2) / 12 + mg * z * z; Izz += mg * r * r / 2
+    assert abs(Ixx - m.inertia[0]) < 1e-12 and abs(Izz - m.inertia[2]) < 1e-12
+
+
+def test_hip_library_defaults_equal_the_oracle_table(oracle):
+    """tgr_default_config (what the HIP kernels are parameterised with) against the oracle's constants, field by field"""
+    from tensegrity_rl_amd import _native as N
+    O = oracle
+    m = O.default_model()
+    for kind in (N.ENV_TENSEGRITY, N.ENV_TR):
+        c = N.default_config(kind, "straight")
+        assert c.timestep == m.timestep and c.gravity == m.gravity and c.cap_radius == m.cap_radius
+        assert list(c.solref) == list(m.solref) and list(c.solimp) == list(m.solimp) and c.impratio == m.impratio
+        assert list(c.friction) == [m.friction[0], m.friction[2], m.friction[3]]
+        assert c.gain == m.gain and list(c.bias) == [m.bias0, m.bias1, m.bias2]
+        assert list(c.force_range) == [m.force_lo, m.force_hi] and list(c.ctrl_range) == [m.ctrl_lo, m.ctrl_hi]
+        for t in range(9):
+            assert c.ten_stiffness[t] == m.ten_stiffness[t] and c.ten_damping[t] == m.ten_damping[t]
+            if m.ten_stiffness[t]:
+                assert c.ten_springlength[t] == m.ten_springlen[t]
+        assert c.frame_skip == 20 and c.max_episode_steps == 5000
