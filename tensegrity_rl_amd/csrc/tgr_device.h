@@ -1047,8 +1047,8 @@ template <typename T, int LW> TGR_DEV void warm_from_lds(Sim<T>& S, const T* lds
 }
 
 // base phase of bar B (see substep): kinematic columns, attached tendons, a0, floor caps, bar pair B
-template <typename T, int LW, int B>
-TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* lds, bool last, Lag<T>& lag) {
+template <typename T, int LW, int B, bool last>
+TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* lds, Lag<T>& lag) {
   const T im = rcp_(P.mass);
   st3<T, LW>(lds, L_EZ + 3 * B, R[B].ez);
   st3<T, LW>(lds, L_X + 3 * B, S.x[B]);
@@ -1135,8 +1135,10 @@ TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* l
 
 // ------------------------------------------------------------------ the sub-step
 // lds: this lane's column base (lds_block + lane); needs L_TOTAL slots of pitch LW
-template <typename T, int LW>
-TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, Lag<T>& lag) {
+// `last` is a template parameter: what only the last sub-step records (lagged kinematics, tendon lengths, contact wrench)
+// would otherwise be carried through all twenty iterations of the caller's loop as live registers
+template <typename T, int LW, bool last>
+TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, Lag<T>& lag) {
   const T im = rcp_(P.mass);
   TGR_STAMP(7);
   __syncthreads();  // every wave is done with the previous sub-step's columns
@@ -1157,9 +1159,9 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, bool last, 
       for (int i = 0; i < 4; i++) lag.q[b][i] = S.q[b][i];
     }
   }
-  if (wid == 0) base_bar<T, LW, 0>(P, S, R, lds, last, lag);
-  else if (wid == 1) base_bar<T, LW, 1>(P, S, R, lds, last, lag);
-  else if (wid == 2) base_bar<T, LW, 2>(P, S, R, lds, last, lag);
+  if (wid == 0) base_bar<T, LW, 0, last>(P, S, R, lds, lag);
+  else if (wid == 1) base_bar<T, LW, 1, last>(P, S, R, lds, lag);
+  else if (wid == 2) base_bar<T, LW, 2, last>(P, S, R, lds, lag);
   TGR_STAMP(0);
   __syncthreads();  // the columns of this sub-step are complete
   T nact = T(0);  // the flags are 0/1: one batch of reads and a sum (a short-circuit `||` would expose twelve LDS round trips)

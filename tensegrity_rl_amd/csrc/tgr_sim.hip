@@ -554,28 +554,13 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
   } else {
     load_sim(k.st, m, e, S);
   }
-  T action[6];
   if (live) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) action[i] = T(k.actions[e * 6 + i]);
-    if (E.env_kind == TGR_ENV_TR) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) S.ctrl[i] = S.ctrl[i] + (action[i] - S.ctrl[i]) * E.dt;  // _action_filter, k_FILTER = 1
-    } else {
-#pragma unroll
-      for (int i = 0; i < 6; i++) S.ctrl[i] = action[i];
+    for (int i = 0; i < 6; i++) {
+      const T a = T(k.actions[e * 6 + i]);
+      S.ctrl[i] = E.env_kind == TGR_ENV_TR ? S.ctrl[i] + (a - S.ctrl[i]) * E.dt : a;  // tr_env: _action_filter, k_FILTER = 1
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 6; i++) action[i] = S.ctrl[i];  // settling: constant tendon targets
   }
-  T xy_bx = k.st[(F_XYLAG + 0) * m + e], xy_by = k.st[(F_XYLAG + 1) * m + e];
-  T reset_psi = k.st[F_RESETPSI * m + e];
-  T ep_ret = k.st[F_EPRET * m + e];
-  int step_num = k.ist[I_STEPNUM * m + e], elapsed = k.ist[I_ELAPSED * m + e];
-  RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
-  ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
-  ModeState<T> ms = load_modes(k.st, k.ist, m, e);
 
   Lag<T> lag;
   lag.cfrc_absmax = T(0); lag.cfrc_clip_sq = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
@@ -588,12 +573,30 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
 #endif
   warm_to_lds<T, LW>(S, lds, wid);
 #pragma unroll 1
-  for (int s = 0; s < E.frame_skip; s++) substep<T, LW>(P, S, lds, wid, s == E.frame_skip - 1, lag);
+  for (int s = 0; s + 1 < E.frame_skip; s++) substep<T, LW, false>(P, S, lds, wid, lag);
+  substep<T, LW, true>(P, S, lds, wid, lag);
 
 #ifdef TGR_STAMPS
   { long long _t = clock64(); lag.stamp[5] += _t - lag.t_last; lag.t_last = _t; }
   if (lane == 0 && TGR_STAMP_BLOCKS) for (int i = 0; i < 32; i++) atomicAdd(&k.counters[8 + wid * 32 + i], (unsigned long long)lag.stamp[i]);
 #endif
+  // everything the epilogue needs and the physics did not is (re)read only now: a value held across the twenty sub-steps
+  // costs a register there, or a scratch round trip
+  T action[6];
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) action[i] = T(k.actions[e * 6 + i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; i++) action[i] = S.ctrl[i];  // settling: constant tendon targets
+  }
+  T xy_bx = k.st[(F_XYLAG + 0) * m + e], xy_by = k.st[(F_XYLAG + 1) * m + e];
+  T reset_psi = k.st[F_RESETPSI * m + e];
+  T ep_ret = k.st[F_EPRET * m + e];
+  int step_num = k.ist[I_STEPNUM * m + e], elapsed = k.ist[I_ELAPSED * m + e];
+  RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
+  ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
+  ModeState<T> ms = load_modes(k.st, k.ist, m, e);
   const bool w0 = wid == 0;  // one wave owns every global store
   if (lane == 0 && w0) {
     atomicAdd(&k.counters[3], (unsigned long long)lag.n_it);
@@ -728,7 +731,8 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void settle_kern
 #pragma unroll 1
   for (int st = 0; st < total; st++) {
 #pragma unroll 1
-    for (int s = 0; s < E.frame_skip; s++) substep<T, LW>(P, S, lds, wid, s == E.frame_skip - 1, lag);
+    for (int s = 0; s + 1 < E.frame_skip; s++) substep<T, LW, false>(P, S, lds, wid, lag);
+    substep<T, LW, true>(P, S, lds, wid, lag);
     if (valid) settle_period_done(P, E, lag, st, ring, step_num, reset_psi, ms, xy_prev, lane_key(E, n, e), (unsigned long long)(unsigned)episode);
   }
   if (!valid || wid != 0) return;
