@@ -411,42 +411,6 @@ template <typename T> TGR_DEV void chol6(T* D, const T* ref) {
     }
   }
 }
-// O <- O L^-T   (O full 6x6 row-major, L packed lower with inverse diagonal)
-template <typename T> TGR_DEV void trsm6(T* O, const T* L) {
-#pragma unroll
-  for (int r = 0; r < 6; r++)
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      T s = O[r * 6 + j];
-#pragma unroll
-      for (int k = 0; k < j; k++) s -= O[r * 6 + k] * L[tri(j, k)];
-      O[r * 6 + j] = s * L[tri(j, j)];
-    }
-}
-// D -= O O^T (lower)
-template <typename T> TGR_DEV void syrk6(T* D, const T* O) {
-#pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int j = 0; j <= i; j++) {
-      T s = T(0);
-#pragma unroll
-      for (int k = 0; k < 6; k++) s += O[i * 6 + k] * O[j * 6 + k];
-      D[tri(i, j)] -= s;
-    }
-}
-// O2 -= Oa Ob^T
-template <typename T> TGR_DEV void gemm6(T* O2, const T* Oa, const T* Ob) {
-#pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      T s = T(0);
-#pragma unroll
-      for (int k = 0; k < 6; k++) s += Oa[i * 6 + k] * Ob[j * 6 + k];
-      O2[i * 6 + j] -= s;
-    }
-}
 template <typename T> TGR_DEV void fsolve6(const T* L, T* x) {  // x <- L^-1 x
 #pragma unroll
   for (int i = 0; i < 6; i++) {
@@ -465,20 +429,6 @@ template <typename T> TGR_DEV void bsolve6(const T* L, T* x) {  // x <- L^-T x
     x[i] = s * L[tri(i, i)];
   }
 }
-template <typename T> TGR_DEV void gemv_sub(const T* O, const T* x, T* y) {  // y -= O x
-#pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int k = 0; k < 6; k++) y[i] -= O[i * 6 + k] * x[k];
-}
-template <typename T> TGR_DEV void gemvT_sub(const T* O, const T* x, T* y) {  // y -= O^T x
-#pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int k = 0; k < 6; k++) y[i] -= O[k * 6 + i] * x[k];
-}
-
-// small dense helpers for the 9x9 Woodbury system (registers)
 template <typename T, int NN> TGR_DEV void chol_factor(T* H) {
 #pragma unroll
   for (int j = 0; j < NN; j++) {
@@ -682,11 +632,14 @@ TGR_DEV int pair_O(int p) { return p == 0 ? H_O10 : (p == 1 ? H_O20 : H_O21); }
 
 // ------------------------------------------------------------------ Newton pieces (LDS-centric, 4 waves per block)
 // The 64 envs of a block are worked on by FOUR wavefronts; lane i of every wave is env i, and the LDS columns are
-// shared.  All four waves hold the same per-lane registers (they run the cheap phases redundantly) and split the
-// contact solve:   wave 0,1,2 = bar 0,1,2 (own 6x6 diagonal block, own floor caps, gradient rows)
-//                  wave 3     = the off-diagonal (bar-pair) blocks and the pair slots of the line search
+// shared.  All four waves hold the lane's rigid-body state in registers (each integrates it, identically) and split the
+// rest:   wave 0,1,2 = bar 0,1,2: base phase of the bar (kinematic columns, attached tendons, floor caps, one bar pair),
+//                      its 6x6 diagonal Hessian block, its gradient rows, its share of the line-search slots
+//         wave 3     = the off-diagonal (bar-pair) blocks and the second pair slots of the line search
+//         wave 0     = additionally the dense factorisation / solve of the coupled 18x18 system
 // Every decision that steers control flow is computed from shared LDS data, so it is identical in the four waves and
-// the __syncthreads() below are reached uniformly.
+// the __syncthreads() below are reached uniformly.  Every LDS column has ONE writer: two template instantiations of the
+// same formula may round differently, so "both write the same value" would be a race.
 
 // which pairs touch bar b, and as which body:  pair p = (A,B): (0,1), (0,2), (1,2)
 TGR_DEV int bar_pair(int b, int j) { return b == 0 ? j : (b == 1 ? (j == 0 ? 0 : 2) : (j == 0 ? 1 : 2)); }
