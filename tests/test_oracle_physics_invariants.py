@@ -1,0 +1,94 @@
+"""Physical invariants of the restated dynamics that hold whatever MuJoCo does (so they test the physics, not the parity):
+free flight of the three tendon-coupled bars far above the floor.  Tendon and bar-bar contact forces are internal, so the
+total linear momentum follows gravity exactly and the angular momentum about the centre of mass is conserved; at constant
+tendon targets every tendon is a (possibly one-sided, saturating) spring with a damper, so the mechanical energy decays.
+The same rollouts on the GPU (fp64) are compared with the oracle state by state in tests/test_gpu_parity.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def quat_to_mat(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def momenta(m, qpos, qvel):
+    """total mass, COM, linear momentum, angular momentum about the COM (qvel: world linear, body-frame angular)"""
+    M = 3 * m.mass
+    I = np.diag(np.array(m.inertia))
+    x = qpos.reshape(3, 7)[:, :3]; q = qpos.reshape(3, 7)[:, 3:]
+    v = qvel.reshape(3, 6)[:, :3]; wb = qvel.reshape(3, 6)[:, 3:]
+    com = x.mean(axis=0)
+    P = m.mass * v.sum(axis=0)
+    L = np.zeros(3)
+    for b in range(3):
+        R = quat_to_mat(q[b])
+        L += np.cross(x[b] - com, m.mass * v[b]) + R @ (I @ wb[b])
+    return M, com, P, L
+
+
+def energy(m, d, O):
+    qpos, qvel = O.arr(d.qpos), O.arr(d.qvel)
+    I = np.array(m.inertia)
+    v = qvel.reshape(3, 6)[:, :3]; wb = qvel.reshape(3, 6)[:, 3:]
+    kin = 0.5 * m.mass * (v ** 2).sum() + 0.5 * (I * wb ** 2).sum()
+    pot = m.mass * m.gravity * qpos.reshape(3, 7)[:, 2].sum()
+    L = O.arr(d.ten_length)
+    k = np.array(m.ten_stiffness); L0 = np.array(m.ten_springlen)
+    spring = 0.5 * (k * (L - L0) ** 2).sum()
+    # actuated tendons at constant ctrl: force = -clamp(ka (L - Lref) + ba Ldot, 0, fmax) -- a one-sided, saturating spring with
+    # a damper.  Its elastic part has the potential U below; since clamp is monotone the damper part only ever dissipates.
+    ka, fmax = -m.bias1, -m.force_lo
+    s_ = ka * (L[:6] - (m.gain * O.arr(d.ctrl) + m.bias0) / ka)
+    U = np.where(s_ <= 0, 0.0, np.where(s_ <= fmax, 0.5 * s_ ** 2 / ka, 0.5 * fmax ** 2 / ka + fmax * (s_ - fmax) / ka))
+    return kin + pot + spring + U.sum()
+
+
+def free_flight(O, seed, h, t_end):
+    Lb = O.lib()
+    m = O.default_model()
+    m.timestep = h
+    d = O.new_data(m)
+    rng = np.random.default_rng(seed)
+    qpos = np.array(m.qpos0).copy()
+    qpos.reshape(3, 7)[:, 2] += 5.0                       # far above the floor: no floor contact during the test
+    O.arr(d.qpos)[:] = qpos
+    O.arr(d.qvel)[:] = rng.normal(0, 0.5, 18)             # tumbling, bars moving against each other
+    O.arr(d.ctrl)[:] = rng.uniform(-0.3, 0.15, 6)         # constant tendon targets
+    Lb.tgo_forward(C.byref(m), C.byref(d))
+    M, com0, P0, L0 = momenta(m, O.arr(d.qpos).copy(), O.arr(d.qvel).copy())
+    E_prev = E0 = energy(m, d, O)
+    n = int(round(t_end / h))
+    for k in range(n):
+        Lb.tgo_step(C.byref(m), C.byref(d), 1)
+        Lb.tgo_forward(C.byref(m), C.byref(d))            # refresh the derived quantities (tendon lengths) for the energy
+        assert all(d.con[i].body1 >= 0 for i in range(d.ncon))  # only bar-bar contacts, if any
+        E = energy(m, d, O)
+        assert E <= E_prev + 1e-6 * abs(E0), (k, E - E_prev)
+        E_prev = E
+    _, com1, P1, L1 = momenta(m, O.arr(d.qpos).copy(), O.arr(d.qvel).copy())
+    return dict(m=m, M=M, n=n, com0=com0, com1=com1, P0=P0, P1=P1, L0=L0, L1=L1, E0=E0, E1=E_prev)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_free_flight_momentum_and_energy(oracle, seed):
+    O = oracle
+    r = free_flight(O, seed, 0.001, 0.2)
+    m, M, n, h = r["m"], r["M"], r["n"], 0.001
+    t = n * h
+    # linear momentum: exact up to rounding (internal forces cancel row by row, also inside the implicit damping solve)
+    np.testing.assert_allclose(r["P1"], r["P0"] + np.array([0, 0, -M * m.gravity * t]), atol=1e-9)
+    # centre of mass: semi-implicit Euler parabola  z = z0 + v0 t - g h^2 n(n+1)/2
+    zc = r["com0"][2] + r["P0"][2] / M * t - m.gravity * h * h * n * (n + 1) / 2
+    np.testing.assert_allclose(r["com1"], [r["com0"][0] + r["P0"][0] / M * t, r["com0"][1] + r["P0"][1] / M * t, zc], atol=1e-9)
+    assert r["E1"] < r["E0"]  # the tendons did dissipate
+    # angular momentum about the COM is conserved by the forces; what drifts is the first-order time integration, so the drift
+    # is small and shrinks with the step
+    drift = np.linalg.norm(r["L1"] - r["L0"])
+    r2 = free_flight(O, seed, 0.0005, 0.2)
+    drift2 = np.linalg.norm(r2["L1"] - r2["L0"])
+    assert drift < 5e-2 * max(np.linalg.norm(r["L0"]), 1.0) and 0.35 * drift < drift2 < 0.7 * drift, (drift, drift2)
