@@ -175,7 +175,7 @@ def main():
                                  "not HBM bound: see DESIGN.md",
                          "kernel_ms": kern_ms, "kernel_ms_p50": step_ms[len(step_ms) // 2]},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed once: rank 0 of the one-GPU run
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 64)
             except Exception as e:  # the oracle is test infrastructure; never let it break the bench line

@@ -961,7 +961,7 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   Params<T>& P = k.P;
   P.h = T(c.timestep); P.grav = T(c.gravity);
   // inertiafromgeom with explicit geom masses (xml:72-78): cylinder 1.0, two spheres 0.5, two cylinders 1.0
-  const double half = 0.688, rr = 0.0381, rs = 0.0675, rb = 0.035, blo = 0.238, bhi = 0.688;
+  const double half = 0.688, rr = 0.0381, rs = c.cap_radius, rb = 0.035, blo = 0.238, bhi = 0.688;
   double L = 2 * half;
   double Ixx = 1.0 * (3 * rr * rr + L * L) / 12.0, Izz = 1.0 * rr * rr / 2.0;
   double Is = 0.4 * 0.5 * rs * rs;
