@@ -980,7 +980,7 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   P.f0 = T(c.friction[0]); P.f1sq = T(c.friction[0] * c.friction[0]); P.f3sq = T(c.friction[1] * c.friction[1]);
   P.f4sq = T(c.friction[2] * c.friction[2]); P.impratio = T(c.impratio);
   P.invweight = T(0.25);
-  double tol = c.solver_tolerance > 0 ? c.solver_tolerance : (sizeof(T) == 4 ? 1e-5 : 1e-11);
+  double tol = c.solver_tolerance > 0 ? c.solver_tolerance : (sizeof(T) == 4 ? 3e-6 : 1e-11);  // fp32: accuracy/speed trade-off measured in DESIGN.md section 4
   P.tol = T(tol); P.ls_tol = T(0.01);
   P.max_iter = c.solver_iterations > 0 ? c.solver_iterations : (sizeof(T) == 4 ? 8 : 40);
   P.ls_iter = sizeof(T) == 4 ? 6 : 50;

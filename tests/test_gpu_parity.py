@@ -73,7 +73,7 @@ def test_fp32_within_stated_tolerance(oracle, kind, action):
     rows, stats = _run(oracle, kind, action, "f32", 256, 5)
     for r in rows:
         assert np.median(r["qpos"]) < 1e-5 and r["qpos"].max() < 3e-2       # 1e-4 relative for qpos: all but chatter cases
-        assert np.mean(r["qpos"] < 1e-4) > 0.93
+        assert np.mean(r["qpos"] < 1e-4) > 0.96
         # BASELINE.json: 1e-4 relative for the typical env.  tr_env envs sit almost at rest (|qvel| ~ 0.05), where the same
         # absolute fp32 error (~3e-5, concentrated in the spin about the bar axis, inertia 0.0038 kg m^2) reads 3x larger
         assert np.median(r["qvel"]) < (1e-4 if kind == "tensegrity_env" else 3e-4)
