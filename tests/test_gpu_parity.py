@@ -110,3 +110,33 @@ def test_reward_obs_epilogue_against_reference_fixture(oracle, golden_dir):
                 xy = np.array([g["x_position"][k], g["y_position"][k]])
                 k += 1
         env.close()
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f64", 1e-9)])
+def test_full_size_free_flight_follows_the_ballistic_parabola(prec, tol):
+    """BASELINE size (N = 4096), no oracle involved: robots thrown far above the floor.  Tendon and bar-bar forces are
+    internal, so every robot's centre of mass must follow the semi-implicit-Euler parabola exactly (up to rounding) and its
+    total linear momentum only changes by gravity -- for all 4096 envs, whatever the tendons and bar contacts do."""
+    from tensegrity_rl_amd import TensegrityVecEnv
+    n, periods = 4096, 5
+    env = TensegrityVecEnv(n, "tensegrity_env-v0", precision=prec, auto_reset=False, seed=3)
+    env.reset_tensors()
+    st = env.get_state()
+    rng = np.random.default_rng(0)
+    qpos = st["qpos"].copy(); qpos.reshape(n, 3, 7)[:, :, 2] += 5.0
+    qvel = rng.normal(0, 0.5, (n, 18))
+    env.set_state(qpos=qpos, qvel=qvel)
+    st0 = env.get_state()                                   # what the device really holds (fp32 rounding of the inputs)
+    x0 = st0["qpos"].reshape(n, 3, 7)[:, :, :3].mean(axis=1); v0 = st0["qvel"].reshape(n, 3, 6)[:, :, :3].mean(axis=1)
+    a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+    for _ in range(periods):
+        env.step_tensors(a)
+    st1 = env.get_state()
+    x1 = st1["qpos"].reshape(n, 3, 7)[:, :, :3].mean(axis=1); v1 = st1["qvel"].reshape(n, 3, 6)[:, :, :3].mean(axis=1)
+    h, k = 0.001, 20 * periods
+    t = h * k
+    g = 9.81
+    x_ref = x0 + v0 * t; x_ref[:, 2] -= g * h * h * k * (k + 1) / 2
+    v_ref = v0.copy(); v_ref[:, 2] -= g * t
+    assert np.abs(v1 - v_ref).max() < tol * 10 and np.abs(x1 - x_ref).max() < tol * 10, (np.abs(v1 - v_ref).max(), np.abs(x1 - x_ref).max())
+    env.close()
