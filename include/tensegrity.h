@@ -106,12 +106,26 @@ typedef struct tgr_config {
    * observation index within the episode), i.e. same distribution, reproducible */
   int32_t use_obs_noise;
   double obs_noise_tendon_stdev, obs_noise_cap_pos_stdev; /* 0.02, 0.05 */
+  /* --- model variant (the reference selects it with xml_file): 0 = 3prism_jonathan_steady_side.xml (flat floor),
+   * 1 = 3prism_jonathan_steady_side_uneven_ground.xml (tgr_uneven_config fills the fields that differ: caps 0.05, tendon site
+   * layout, nine passive tendons, dyntype=filter actuators, initial pose, heightfield floor -- upload the elevations with
+   * tgr_set_hfield before the first reset) */
+  int32_t model_kind;
+  double site_offset;     /* radial offset of the tendon sites (0.0675 / 0.05) */
+  double act_tau;         /* dynprm[0] of the filter actuators */
+  double hf_size[4];      /* heightfield: radius_x, radius_y, elevation_z, base_z (uneven xml:48) */
+  double hf_pos[3];       /* position of the heightfield geom (uneven xml:56) */
 } tgr_config;
 
 typedef struct tgr_handle tgr_handle;
 
 /* fills *cfg with the reference defaults of the given env class / desired_action */
 int tgr_default_config(tgr_config* cfg, int env_kind, int desired_action);
+/* switches an already filled *cfg to the uneven-ground model (what xml_file=..._uneven_ground.xml selects in the reference) */
+int tgr_uneven_config(tgr_config* cfg);
+/* heightfield of model_kind 1: normalised elevations in [0,1], host pointer, [nrow][ncol], row 0 at y = -radius_y, column 0 at
+ * x = -radius_x (mujoco's hfield_data layout [ext]); copied to the device */
+int tgr_set_hfield(tgr_handle* h, const float* heights_host, int nrow, int ncol);
 int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_handle** out);
 int tgr_destroy(tgr_handle* h);
 int tgr_num_envs(const tgr_handle* h);
@@ -132,12 +146,13 @@ int tgr_step_f64(tgr_handle* h, const float* actions, double* obs, double* rewar
 
 /* HOST arrays, any may be NULL: qpos[N][21], qvel[N][18] (MuJoCo convention: world linear,
  * body-frame angular), ctrl[N][6], qacc_warmstart[N][18], aux[N][TGR_AUX_K] */
-#define TGR_AUX_K 17
+#define TGR_AUX_K 23
 enum {
   TGR_AUX_XY_LAG_X = 0, TGR_AUX_XY_LAG_Y, TGR_AUX_PSI_LAG, TGR_AUX_RESET_PSI, TGR_AUX_EP_RETURN,
   TGR_AUX_STEP_NUM, TGR_AUX_ELAPSED, TGR_AUX_EPISODE, TGR_AUX_RING_LEN, TGR_AUX_WAYPT_X, TGR_AUX_WAYPT_Y,
   TGR_AUX_ORI_X, TGR_AUX_ORI_Y, TGR_AUX_VCMD_X, TGR_AUX_VCMD_Y, TGR_AUX_VCMD_W,
-  TGR_AUX_SRC /* lane whose RNG key produced the current episode: the env itself or a donor lane; TGR_AUX_EPISODE is the episode index under that key */
+  TGR_AUX_SRC, /* lane whose RNG key produced the current episode: the env itself or a donor lane; TGR_AUX_EPISODE is the episode index under that key */
+  TGR_AUX_ACT = 17 /* ..22: actuator activations (model_kind 1) */
 };
 int tgr_get_state(tgr_handle* h, double* qpos, double* qvel, double* ctrl, double* qacc_warmstart, double* aux);
 /* set_state: like MujocoEnv.set_state it also recomputes the derived (lagged) kinematics from qpos;

@@ -29,7 +29,9 @@ class Model(C.Structure):
                 ("ten_springlen", d * NTEN), ("gain", d), ("bias0", d), ("bias1", d), ("bias2", d), ("force_lo", d),
                 ("force_hi", d), ("ctrl_lo", d), ("ctrl_hi", d), ("solref", d * 2), ("solimp", d * 5),
                 ("friction", d * 5), ("impratio", d), ("actuator_deriv_skip_clamped", C.c_int),
-                ("newton_maxiter", C.c_int), ("qpos0", d * NQ)]
+                ("newton_maxiter", C.c_int), ("qpos0", d * NQ), ("model_kind", C.c_int), ("site_local", (d * 3) * 6),
+                ("ten_ends", (C.c_int * 4) * NTEN), ("act_filter", C.c_int), ("act_tau", d), ("hf_nrow", C.c_int),
+                ("hf_ncol", C.c_int), ("hf_size", d * 4), ("hf_pos", d * 3), ("hf_data", C.c_void_p)]
 
 
 class Contact(C.Structure):
@@ -45,7 +47,7 @@ class Data(C.Structure):
                 ("ten_J", (d * NV) * NTEN), ("actuator_force", d * NU), ("qfrc_passive", d * NV),
                 ("qfrc_actuator", d * NV), ("qfrc_bias", d * NV), ("qfrc_smooth", d * NV), ("qacc_smooth", d * NV),
                 ("qfrc_constraint", d * NV), ("qacc", d * NV), ("ncon", C.c_int), ("con", Contact * MAXCON),
-                ("cfrc_ext", (d * 6) * 4), ("solver_iter", C.c_int), ("flags", C.c_int)]
+                ("cfrc_ext", (d * 6) * 4), ("solver_iter", C.c_int), ("flags", C.c_int), ("act", d * NU), ("act_dot", d * NU)]
 
 
 class EnvCfg(C.Structure):
@@ -58,7 +60,8 @@ class EnvCfg(C.Structure):
                 ("waypt_angle_range", d * 2), ("ditch_reward_max", d), ("ditch_reward_stdev", d),
                 ("waypt_reward_amplitude", d), ("waypt_reward_stdev", d), ("yaw_reward_weight", d),
                 ("frame_skip", C.c_int), ("max_episode_steps", C.c_int), ("use_obs_noise", C.c_int),
-                ("obs_noise_tendon_stdev", d), ("obs_noise_cap_pos_stdev", d)]
+                ("obs_noise_tendon_stdev", d), ("obs_noise_cap_pos_stdev", d), ("model_kind", C.c_int), ("hf_nrow", C.c_int),
+                ("hf_ncol", C.c_int), ("hf_data", C.c_void_p)]
 
 
 class Env(C.Structure):
@@ -144,7 +147,21 @@ def rolling_qpos():
     return np.array((d * NQ * 6).in_dll(lib(), "tgo_rolling_qpos")).reshape(6, NQ)
 
 
-def make_cfg(env_kind="tensegrity_env", desired_action="straight", **kw):
+_keep = []  # heightfield arrays handed to C by reference
+
+
+def uneven_model(heights=None):
+    """tgo_model of the uneven-ground XML; heights: float32 [nrow, ncol] normalised elevations, or None (flat at z = -1)"""
+    m = Model()
+    if heights is None:
+        lib().tgo_uneven_model(C.byref(m), None, 0, 0)
+    else:
+        h = np.ascontiguousarray(heights, dtype=np.float32); _keep.append(h)
+        lib().tgo_uneven_model(C.byref(m), h.ctypes.data_as(C.c_void_p), h.shape[0], h.shape[1])
+    return m
+
+
+def make_cfg(env_kind="tensegrity_env", desired_action="straight", heights=None, **kw):
     c = EnvCfg()
     kind = ENV_TENSEGRITY if env_kind in ("tensegrity_env", 0) else ENV_TR
     lib().tgo_env_default_cfg(C.byref(c), kind, ACTIONS[desired_action] if isinstance(desired_action, str) else desired_action)
@@ -152,6 +169,9 @@ def make_cfg(env_kind="tensegrity_env", desired_action="straight", **kw):
         if not hasattr(c, k):
             raise KeyError(k)
         setattr(c, k, v)
+    if heights is not None:
+        h = np.ascontiguousarray(heights, dtype=np.float32); _keep.append(h)
+        c.hf_data = h.ctypes.data; c.hf_nrow, c.hf_ncol = h.shape
     return c
 
 
@@ -231,12 +251,14 @@ class OracleBatch:
         """qpos[N,21], qvel[N,18], ctrl[N,6], warm[N,18], aux dict of arrays (what the HIP path keeps per env)."""
         n = self.n
         qpos = np.zeros((n, NQ)); qvel = np.zeros((n, NV)); ctrl = np.zeros((n, NU)); warm = np.zeros((n, NV))
+        self.last_act = np.zeros((n, NU))  # actuator activations (uneven-ground model only)
         aux = {k: np.zeros(n) for k in ("xy_lag_x", "xy_lag_y", "psi_lag", "reset_psi", "step_num", "elapsed", "ep_return",
                                         "waypt_x", "waypt_y", "ori_x", "ori_y", "vcmd_x", "vcmd_y", "vcmd_w")}
         for i in range(n):
             e = self.env(i)
             qpos[i] = arr(e.data.qpos); qvel[i] = arr(e.data.qvel); ctrl[i] = arr(e.data.ctrl)
             warm[i] = arr(e.data.qacc_warmstart)
+            self.last_act[i] = arr(e.data.act)
             xp = arr(e.data.xpos)
             aux["xy_lag_x"][i] = xp[:, 0].mean(); aux["xy_lag_y"][i] = xp[:, 1].mean()
             cap = arr(e.data.cap_xpos)

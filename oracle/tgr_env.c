@@ -148,7 +148,8 @@ int tgo_env_obs_dim(const tgo_env_cfg* c) {
 void tgo_env_init(tgo_env* e, const tgo_env_cfg* c) {
   memset(e, 0, sizeof(*e));
   e->cfg = *c;
-  tgo_default_model(&e->model);
+  if (c->model_kind == 1) tgo_uneven_model(&e->model, c->hf_data, c->hf_nrow, c->hf_ncol);
+  else tgo_default_model(&e->model);
   tgo_reset_data(&e->model, &e->data);
   tgo_forward(&e->model, &e->data);
   e->x_velocity = 1; e->y_velocity = 1; /* tensegrity_env.py:204-205 */

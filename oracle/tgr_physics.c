@@ -119,6 +119,14 @@ void tgo_default_model(tgo_model* m) {
   m->impratio = 1;
   m->actuator_deriv_skip_clamped = 0;
   m->newton_maxiter = 100;
+  m->model_kind = 0;
+  for (int s_ = 0; s_ < 6; s_++) {
+    m->site_local[s_][0] = SITE_SGN[s_][0] * m->site_off; m->site_local[s_][1] = SITE_SGN[s_][1] * m->site_off;
+    m->site_local[s_][2] = SITE_SGN[s_][2] * m->site_z;
+  }
+  memcpy(m->ten_ends, TEN, sizeof(TEN));
+  m->act_filter = 0; m->act_tau = 1.0;
+  m->hf_data = NULL; m->hf_nrow = m->hf_ncol = 0;
   {
     static const double q0[TGO_NQ] = {/* xml:71,90,108 */
         0.08369179, -0.28792231, 0.24830847, -0.49145555, 0.7539914, -0.27511722, -0.33805166,
@@ -126,6 +134,55 @@ void tgo_default_model(tgo_model* m) {
         0.04557825, -0.29876206, 0.39531985, -0.35798606, -0.47531391, 0.72471075, 0.34744352};
     memcpy(m->qpos0, q0, sizeof(q0));
   }
+}
+
+/* 3prism_jonathan_steady_side_uneven_ground.xml.  Differences to the flat model: caps r = 0.05 (xml:69-70),
+ * tendon sites at 0.05 from the axis in a different arrangement (xml:76-81,94-99,112-117), all nine tendons passive
+ * spring-dampers k = 1e4, b = 1e3 with rest length 0.5 / 0.8 (xml:38,122-158), actuators dyntype=filter (tau 1 s) with
+ * gain 15000, no bias, no force limit (xml:39), other initial pose (xml:65,84,102), heightfield floor of radius 50 m,
+ * elevation 1 m, placed at z = -1 (xml:48,56). */
+void tgo_uneven_model(tgo_model* m, const float* heights, int nrow, int ncol) {
+  tgo_default_model(m);
+  m->model_kind = 1;
+  m->cap_radius = 0.05;
+  m->site_off = 0.05;
+  { /* inertia with the smaller caps */
+    double mr = 1.0, ms = 0.5, mb = 1.0;
+    double L = 2 * m->bar_half, r = m->rcyl_radius, rs = m->cap_radius;
+    double Ixx = mr * (3 * r * r + L * L) / 12.0, Izz = mr * r * r / 2.0, Is = 0.4 * ms * rs * rs;
+    Ixx += 2 * (Is + ms * m->bar_half * m->bar_half); Izz += 2 * Is;
+    double Lb = m->bcyl_hi - m->bcyl_lo, rb = m->bcyl_radius, cb = 0.5 * (m->bcyl_hi + m->bcyl_lo);
+    Ixx += 2 * (mb * (3 * rb * rb + Lb * Lb) / 12.0 + mb * cb * cb); Izz += 2 * (mb * rb * rb / 2.0);
+    m->inertia[0] = Ixx; m->inertia[1] = Ixx; m->inertia[2] = Izz;
+  }
+  /* the six site positions of a bar, in the order used by ten_ends below: (-x,+z) (+x,+z) (-y,+z) (-y,-z) (+y,-z) (+x,-z) */
+  static const double sg[6][3] = {{-1, 0, 1}, {1, 0, 1}, {0, -1, 1}, {0, -1, -1}, {0, 1, -1}, {1, 0, -1}};
+  for (int s_ = 0; s_ < 6; s_++) {
+    m->site_local[s_][0] = sg[s_][0] * m->site_off; m->site_local[s_][1] = sg[s_][1] * m->site_off; m->site_local[s_][2] = sg[s_][2] * m->site_z;
+  }
+  /* site names -> index per bar: r01: h04 h03 h02 h14 h13 h15 ; r23: h24 h20 h25 h31 h30 h35 ; r45: h41 h40 h42 h51 h53 h52 */
+  static const int te[TGO_NTEN][4] = {
+      {0, 0, 2, 1}, /* td_0 h04-h40 */ {0, 2, 1, 1}, /* td_1 h02-h20 */ {1, 0, 2, 2}, /* td_2 h24-h42 */
+      {0, 5, 2, 3}, /* td_3 h15-h51 */ {0, 4, 1, 3}, /* td_4 h13-h31 */ {1, 5, 2, 4}, /* td_5 h35-h53 */
+      {0, 3, 2, 0}, /* td_6 h14-h41 */ {0, 1, 1, 4}, /* td_7 h03-h30 */ {1, 2, 2, 5}, /* td_8 h25-h52 */
+  };
+  memcpy(m->ten_ends, te, sizeof(te));
+  for (int t = 0; t < TGO_NTEN; t++) {
+    m->ten_stiffness[t] = 10000.0; m->ten_damping[t] = 1000.0; m->ten_springlen[t] = t < 6 ? 0.5 : 0.8;
+  }
+  m->act_filter = 1; m->act_tau = 1.0;
+  m->gain = 15000.0; m->bias0 = m->bias1 = m->bias2 = 0.0;
+  m->force_lo = -1e300; m->force_hi = 1e300; /* forcelimited not set */
+  {
+    static const double q0[TGO_NQ] = {/* uneven xml:65,84,102 */
+        0.25551711, -0.00069342, 0.22404039, -0.49720971, 0.24315431, 0.75327284, -0.35530059,
+        0.14409445, 0.0654207, 0.33662589, 0.42572066, 0.01379464, -0.53972521, 0.72613244,
+        0.28544944, -0.04883333, 0.38591159, 0.137357, 0.06898275, -0.85996553, 0.48665565};
+    memcpy(m->qpos0, q0, sizeof(q0));
+  }
+  m->hf_data = heights; m->hf_nrow = nrow; m->hf_ncol = ncol;
+  m->hf_size[0] = 50; m->hf_size[1] = 50; m->hf_size[2] = 1; m->hf_size[3] = 0.1;
+  m->hf_pos[0] = 0; m->hf_pos[1] = 0; m->hf_pos[2] = -1.0;
 }
 
 void tgo_reset_data(const tgo_model* m, tgo_data* d) {
@@ -142,7 +199,7 @@ static void kinematics(const tgo_model* m, tgo_data* d) {
     quat2mat(d->xmat[b], q + 3);
     const double* R = d->xmat[b];
     for (int s = 0; s < 6; s++) {
-      double l[3] = {SITE_SGN[s][0] * m->site_off, SITE_SGN[s][1] * m->site_off, SITE_SGN[s][2] * m->site_z};
+      const double* l = m->site_local[s];
       for (int i = 0; i < 3; i++) d->site_xpos[b][s][i] = q[i] + R[3 * i] * l[0] + R[3 * i + 1] * l[1] + R[3 * i + 2] * l[2];
     }
     for (int e = 0; e < 2; e++) { /* caps s(2b) at +z, s(2b+1) at -z */
@@ -163,12 +220,11 @@ static void add_point_force(const tgo_data* d, int b, const double* p, const dou
 }
 
 static void tendons(const tgo_model* m, tgo_data* d) {
-  (void)m;
   memset(d->ten_J, 0, sizeof(d->ten_J));
   for (int t = 0; t < TGO_NTEN; t++) {
-    int ba = TEN[t][0], bb = TEN[t][2];
-    const double* pa = d->site_xpos[ba][TEN[t][1]];
-    const double* pb = d->site_xpos[bb][TEN[t][3]];
+    int ba = m->ten_ends[t][0], bb = m->ten_ends[t][2];
+    const double* pa = d->site_xpos[ba][m->ten_ends[t][1]];
+    const double* pb = d->site_xpos[bb][m->ten_ends[t][3]];
     double dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
     double len = norm3(dif);
     d->ten_length[t] = len;
@@ -310,10 +366,84 @@ static void cyl_cyl(tgo_data* d, const bgeom* A, int bA, const bgeom* B, int bB)
   add_contact(d, pos, n, dist, bA, bB, A->geom, B->geom);
 }
 
+/* closest point of triangle (a,b,c) to p (Ericson, Real-Time Collision Detection 5.1.5) */
+static void closest_on_triangle(const double* p, const double* a, const double* b, const double* c, double* out) {
+  double ab[3], ac[3], ap[3], bp[3], cp[3];
+  for (int i = 0; i < 3; i++) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
+  double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { memcpy(out, a, 24); return; }
+  for (int i = 0; i < 3; i++) bp[i] = p[i] - b[i];
+  double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { memcpy(out, b, 24); return; }
+  double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); for (int i = 0; i < 3; i++) out[i] = a[i] + v * ab[i]; return; }
+  for (int i = 0; i < 3; i++) cp[i] = p[i] - c[i];
+  double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { memcpy(out, c, 24); return; }
+  double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { double w = d2 / (d2 - d6); for (int i = 0; i < 3; i++) out[i] = a[i] + w * ac[i]; return; }
+  double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    for (int i = 0; i < 3; i++) out[i] = b[i] + w * (c[i] - b[i]);
+    return;
+  }
+  double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den;
+  for (int i = 0; i < 3; i++) out[i] = a[i] + ab[i] * v + ac[i] * w;
+}
+
+/* Cap sphere against the heightfield floor.  MuJoCo (mjc_ConvexHField [ext]) walks the grid cells under the geom's bounding
+ * box, turns every grid triangle into a prism and runs its convex penetration test on each; for a sphere that is shallowly
+ * in contact this yields, per triangle, the closest point of the triangle, the direction from it to the centre as normal and
+ * radius - distance as depth.  Restated analytically with two simplifications that DESIGN.md records: only the deepest
+ * triangle of a cap is kept (one contact per cap, as on the plane), and the cell diagonal runs from (c, r+1) to (c+1, r)
+ * (the order in which mujoco strips the vertices of a grid row).  Cylinders are not tested against the terrain. */
+static void hfield_caps(const tgo_model* m, tgo_data* d) {
+  const int nr = m->hf_nrow, nc = m->hf_ncol;
+  const double rx = m->hf_size[0], ry = m->hf_size[1], ez = m->hf_size[2];
+  const double dx = 2 * rx / (nc - 1), dy = 2 * ry / (nr - 1), rad = m->cap_radius;
+  for (int k = 0; k < 6; k++) {
+    const double* cw = d->cap_xpos[k];
+    double p[3] = {cw[0] - m->hf_pos[0], cw[1] - m->hf_pos[1], cw[2] - m->hf_pos[2]};
+    if (p[0] < -rx - rad || p[0] > rx + rad || p[1] < -ry - rad || p[1] > ry + rad || p[2] > ez + rad) continue;
+    int c0 = (int)floor((p[0] - rad + rx) / dx), c1 = (int)floor((p[0] + rad + rx) / dx);
+    int r0 = (int)floor((p[1] - rad + ry) / dy), r1 = (int)floor((p[1] + rad + ry) / dy);
+    if (c0 < 0) c0 = 0;
+    if (r0 < 0) r0 = 0;
+    if (c1 > nc - 2) c1 = nc - 2;
+    if (r1 > nr - 2) r1 = nr - 2;
+    double best = 0, bq[3] = {0, 0, 0}; int have = 0;
+    for (int r = r0; r <= r1; r++)
+      for (int c = c0; c <= c1; c++) {
+        double v[4][3]; /* (c,r) (c,r+1) (c+1,r) (c+1,r+1) */
+        for (int j = 0; j < 4; j++) {
+          int cc = c + (j >> 1), rr = r + (j & 1);
+          v[j][0] = cc * dx - rx; v[j][1] = rr * dy - ry; v[j][2] = (double)m->hf_data[rr * nc + cc] * ez;
+        }
+        for (int tri = 0; tri < 2; tri++) {
+          double q[3];
+          closest_on_triangle(p, v[tri], v[tri + 1], v[tri + 2], q);
+          double dif[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+          double dist = norm3(dif) - rad;
+          if (dist < 0 && (!have || dist < best)) { have = 1; best = dist; memcpy(bq, q, 24); }
+        }
+      }
+    if (!have) continue;
+    double n[3] = {p[0] - bq[0], p[1] - bq[1], p[2] - bq[2]};
+    double nn = norm3(n);
+    if (nn < MINVAL) { d->flags |= TGO_FLAG_DEEP; continue; }
+    for (int i = 0; i < 3; i++) n[i] /= nn;
+    double pos[3];
+    for (int i = 0; i < 3; i++) pos[i] = cw[i] - n[i] * (rad + 0.5 * best);
+    add_contact(d, pos, n, best, -1, k / 2, 0, 1 + 5 * (k / 2) + 1 + (k % 2));
+  }
+}
+
 static void collision(const tgo_model* m, tgo_data* d) {
   d->ncon = 0;
+  if (m->hf_data) hfield_caps(m, d);
   /* floor plane (geom 0, z=0, normal +z) vs the 6 cap spheres: mjc_PlaneSphere */
-  for (int b = 0; b < TGO_NBAR; b++) {
+  for (int b = 0; b < TGO_NBAR && !m->hf_data; b++) {
     for (int e = 0; e < 2; e++) {
       const double* c = d->cap_xpos[2 * b + e];
       double cdist = c[2];
@@ -441,7 +571,12 @@ static void smooth_forces(const tgo_model* m, tgo_data* d) {
   }
   for (int a = 0; a < TGO_NU; a++) {
     double ctrl = clampd(d->ctrl[a], m->ctrl_lo, m->ctrl_hi);
-    double f = m->gain * ctrl + m->bias0 + m->bias1 * d->ten_length[a] + m->bias2 * d->ten_velocity[a];
+    double in = ctrl;
+    if (m->act_filter) { /* dyntype filter: act_dot = (ctrl - act) / tau, the force sees the activation (mj_fwdActuation [ext]) */
+      d->act_dot[a] = (ctrl - d->act[a]) / fmax(MINVAL, m->act_tau);
+      in = d->act[a];
+    }
+    double f = m->gain * in + m->bias0 + m->bias1 * d->ten_length[a] + m->bias2 * d->ten_velocity[a];
     f = clampd(f, m->force_lo, m->force_hi);
     d->actuator_force[a] = f;
     for (int k = 0; k < TGO_NV; k++) d->qfrc_actuator[k] += d->ten_J[a][k] * f;
@@ -756,6 +891,8 @@ static void implicitfast_advance(const tgo_model* m, tgo_data* d) {
     mulquat(qn, q + 3, qr);
     memcpy(q + 3, qn, sizeof(qn));
   }
+  if (m->act_filter)
+    for (int a = 0; a < TGO_NU; a++) d->act[a] += h * d->act_dot[a]; /* mj_advance: explicit Euler on the activations */
   d->time += h;
 }
 

@@ -70,6 +70,11 @@ template <typename T> struct Params {
   T tol, ls_tol;
   T cf_lo, cf_hi;                         // contact_force_range of the env (for contact_cost)
   int max_iter, ls_iter, skip_clamped, warm_start;
+  // uneven-ground model only (MODEL = 1): activation filter and heightfield floor
+  T act_itau;                              // 1 / dynprm[0]
+  T hf_rx, hf_ry, hf_ez, hf_x0, hf_y0, hf_z0, hf_dx, hf_dy;
+  int hf_nrow, hf_ncol;
+  const float* hf;                         // normalised elevations [nrow][ncol] in device memory
 };
 
 // static model tables (3prism_jonathan_steady_side.xml:82-87,127-164)
@@ -79,6 +84,10 @@ struct Tab {
   // tendon: bar_a, site_a, bar_b, site_b
   static constexpr int TEN[9][4] = {{0, 1, 2, 0}, {0, 0, 1, 1}, {1, 0, 2, 1}, {0, 5, 2, 4}, {0, 4, 1, 5},
                                     {1, 4, 2, 5}, {0, 3, 2, 2}, {0, 2, 1, 3}, {1, 2, 2, 3}};
+  // 3prism_jonathan_steady_side_uneven_ground.xml:76-81,94-99,112-117,122-158 (MODEL = 1): same bars per tendon, other sites
+  static constexpr int S1[6][3] = {{-1, 0, 1}, {1, 0, 1}, {0, -1, 1}, {0, -1, -1}, {0, 1, -1}, {1, 0, -1}};
+  static constexpr int TEN1[9][4] = {{0, 0, 2, 1}, {0, 2, 1, 1}, {1, 0, 2, 2}, {0, 5, 2, 3}, {0, 4, 1, 3},
+                                     {1, 5, 2, 4}, {0, 3, 2, 0}, {0, 1, 1, 4}, {1, 2, 2, 5}};
 };
 
 // ------------------------------------------------------------------ per-lane LDS columns (slot indices)
@@ -99,6 +108,8 @@ enum : int {
   L_RED = L_X + 9,      // cross-wave partial sums and exchange slots (50)
   L_TOTAL = L_RED + 50  // 545
 };
+constexpr int L_FN = L_TOTAL;  // MODEL = 1 only: normals of the six floor contacts (18)
+template <int MODEL> constexpr __host__ __device__ int lds_slots() { return MODEL ? L_TOTAL + 18 : L_TOTAL; }
 constexpr __host__ __device__ int H_D(int b) { return L_H + 21 * b; }
 constexpr int H_O10 = L_H + 63, H_O20 = L_H + 99, H_O21 = L_H + 135;
 
@@ -111,6 +122,7 @@ template <typename T> struct Sim {
   V3<T> al[3];  // warm-start acceleration, linear
   V3<T> aa[3];  // warm-start acceleration, angular (world frame)
   T ctrl[6];
+  T act[6];     // actuator activations (MODEL = 1: dyntype filter)
 };
 
 // quantities of the forward pass of the LAST sub-step (what the reference reads after mj_step: one sub-step old)
@@ -187,10 +199,10 @@ template <typename T> TGR_DEV void contact_params(const Params<T>& P, T dist, in
   c.Dn = rcp_(R0);
   c.c0 = P.K * imp * dist;
 }
-template <typename T, int LW> TGR_DEV Contact<T> load_floor(const T* lds, int k) {
+template <typename T, int LW, int MODEL = 0> TGR_DEV Contact<T> load_floor(const T* lds, int k) {
   Contact<T> c;
   const int s = L_CF + 6 * k;
-  c.n = mk(T(0), T(0), T(1));
+  c.n = MODEL ? ld3<T, LW>(lds, L_FN + 3 * k) : mk(T(0), T(0), T(1));
   c.rA = mk(T(0), T(0), T(0));
   c.rB = ld3<T, LW>(lds, s);
   c.c0 = lds[(s + 3) * LW]; c.Dn = lds[(s + 4) * LW]; c.active = lds[(s + 5) * LW] != T(0);
@@ -658,7 +670,7 @@ TGR_DEV unsigned pair_coupling(const T* lds) {
 
 // evaluate the contacts at the current A (in LDS): Hessian blocks, constraint wrench FC, gradient G.
 // returns |G|^2 (all waves) ; cfrc_max = max |FC|
-template <typename T, int LW>
+template <typename T, int LW, int MODEL>
 TGR_DEV T newton_assemble(const Params<T>& P, T* lds, int wid, unsigned cpl, T& cfrc_max) {
   if (wid < 3) {
     const int b = wid;
@@ -677,10 +689,10 @@ TGR_DEV T newton_assemble(const Params<T>& P, T* lds, int wid, unsigned cpl, T& 
     V3<T> fl = mk(T(0), T(0), T(0)), fa = fl;
 #pragma unroll 1
     for (int e = 0; e < 2; e++) {
-      Contact<T> c = load_floor<T, LW>(lds, 2 * b + e);
+      Contact<T> c = load_floor<T, LW, MODEL>(lds, 2 * b + e);
       if (__any(c.active)) {
         V3<T> jl = yl + cross(ya, c.rB);
-        jl.z += c.c0;
+        if (MODEL) jl = jl + c.c0 * c.n; else jl.z += c.c0;
         Cone<T> o = cone_eval(P, c, jl, ya);
         fl = fl + o.fl;
         fa = fa + cross(c.rB, o.fl) + o.fa;
@@ -941,7 +953,7 @@ TGR_DEV LSlot<T> ls_pair_slot(const Params<T>& P, const T* lds, int p, int s) {
   return ls_make(c, jl, ja, ql, qa);
 }
 
-template <typename T, int LW>
+template <typename T, int LW, int MODEL>
 TGR_DEV void ls_setup(const Params<T>& P, const T* lds, int wid, unsigned cpl, LSlot<T>* ls) {
 #pragma unroll
   for (int k = 0; k < 3; k++) { ls[k].act = false; ls[k].A0 = ls[k].A1 = ls[k].A2 = ls[k].B0 = ls[k].B1 = ls[k].B2 = T(0); ls[k].jn0 = ls[k].qn = ls[k].jo0 = ls[k].qo = T(0); ls[k].Dn = T(0); }
@@ -952,9 +964,9 @@ TGR_DEV void ls_setup(const Params<T>& P, const T* lds, int wid, unsigned cpl, L
     V3<T> ya = ld3<T, LW>(lds, L_A + 6 * b + 3) + ld3<T, LW>(lds, L_BV + 6 * b + 3);
 #pragma unroll
     for (int e = 0; e < 2; e++) {
-      Contact<T> c = load_floor<T, LW>(lds, 2 * b + e);
+      Contact<T> c = load_floor<T, LW, MODEL>(lds, 2 * b + e);
       V3<T> jl = yl + cross(ya, c.rB);
-      jl.z += c.c0;
+      if (MODEL) jl = jl + c.c0 * c.n; else jl.z += c.c0;
       V3<T> ql = pl + cross(pa, c.rB);
       ls[e] = ls_make(c, jl, ya, ql, pa);
     }
@@ -1000,7 +1012,66 @@ template <typename T, int LW> TGR_DEV void warm_from_lds(Sim<T>& S, const T* lds
 }
 
 // base phase of bar B (see substep): kinematic columns, attached tendons, a0, floor caps, bar pair B
-template <typename T, int LW, int B, bool last>
+// closest point of triangle (a, b, c) to p (Ericson, Real-Time Collision Detection 5.1.5)
+template <typename T> TGR_DEV V3<T> closest_on_triangle(V3<T> p, V3<T> a, V3<T> b, V3<T> c) {
+  V3<T> ab = b - a, ac = c - a, ap = p - a;
+  T d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= T(0) && d2 <= T(0)) return a;
+  V3<T> bp = p - b;
+  T d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= T(0) && d4 <= d3) return b;
+  T vc = d1 * d4 - d3 * d2;
+  if (vc <= T(0) && d1 >= T(0) && d3 <= T(0)) return a + (d1 / (d1 - d3)) * ab;
+  V3<T> cp = p - c;
+  T d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= T(0) && d5 <= d6) return c;
+  T vb = d5 * d2 - d1 * d6;
+  if (vb <= T(0) && d2 >= T(0) && d6 <= T(0)) return a + (d2 / (d2 - d6)) * ac;
+  T va = d3 * d6 - d5 * d4;
+  if (va <= T(0) && (d4 - d3) >= T(0) && (d5 - d6) >= T(0)) return b + ((d4 - d3) / ((d4 - d3) + (d5 - d6))) * (c - b);
+  T den = T(1) / (va + vb + vc);
+  return a + (vb * den) * ab + (vc * den) * ac;
+}
+// cap sphere (centre cw, world) against the heightfield floor: deepest triangle of the (at most 2x2) cells under the cap.
+// Each grid cell is two triangles of the strip (c,r) (c,r+1) (c+1,r) (c+1,r+1).  Returns dist (>= 0: no contact), normal, and
+// the surface point.
+template <typename T> TGR_DEV T hfield_cap(const Params<T>& P, V3<T> cw, V3<T>& n_out) {
+  const T rad = P.cap_r;
+  V3<T> p = mk(cw.x - P.hf_x0, cw.y - P.hf_y0, cw.z - P.hf_z0);
+  n_out = mk(T(0), T(0), T(1));
+  if (p.x < -P.hf_rx - rad || p.x > P.hf_rx + rad || p.y < -P.hf_ry - rad || p.y > P.hf_ry + rad || p.z > P.hf_ez + rad) return T(1);
+  const T idx = rcp_(P.hf_dx), idy = rcp_(P.hf_dy);
+  int c0 = (int)floor(double((p.x - rad + P.hf_rx) * idx)), c1 = (int)floor(double((p.x + rad + P.hf_rx) * idx));
+  int r0 = (int)floor(double((p.y - rad + P.hf_ry) * idy)), r1 = (int)floor(double((p.y + rad + P.hf_ry) * idy));
+  c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
+  c1 = c1 > P.hf_ncol - 2 ? P.hf_ncol - 2 : c1; r1 = r1 > P.hf_nrow - 2 ? P.hf_nrow - 2 : r1;
+  T best = T(1);
+  V3<T> bq = p;
+  for (int r = r0; r <= r1; r++)
+    for (int c = c0; c <= c1; c++) {
+      V3<T> v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int cc = c + (j >> 1), rr = r + (j & 1);
+        v[j] = mk(T(cc) * P.hf_dx - P.hf_rx, T(rr) * P.hf_dy - P.hf_ry, T(P.hf[rr * P.hf_ncol + cc]) * P.hf_ez);
+      }
+#pragma unroll
+      for (int tri = 0; tri < 2; tri++) {
+        V3<T> q = closest_on_triangle(p, v[tri], v[tri + 1], v[tri + 2]);
+        V3<T> df = p - q;
+        T dist = sqrt_(dot(df, df)) - rad;
+        if (dist < T(0) && dist < best) { best = dist; bq = q; }
+      }
+    }
+  if (best >= T(0)) return T(1);
+  V3<T> df = p - bq;
+  T nn = sqrt_(dot(df, df));
+  if (!(nn > T(1e-12))) return T(1);
+  n_out = rcp_(nn) * df;
+  return best;
+}
+
+template <typename T, int LW, int B, bool last, int MODEL>
 TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* lds, Lag<T>& lag) {
   const T im = rcp_(P.mass);
   st3<T, LW>(lds, L_EZ + 3 * B, R[B].ez);
@@ -1012,12 +1083,15 @@ TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* l
   V3<T> Tq = (-(P.Izz - P.Ixx) * dot(R[B].ez, S.w[B])) * cross(S.w[B], R[B].ez);
 #pragma unroll
   for (int t = 0; t < 9; t++) {
-    const int ba = Tab::TEN[t][0], sa = Tab::TEN[t][1], bb = Tab::TEN[t][2], sb = Tab::TEN[t][3];
+    const int ba = Tab::TEN[t][0], bb = Tab::TEN[t][2];  // the bars of a tendon are the same in both models
+    const int sa = MODEL ? Tab::TEN1[t][1] : Tab::TEN[t][1], sb = MODEL ? Tab::TEN1[t][3] : Tab::TEN[t][3];
     const bool mine = (ba == B) || (bb == B);
     // the observation and tr_env's control cost need all nine lengths: in the last sub-step also the three foreign ones
     if (!mine && !last) continue;
-    V3<T> ra = rot_apply(R[ba], mk(T(Tab::S[sa][0]) * P.site_off, T(Tab::S[sa][1]) * P.site_off, T(Tab::S[sa][2]) * P.site_z));
-    V3<T> rb = rot_apply(R[bb], mk(T(Tab::S[sb][0]) * P.site_off, T(Tab::S[sb][1]) * P.site_off, T(Tab::S[sb][2]) * P.site_z));
+    V3<T> ra = rot_apply(R[ba], MODEL ? mk(T(Tab::S1[sa][0]) * P.site_off, T(Tab::S1[sa][1]) * P.site_off, T(Tab::S1[sa][2]) * P.site_z)
+                                      : mk(T(Tab::S[sa][0]) * P.site_off, T(Tab::S[sa][1]) * P.site_off, T(Tab::S[sa][2]) * P.site_z));
+    V3<T> rb = rot_apply(R[bb], MODEL ? mk(T(Tab::S1[sb][0]) * P.site_off, T(Tab::S1[sb][1]) * P.site_off, T(Tab::S1[sb][2]) * P.site_z)
+                                      : mk(T(Tab::S[sb][0]) * P.site_off, T(Tab::S[sb][1]) * P.site_off, T(Tab::S[sb][2]) * P.site_z));
     V3<T> dif = (S.x[bb] + rb) - (S.x[ba] + ra);
     T L2 = dot(dif, dif);
     T iL = rsqrt_(max_(L2, T(1e-30)));
@@ -1028,7 +1102,11 @@ TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* l
     V3<T> va = S.v[ba] + cross(S.w[ba], ra), vb = S.v[bb] + cross(S.w[bb], rb);
     T Ld = dot(u, vb - va);
     T f, damp;
-    if (t < 6) {
+    if (t < 6 && MODEL) {
+      // dyntype filter, no bias, no force limit (uneven xml:39): the force sees the activation
+      f = P.gain * S.act[t] - P.ten_k[t] * (L - P.ten_L0[t]) - P.ten_b[t] * Ld;
+      damp = P.ten_b[t];
+    } else if (t < 6) {
       T cc = clamp_(S.ctrl[t], P.ctrl_lo, P.ctrl_hi);
       T fr = P.gain * cc + P.bias0 + P.bias1 * L + P.bias2 * Ld;
       f = clamp_(fr, P.force_lo, P.force_hi);
@@ -1067,12 +1145,24 @@ TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* l
   for (int e = 0; e < 2; e++) {
     T sg = e == 0 ? P.bar_half : -P.bar_half;
     V3<T> arm = sg * R[B].ez;
-    T dist = S.x[B].z + arm.z - P.cap_r;
-    Contact<T> c;
-    contact_params(P, dist, 1, c);
     const int s = L_CF + 6 * (2 * B + e);
-    lds[s * LW] = arm.x; lds[(s + 1) * LW] = arm.y; lds[(s + 2) * LW] = arm.z - (P.cap_r + T(0.5) * dist);
-    lds[(s + 3) * LW] = c.c0; lds[(s + 4) * LW] = c.Dn; lds[(s + 5) * LW] = dist < T(0) ? T(1) : T(0);
+    Contact<T> c;
+    if (MODEL) {
+      V3<T> n;
+      T dist = hfield_cap(P, S.x[B] + arm, n);
+      const bool hit = dist < T(0);
+      if (!hit) dist = T(0);
+      contact_params(P, dist, 1, c);
+      V3<T> rB = arm - (P.cap_r + T(0.5) * dist) * n;
+      st3<T, LW>(lds, s, rB);
+      st3<T, LW>(lds, L_FN + 3 * (2 * B + e), n);
+      lds[(s + 3) * LW] = c.c0; lds[(s + 4) * LW] = c.Dn; lds[(s + 5) * LW] = hit ? T(1) : T(0);
+    } else {
+      T dist = S.x[B].z + arm.z - P.cap_r;
+      contact_params(P, dist, 1, c);
+      lds[s * LW] = arm.x; lds[(s + 1) * LW] = arm.y; lds[(s + 2) * LW] = arm.z - (P.cap_r + T(0.5) * dist);
+      lds[(s + 3) * LW] = c.c0; lds[(s + 4) * LW] = c.Dn; lds[(s + 5) * LW] = dist < T(0) ? T(1) : T(0);
+    }
   }
   // bar pair B = (pA, pB)
   {
@@ -1090,7 +1180,7 @@ TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* l
 // lds: this lane's column base (lds_block + lane); needs L_TOTAL slots of pitch LW
 // `last` is a template parameter: what only the last sub-step records (lagged kinematics, tendon lengths, contact wrench)
 // would otherwise be carried through all twenty iterations of the caller's loop as live registers
-template <typename T, int LW, bool last>
+template <typename T, int LW, bool last, int MODEL>
 TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, Lag<T>& lag) {
   const T im = rcp_(P.mass);
   TGR_STAMP(7);
@@ -1112,9 +1202,9 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, Lag<T>& lag
       for (int i = 0; i < 4; i++) lag.q[b][i] = S.q[b][i];
     }
   }
-  if (wid == 0) base_bar<T, LW, 0, last>(P, S, R, lds, lag);
-  else if (wid == 1) base_bar<T, LW, 1, last>(P, S, R, lds, lag);
-  else if (wid == 2) base_bar<T, LW, 2, last>(P, S, R, lds, lag);
+  if (wid == 0) base_bar<T, LW, 0, last, MODEL>(P, S, R, lds, lag);
+  else if (wid == 1) base_bar<T, LW, 1, last, MODEL>(P, S, R, lds, lag);
+  else if (wid == 2) base_bar<T, LW, 2, last, MODEL>(P, S, R, lds, lag);
   TGR_STAMP(0);
   __syncthreads();  // the columns of this sub-step are complete
   T nact = T(0);  // the flags are 0/1: one batch of reads and a sum (a short-circuit `||` would expose twelve LDS round trips)
@@ -1140,7 +1230,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, Lag<T>& lag
 #pragma unroll 1
   for (int it = 0;; it++) {
     TGR_STAMP(6);
-    T gn = newton_assemble<T, LW>(P, lds, wid, cpl, cfrc_max);
+    T gn = newton_assemble<T, LW, MODEL>(P, lds, wid, cpl, cfrc_max);
     TGR_STAMP(1);
     conv = conv || !(scale * sqrt_(gn) >= P.tol);
     if (__all(conv) || it >= P.max_iter) break;
@@ -1166,7 +1256,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, Lag<T>& lag
     }
     // the line-search slots, and their contribution at the first trial point alpha = 1, ride on the same barrier
     LSlot<T> lsl[3];
-    ls_setup<T, LW>(P, lds, wid, cpl, lsl);
+    ls_setup<T, LW, MODEL>(P, lds, wid, cpl, lsl);
     n_ls++;
     {
       T p1 = T(0), p2 = T(0);
@@ -1321,6 +1411,10 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, Lag<T>& lag
     T ny = rw * q[2] - rx * q[3] + ry * q[0] + rz * q[1];
     T nz = rw * q[3] + rx * q[2] - ry * q[1] + rz * q[0];
     q[0] = nw; q[1] = nx; q[2] = ny; q[3] = nz;
+  }
+  if (MODEL) {  // mj_advance: explicit Euler on the activations, act_dot = (ctrl - act) / tau evaluated with this sub-step's act
+#pragma unroll
+    for (int a = 0; a < 6; a++) S.act[a] += P.h * (clamp_(S.ctrl[a], P.ctrl_lo, P.ctrl_hi) - S.act[a]) * P.act_itau;
   }
 }
 

@@ -29,7 +29,7 @@ namespace tgr {
 // ------------------------------------------------------------------ state layout
 enum : int {
   F_QPOS = 0, F_QVEL = 21, F_WARM = 39, F_CTRL = 57, F_XYLAG = 63, F_PSILAG = 65, F_RESETPSI = 66,
-  F_EPRET = 67, F_WAYPT = 68, F_ORI = 70, F_VCMD = 72, NF = 75
+  F_EPRET = 67, F_WAYPT = 68, F_ORI = 70, F_VCMD = 72, F_ACT = 75, NF = 81
 };
 enum : int { I_STEPNUM = 0, I_ELAPSED, I_RINGLEN, I_RINGHEAD, I_EPISODE, I_PHASE, I_SRC, I_SRCEP, NI };
 constexpr int RING = 32;
@@ -37,7 +37,7 @@ constexpr double PI = 3.14159265358979323846;
 
 template <typename T> struct EnvCfg {
   int env_kind, action, terminate_when_unhealthy, use_contact_forces, use_cap_velocity, is_test;
-  int reward_delay_steps, frame_skip, max_episode_steps, obs_dim, use_obs_noise;
+  int reward_delay_steps, frame_skip, max_episode_steps, obs_dim, use_obs_noise, model_kind;
   T noise_tendon, noise_cap;
   T direction, ctrl_cost_weight, contact_cost_weight, healthy_reward, contact_lo, contact_hi, dt;
   T ditch_max, ditch_std, waypt_amp, waypt_std, yaw_weight;
@@ -64,6 +64,10 @@ template <typename T> struct KArgs {
 __constant__ double c_qpos0[21] = {0.08369179, -0.28792231, 0.24830847, -0.49145555, 0.7539914, -0.27511722, -0.33805166,
                                    0.14497616, -0.19291743, 0.35052097, -0.84766041, 0.27950622, 0.45085889, 0.00862359,
                                    0.04557825, -0.29876206, 0.39531985, -0.35798606, -0.47531391, 0.72471075, 0.34744352};
+// 3prism_jonathan_steady_side_uneven_ground.xml:65,84,102
+__constant__ double c_qpos0_uneven[21] = {0.25551711, -0.00069342, 0.22404039, -0.49720971, 0.24315431, 0.75327284, -0.35530059,
+                                          0.14409445, 0.0654207, 0.33662589, 0.42572066, 0.01379464, -0.53972521, 0.72613244,
+                                          0.28544944, -0.04883333, 0.38591159, 0.137357, 0.06898275, -0.85996553, 0.48665565};
 // tr_env.py:723-728
 __constant__ double c_rolling[6][21] = {
     {0.07900689, -0.32670045, 0.23079722, 0.49365198, -0.74001353, 0.26668361, 0.37090101, 0.13713385, -0.24342633, 0.32722167, 0.82936968, -0.31256817, -0.46189217, -0.03320677, 0.04903377, -0.3421725, 0.36675097, 0.33407281, 0.43794432, -0.72515863, -0.41321313},
@@ -127,7 +131,7 @@ template <typename T> TGR_DEV void load_sim(const T* st, int n, int e, Sim<T>& S
     S.aa[b] = rot_apply(R, ab);
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) S.ctrl[i] = st[(F_CTRL + i) * n + e];
+  for (int i = 0; i < 6; i++) { S.ctrl[i] = st[(F_CTRL + i) * n + e]; S.act[i] = st[(F_ACT + i) * n + e]; }
 }
 // wb_out: body-frame angular velocity (what qvel stores), needed by the tr_env observation
 template <typename T> TGR_DEV void store_sim(T* st, int n, int e, Sim<T>& S, const Lag<T>& lag, V3<T>* wb_out) {
@@ -149,7 +153,7 @@ template <typename T> TGR_DEV void store_sim(T* st, int n, int e, Sim<T>& S, con
     st[(F_WARM + 6 * b + 3) * n + e] = ab.x; st[(F_WARM + 6 * b + 4) * n + e] = ab.y; st[(F_WARM + 6 * b + 5) * n + e] = ab.z;
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) st[(F_CTRL + i) * n + e] = S.ctrl[i];
+  for (int i = 0; i < 6; i++) { st[(F_CTRL + i) * n + e] = S.ctrl[i]; st[(F_ACT + i) * n + e] = S.act[i]; }
 }
 
 template <typename T> TGR_DEV T atan2_(T y, T x) { return sizeof(T) == 4 ? T(atan2f(float(y), float(x))) : T(atan2(double(y), double(x))); }
@@ -423,7 +427,7 @@ template <typename T> TGR_DEV unsigned long long lane_key(const EnvCfg<T>& E, in
 template <typename T> TGR_DEV void init_episode(const EnvCfg<T>& E, unsigned long long key, unsigned long long episode, Sim<T>& S) {
   Draws dr = reset_draws(E, key, episode);
   double c = cos(dr.theta), s = sin(dr.theta), ch = cos(0.5 * dr.theta), sh = sin(0.5 * dr.theta);
-  const double* q0 = E.env_kind == TGR_ENV_TR ? c_rolling[dr.pose] : c_qpos0;
+  const double* q0 = E.env_kind == TGR_ENV_TR ? c_rolling[dr.pose] : (E.model_kind ? c_qpos0_uneven : c_qpos0);
 #pragma unroll
   for (int b = 0; b < 3; b++) {
     const double* q = q0 + 7 * b;
@@ -433,7 +437,7 @@ template <typename T> TGR_DEV void init_episode(const EnvCfg<T>& E, unsigned lon
     S.v[b] = mk(T(0), T(0), T(0)); S.w[b] = S.v[b]; S.al[b] = S.v[b]; S.aa[b] = S.v[b];
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) S.ctrl[i] = T(dr.tendons[i]);
+  for (int i = 0; i < 6; i++) { S.ctrl[i] = T(dr.tendons[i]); S.act[i] = T(0); }  // mj_resetData zeroes the activations
 }
 
 template <typename T> TGR_DEV int settle_total(const EnvCfg<T>& E) {
@@ -525,8 +529,8 @@ TGR_DEV void store_reset_aux(const Params<T>& P, T* st, int* ist, int m, int e, 
 }
 
 // ------------------------------------------------------------------ step kernel
-template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel(KArgs<T> k) {
-  __shared__ T lds_all[L_TOTAL * LW];
+template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void step_kernel(KArgs<T> k) {
+  __shared__ T lds_all[lds_slots<MODEL>() * LW];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 4 waves share the block's LW envs
   if (lane >= LW) return;
@@ -573,8 +577,8 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
 #endif
   warm_to_lds<T, LW>(S, lds, wid);
 #pragma unroll 1
-  for (int s = 0; s + 1 < E.frame_skip; s++) substep<T, LW, false>(P, S, lds, wid, lag);
-  substep<T, LW, true>(P, S, lds, wid, lag);
+  for (int s = 0; s + 1 < E.frame_skip; s++) substep<T, LW, false, MODEL>(P, S, lds, wid, lag);
+  substep<T, LW, true, MODEL>(P, S, lds, wid, lag);
 
 #ifdef TGR_STAMPS
   { long long _t = clock64(); lag.stamp[5] += _t - lag.t_last; lag.t_last = _t; }
@@ -697,8 +701,8 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void step_kernel
 // ------------------------------------------------------------------ settle kernel: reset_model() in one go
 // one lane per entry of list[]; used by tgr_reset() and for live envs that found no ready donor.
 // reproduces tensegrity_env.py:433-512 / tr_env.py:709-872.
-template <typename T, int LW> __global__ __launch_bounds__(256) void settle_kernel(KArgs<T> k) {
-  __shared__ T lds_all[L_TOTAL * LW];
+template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void settle_kernel(KArgs<T> k) {
+  __shared__ T lds_all[lds_slots<MODEL>() * LW];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (lane >= LW) return;
@@ -731,8 +735,8 @@ template <typename T, int LW> __global__ __launch_bounds__(256) void settle_kern
 #pragma unroll 1
   for (int st = 0; st < total; st++) {
 #pragma unroll 1
-    for (int s = 0; s + 1 < E.frame_skip; s++) substep<T, LW, false>(P, S, lds, wid, lag);
-    substep<T, LW, true>(P, S, lds, wid, lag);
+    for (int s = 0; s + 1 < E.frame_skip; s++) substep<T, LW, false, MODEL>(P, S, lds, wid, lag);
+    substep<T, LW, true, MODEL>(P, S, lds, wid, lag);
     if (valid) settle_period_done(P, E, lag, st, ring, step_num, reset_psi, ms, xy_prev, lane_key(E, n, e), (unsigned long long)(unsigned)episode);
   }
   if (!valid || wid != 0) return;
@@ -863,6 +867,8 @@ struct tgr_handle {
   int* rlist = nullptr;
   uint8_t* doneflag = nullptr;
   unsigned long long* counters = nullptr;
+  float* hf = nullptr;  // heightfield elevations (model_kind 1)
+  int hf_nrow = 0, hf_ncol = 0;
   std::string err;
 };
 
@@ -945,6 +951,25 @@ extern "C" int tgr_default_config(tgr_config* c, int env_kind, int desired_actio
   c->yaw_reward_weight = 1;
   c->solver_warm_start = 0;
   c->use_obs_noise = 0; c->obs_noise_tendon_stdev = 0.02; c->obs_noise_cap_pos_stdev = 0.05;
+  c->model_kind = 0; c->site_offset = 0.0675; c->act_tau = 1.0;
+  c->hf_size[0] = 50; c->hf_size[1] = 50; c->hf_size[2] = 1; c->hf_size[3] = 0.1;
+  c->hf_pos[0] = 0; c->hf_pos[1] = 0; c->hf_pos[2] = -1.0;
+  return TGR_OK;
+}
+
+// 3prism_jonathan_steady_side_uneven_ground.xml vs the flat model: xml:38-39 (tendon and actuator defaults), :48,56 (heightfield),
+// :69-70 (caps), :76-81 (sites), :122-158 (tendons)
+extern "C" int tgr_uneven_config(tgr_config* c) {
+  if (!c) return TGR_ERR_INVALID;
+  c->model_kind = 1;
+  c->cap_radius = 0.05;
+  c->site_offset = 0.05;
+  for (int t = 0; t < 9; t++) { c->ten_stiffness[t] = 10000.0; c->ten_damping[t] = 1000.0; c->ten_springlength[t] = t < 6 ? 0.5 : 0.8; }
+  c->gain = 15000.0; c->bias[0] = c->bias[1] = c->bias[2] = 0.0;
+  c->force_range[0] = -1e30; c->force_range[1] = 1e30;  // forcelimited is not set
+  c->act_tau = 1.0;
+  c->hf_size[0] = 50; c->hf_size[1] = 50; c->hf_size[2] = 1; c->hf_size[3] = 0.1;
+  c->hf_pos[0] = 0; c->hf_pos[1] = 0; c->hf_pos[2] = -1.0;
   return TGR_OK;
 }
 
@@ -970,7 +995,7 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   Ixx += 2 * (1.0 * (3 * rb * rb + Lb * Lb) / 12.0 + 1.0 * cb * cb); Izz += 2 * (1.0 * rb * rb / 2.0);
   P.mass = T(4.0); P.Ixx = T(Ixx); P.Izz = T(Izz);
   P.cap_r = T(c.cap_radius); P.bar_half = T(half); P.rcyl_r = T(rr); P.bcyl_r = T(rb); P.bcyl_lo = T(blo); P.bcyl_hi = T(bhi);
-  P.site_off = T(0.0675); P.site_z = T(0.668);
+  P.site_off = T(c.site_offset); P.site_z = T(0.668);
   for (int t = 0; t < 9; t++) { P.ten_k[t] = T(c.ten_stiffness[t]); P.ten_b[t] = T(c.ten_damping[t]); P.ten_L0[t] = T(c.ten_springlength[t]); }
   P.gain = T(c.gain); P.bias0 = T(c.bias[0]); P.bias1 = T(c.bias[1]); P.bias2 = T(c.bias[2]);
   P.force_lo = T(c.force_range[0]); P.force_hi = T(c.force_range[1]); P.ctrl_lo = T(c.ctrl_range[0]); P.ctrl_hi = T(c.ctrl_range[1]);
@@ -986,12 +1011,18 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   P.ls_iter = sizeof(T) == 4 ? 6 : 50;
   P.skip_clamped = c.actuator_deriv_skip_clamped;
   P.warm_start = c.solver_warm_start;
+  P.act_itau = T(1.0 / (c.act_tau > 1e-12 ? c.act_tau : 1e-12));
+  P.hf = h->hf; P.hf_nrow = h->hf_nrow; P.hf_ncol = h->hf_ncol;
+  P.hf_rx = T(c.hf_size[0]); P.hf_ry = T(c.hf_size[1]); P.hf_ez = T(c.hf_size[2]);
+  P.hf_x0 = T(c.hf_pos[0]); P.hf_y0 = T(c.hf_pos[1]); P.hf_z0 = T(c.hf_pos[2]);
+  P.hf_dx = T(h->hf_ncol > 1 ? 2 * c.hf_size[0] / (h->hf_ncol - 1) : 1.0); P.hf_dy = T(h->hf_nrow > 1 ? 2 * c.hf_size[1] / (h->hf_nrow - 1) : 1.0);
   EnvCfg<T>& E = k.E;
   E.env_kind = c.env_kind; E.action = c.desired_action; E.terminate_when_unhealthy = c.terminate_when_unhealthy;
   E.use_contact_forces = c.use_contact_forces; E.use_cap_velocity = c.use_cap_velocity; E.is_test = c.is_test;
   E.reward_delay_steps = c.reward_delay_steps; E.frame_skip = c.frame_skip; E.max_episode_steps = c.max_episode_steps;
   E.obs_dim = h->obs_dim;
   E.use_obs_noise = (c.use_obs_noise && c.env_kind == TGR_ENV_TR) ? 1 : 0;
+  E.model_kind = c.model_kind;
   E.noise_tendon = T(c.obs_noise_tendon_stdev); E.noise_cap = T(c.obs_noise_cap_pos_stdev);
   E.direction = T(c.desired_direction); E.ctrl_cost_weight = T(c.ctrl_cost_weight); E.contact_cost_weight = T(c.contact_cost_weight);
   E.healthy_reward = T(c.healthy_reward); E.contact_lo = T(c.contact_force_lo); E.contact_hi = T(c.contact_force_hi);
@@ -1019,6 +1050,7 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
     g_err = "tgr_create: desired_action not supported by this env class (tensegrity_env: straight|turn; tr_env: + aiming|tracking|vel_track)";
     return TGR_ERR_UNSUPPORTED;
   }
+  if (cfg->model_kind < 0 || cfg->model_kind > 1) { g_err = "tgr_create: model_kind must be 0 (flat) or 1 (uneven ground)"; return TGR_ERR_UNSUPPORTED; }
   if (cfg->solimp[4] != 2.0 || cfg->solref[0] >= 0) { g_err = "tgr_create: only direct solref and power-2 solimp"; return TGR_ERR_UNSUPPORTED; }
   if (cfg->n_donors > 8 * n_envs) { g_err = "tgr_create: n_donors must be <= 8 * n_envs"; return TGR_ERR_INVALID; }
   if (cfg->reward_delay_steps >= RING - 1 || cfg->reward_delay_steps < 0) { g_err = "tgr_create: reward_delay_steps too large"; return TGR_ERR_INVALID; }
@@ -1057,10 +1089,23 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   return TGR_OK;
 }
 
+extern "C" int tgr_set_hfield(tgr_handle* h, const float* heights, int nrow, int ncol) {
+  if (!h) return TGR_ERR_INVALID;
+  if (!heights || nrow < 2 || ncol < 2) { h->err = "tgr_set_hfield: need a [nrow >= 2][ncol >= 2] array"; return TGR_ERR_INVALID; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipDeviceSynchronize());
+  if (h->hf) { (void)hipFree(h->hf); h->hf = nullptr; }
+  HIP_TRY(h, hipMalloc((void**)&h->hf, sizeof(float) * (size_t)nrow * ncol));
+  HIP_TRY(h, hipMemcpy(h->hf, heights, sizeof(float) * (size_t)nrow * ncol, hipMemcpyHostToDevice));
+  h->hf_nrow = nrow; h->hf_ncol = ncol;
+  return TGR_OK;
+}
+
 extern "C" int tgr_destroy(tgr_handle* h) {
   if (!h) return TGR_OK;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
+  (void)hipFree(h->hf);
   (void)hipFree(h->st); (void)hipFree(h->ist); (void)hipFree(h->ring); (void)hipFree(h->dobs); (void)hipFree(h->list_count);
   (void)hipFree(h->list); (void)hipFree(h->rlist); (void)hipFree(h->doneflag); (void)hipFree(h->counters);
   delete h;
@@ -1100,6 +1145,7 @@ extern "C" int tgr_stats(tgr_handle* h, uint64_t out[8]) {
 }
 
 template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, void* obs, hipStream_t s) {
+  if (h->cfg.model_kind == 1 && !h->hf) { h->err = "tgr_reset: the uneven-ground model needs tgr_set_hfield first"; return TGR_ERR_INVALID; }
   std::vector<int> idx;
   idx.reserve(h->m);
   for (int i = 0; i < h->n; i++)
@@ -1117,7 +1163,8 @@ template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, 
   k.obs_reset = (T*)obs;
   constexpr int LW = LaneW<T>::value;
   int blocks = (cnt + LW - 1) / LW;
-  hipLaunchKernelGGL((settle_kernel<T, LW>), dim3(blocks), dim3(256), 0, s, k);
+  if (h->cfg.model_kind) hipLaunchKernelGGL((settle_kernel<T, LW, 1>), dim3(blocks), dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((settle_kernel<T, LW, 0>), dim3(blocks), dim3(256), 0, s, k);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->list_count, 0, sizeof(int), s));
   return TGR_OK;
@@ -1134,6 +1181,7 @@ template <typename T>
 static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uint8_t* terminated, uint8_t* truncated,
                      T* terminal_obs, T* info, hipStream_t s) {
   if (!actions || !obs || !reward || !terminated || !truncated) { h->err = "tgr_step: null buffer"; return TGR_ERR_INVALID; }
+  if (h->cfg.model_kind == 1 && !h->hf) { h->err = "tgr_step: the uneven-ground model needs tgr_set_hfield first"; return TGR_ERR_INVALID; }
   KArgs<T> k;
   fill_args<T>(h, k);
   k.actions = actions; k.obs = obs; k.reward = reward; k.terminated = terminated; k.truncated = truncated;
@@ -1141,14 +1189,16 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
   k.obs_reset = obs;
   constexpr int LW = LaneW<T>::value;
   int blocks = (h->m + LW - 1) / LW;
-  hipLaunchKernelGGL((step_kernel<T, LW>), dim3(blocks), dim3(256), 0, s, k);
+  if (h->cfg.model_kind) hipLaunchKernelGGL((step_kernel<T, LW, 1>), dim3(blocks), dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((step_kernel<T, LW, 0>), dim3(blocks), dim3(256), 0, s, k);
   HIP_TRY(h, hipGetLastError());
   if (h->cfg.auto_reset) {
     hipLaunchKernelGGL((match_kernel<T>), dim3(1), dim3(1024), 0, s, k);
     HIP_TRY(h, hipGetLastError());
     // envs that found no ready donor are settled here and now (grid sized for the worst case, exits on an empty list)
     int sblocks = (h->n + LW - 1) / LW;
-    hipLaunchKernelGGL((settle_kernel<T, LW>), dim3(sblocks), dim3(256), 0, s, k);
+    if (h->cfg.model_kind) hipLaunchKernelGGL((settle_kernel<T, LW, 1>), dim3(sblocks), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((settle_kernel<T, LW, 0>), dim3(sblocks), dim3(256), 0, s, k);
     HIP_TRY(h, hipGetLastError());
   }
   return TGR_OK;
@@ -1193,6 +1243,7 @@ template <typename T> static int get_state_impl(tgr_handle* h, double* qpos, dou
       a[TGR_AUX_ORI_X] = (double)st[(F_ORI + 0) * n + e]; a[TGR_AUX_ORI_Y] = (double)st[(F_ORI + 1) * n + e];
       a[TGR_AUX_VCMD_X] = (double)st[(F_VCMD + 0) * n + e]; a[TGR_AUX_VCMD_Y] = (double)st[(F_VCMD + 1) * n + e];
       a[TGR_AUX_VCMD_W] = (double)st[(F_VCMD + 2) * n + e];
+      for (int i = 0; i < 6; i++) a[TGR_AUX_ACT + i] = (double)st[(F_ACT + i) * n + e];
     }
   }
   return TGR_OK;
@@ -1231,6 +1282,7 @@ static int set_state_impl(tgr_handle* h, const double* qpos, const double* qvel,
       st[(F_ORI + 0) * n + e] = (T)a[TGR_AUX_ORI_X]; st[(F_ORI + 1) * n + e] = (T)a[TGR_AUX_ORI_Y];
       st[(F_VCMD + 0) * n + e] = (T)a[TGR_AUX_VCMD_X]; st[(F_VCMD + 1) * n + e] = (T)a[TGR_AUX_VCMD_Y];
       st[(F_VCMD + 2) * n + e] = (T)a[TGR_AUX_VCMD_W];
+      for (int i = 0; i < 6; i++) st[(F_ACT + i) * n + e] = (T)a[TGR_AUX_ACT + i];
     }
     HIP_TRY(h, hipMemcpy(h->st, st.data(), sizeof(T) * NF * n, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->ist, ist.data(), sizeof(int) * NI * n, hipMemcpyHostToDevice));

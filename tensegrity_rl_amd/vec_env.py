@@ -6,6 +6,7 @@ auto-reset with infos[i]["terminal_observation"], "TimeLimit.truncated" and Moni
 info["episode"] = {"r","l","t"}.  PyTorch is only plumbing here: device buffers + the current stream.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -27,6 +28,22 @@ _IGNORED = ["xml_file", "render_mode", "reset_noise_scale", "contact_with_self_p
             "threshold_waypt", "width", "height", "camera_id", "camera_name"]
 
 
+def heights_from_image(img):
+    """Elevations of a heightfield image the way mujoco's compiler prepares them [ext]: grey level, normalised to [0, 1] by
+    (h - min) / (max - min), rows flipped so that row 0 is the southern edge (y = -radius_y) -- the image's top row is north.
+    (Row order and the triangulation are assumptions of this restatement: DESIGN.md, "uneven ground".)"""
+    a = np.asarray(img, dtype=np.float64)
+    if a.ndim == 3:
+        a = a[..., :3].mean(axis=2)
+    lo, hi = a.min(), a.max()
+    a = (a - lo) / (hi - lo) if hi > lo else np.zeros_like(a)
+    return np.ascontiguousarray(a[::-1], dtype=np.float32)
+
+
+def is_uneven_xml(xml_file):
+    return isinstance(xml_file, str) and "uneven" in os.path.basename(xml_file)
+
+
 def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision="f32", auto_reset=True, seed=1234,
                 first_env_id=0, max_episode_steps=5000, **kwargs):
     """tgr_config from the reference's constructor kwargs (tensegrity_env.py:160-181, tr_env.py:137-173)."""
@@ -36,6 +53,9 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
     if desired_action not in N.ACTIONS:
         raise ValueError(f"unknown desired_action {desired_action!r}")
     cfg = N.default_config(kind, desired_action)
+    # the reference picks the model with xml_file (run.py --env_xml); `model="uneven"` does the same without a path
+    if kwargs.pop("model", "flat") == "uneven" or is_uneven_xml(kwargs.get("xml_file")):
+        N.load().tgr_uneven_config(C.byref(cfg))
     for k in list(kwargs):
         if k in _DIRECT:
             setattr(cfg, k, type(getattr(cfg, k))(kwargs.pop(k)))
@@ -76,7 +96,9 @@ class TensegrityVecEnv:
 
     metadata = {"render_modes": ["human", "rgb_array", "depth_array"], "render_fps": 50}
 
-    def __init__(self, num_envs, env_id="tensegrity_env-v0", device=0, info_mode="minimal", **kwargs):
+    def __init__(self, num_envs, env_id="tensegrity_env-v0", device=0, info_mode="minimal", terrain=None, **kwargs):
+        """terrain: for the uneven-ground model, the heightfield -- an image array (uint8, as in terrain_image_100.png) or float
+        elevations already normalised to [0, 1] with row 0 at y = -radius_y."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("TensegrityVecEnv needs a HIP device (MI355X); there is no CPU fallback")
@@ -90,6 +112,13 @@ class TensegrityVecEnv:
         self.handle = C.c_void_p()
         rc = self.lib.tgr_create(C.byref(self.cfg), self.num_envs, self.device_index, C.byref(self.handle))
         N.check(self.handle if self.handle else None, rc, "tgr_create")
+        if self.cfg.model_kind == 1:
+            if terrain is None:
+                raise ValueError("the uneven-ground model needs terrain= (the heightfield image or normalised elevations)")
+            t_ = np.asarray(terrain)
+            hts = heights_from_image(t_) if t_.dtype == np.uint8 or t_.ndim == 3 else np.ascontiguousarray(t_, dtype=np.float32)
+            self.heights = hts
+            N.check(self.handle, self.lib.tgr_set_hfield(self.handle, hts.ctypes.data, hts.shape[0], hts.shape[1]), "tgr_set_hfield")
         self.obs_dim = self.lib.tgr_obs_dim(self.handle)
         self.f64 = self.cfg.precision == 1
         dt = torch.float64 if self.f64 else torch.float32

@@ -2,7 +2,9 @@
 import numpy as np
 
 AUX = {"xy_lag_x": 0, "xy_lag_y": 1, "psi_lag": 2, "reset_psi": 3, "ep_return": 4, "step_num": 5, "elapsed": 6, "episode": 7,
-       "ring_len": 8, "waypt_x": 9, "waypt_y": 10, "ori_x": 11, "ori_y": 12, "vcmd_x": 13, "vcmd_y": 14, "vcmd_w": 15, "src": 16}
+       "ring_len": 8, "waypt_x": 9, "waypt_y": 10, "ori_x": 11, "ori_y": 12, "vcmd_x": 13, "vcmd_y": 14, "vcmd_w": 15, "src": 16,
+       "act": 17}  # act: 17..22
+AUX_K = 23
 
 
 def qfix(a, b):
@@ -19,12 +21,13 @@ def oracle_to_gpu_state(ob, env):
     """copy the oracle batch's full per-env state into the HIP handle (identical (state, action) parity)"""
     qpos, qvel, ctrl, warm, aux = ob.get_state()
     n = ob.n
-    A = np.zeros((n, 17))
+    A = np.zeros((n, AUX_K))
     A[:, AUX["xy_lag_x"]] = aux["xy_lag_x"]; A[:, AUX["xy_lag_y"]] = aux["xy_lag_y"]
     A[:, AUX["reset_psi"]] = aux["reset_psi"]; A[:, AUX["step_num"]] = aux["step_num"]
     A[:, AUX["elapsed"]] = aux["elapsed"]; A[:, AUX["ep_return"]] = aux["ep_return"]
     for k in ("psi_lag", "waypt_x", "waypt_y", "ori_x", "ori_y", "vcmd_x", "vcmd_y", "vcmd_w"):
         A[:, AUX[k]] = aux[k]
+    A[:, AUX["act"]:AUX["act"] + 6] = ob.last_act  # actuator activations (uneven-ground model; zero otherwise)
     env.set_state(qpos, qvel, ctrl, warm, A)
     return qpos, qvel
 

@@ -98,7 +98,7 @@ def test_reward_obs_epilogue_against_reference_fixture(oracle, golden_dir):
             qpos, qvel, ctrl = g["reset_qpos"][ep], g["reset_qvel"][ep], g["reset_ctrl"][ep]
             xy = g["reset_xy_lag"][ep]
             for t in range(T):
-                A = np.zeros((1, 17)); A[0, 0], A[0, 1], A[0, 3] = xy[0], xy[1], g["reset_reset_psi"][ep]
+                A = np.zeros((1, 23)); A[0, 0], A[0, 1], A[0, 3] = xy[0], xy[1], g["reset_reset_psi"][ep]
                 env.set_state(qpos[None], qvel[None], ctrl[None], None, A)
                 obs, rew, term, trunc, _, info = [x.cpu().numpy() for x in env.step_tensors(g["actions"][k][None])]
                 np.testing.assert_allclose(obs[0], g["obs"][k], atol=2e-6, err_msg=f"{fname} step {k}")

@@ -1,0 +1,77 @@
+"""Uneven-ground model (BASELINE config #4): 3prism_jonathan_steady_side_uneven_ground.xml -- caps of 5 cm,
+another tendon-site layout, nine passive spring-damper tendons, dyntype=filter actuators, heightfield floor from
+terrain_image_100.png (tests/golden/terrain_100.npy, extracted by oracle/extract_terrain.py).  The HIP path (MODEL = 1 kernels)
+against the oracle on identical (state, action); physics against MuJoCo is unpinned as for the flat model, and the row order of
+the image / the cell diagonal of the heightfield are assumptions both sides share."""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_common import oracle_to_gpu_state, qfix, rel_env
+
+pytestmark = pytest.mark.gpu
+
+
+def terrain(golden_dir):
+    return np.load(os.path.join(golden_dir, "terrain_100.npy"))
+
+
+@pytest.mark.parametrize("kind", ["tensegrity_env", "tr_env"])
+def test_uneven_fp64_matches_oracle(oracle, golden_dir, kind):
+    from tensegrity_rl_amd import TensegrityVecEnv
+    from tensegrity_rl_amd.vec_env import heights_from_image
+    O = oracle
+    img = terrain(golden_dir)
+    h = heights_from_image(img)
+    n = 48
+    ob = O.OracleBatch(O.make_cfg(kind, "straight", heights=h, model_kind=1), n, seed=21)
+    ob.reset()                                    # drops the robots ~0.8 m onto the terrain and settles them (reset_model)
+    env = TensegrityVecEnv(n, kind + "-v0", desired_action="straight", precision="f64", auto_reset=False, seed=21,
+                           xml_file="3prism_jonathan_steady_side_uneven_ground.xml", terrain=img)
+    assert env.cfg.model_kind == 1 and env.cfg.cap_radius == 0.05
+    rng = np.random.default_rng(2)
+    ncon = 0
+    for t in range(6):
+        oracle_to_gpu_state(ob, env)
+        a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+        o_obs, o_rew, o_term, _, _, o_info = ob.step(a, auto_reset=False)
+        g_obs, g_rew, g_term, _, _, g_info = [x.cpu().numpy() for x in env.step_tensors(a)]
+        st = env.get_state()
+        q2, v2, _, _, _ = ob.get_state()
+        assert rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3).max() < 1e-7
+        assert rel_env(st["qvel"] - v2, v2, 1e-2).max() < 1e-5
+        assert np.abs(st["aux"][:, 17:23] - ob.last_act).max() < 1e-12      # activations: act += h (ctrl - act) / tau
+        assert np.abs(g_obs - o_obs).max() < 1e-5 and np.abs(g_rew - o_rew).max() < 1e-6 and not (g_term.astype(bool) != o_term).any()
+        ncon += sum(ob.env(i).data.ncon for i in range(n))
+    assert ncon > n  # the robots do stand on the terrain
+    assert np.abs(ob.last_act).max() > 0.01
+    z = q2.reshape(n, 3, 7)[:, :, 2]
+    assert z.max() < 0.0 and z.min() > -1.2   # resting on the heightfield (surface between z = -1 and 0), not on a z = 0 plane
+    env.close(); ob.close()
+
+
+def test_uneven_full_size_rollout_fp32(golden_dir):
+    """BASELINE config #4 size: 8192 envs on the heightfield, fp32, auto-reset through donor lanes: finite, deterministic,
+    episodes end and restart."""
+    import torch
+    from tensegrity_rl_amd import TensegrityVecEnv
+    img = terrain(golden_dir)
+    n = 8192
+    outs = []
+    for rep in range(2):
+        env = TensegrityVecEnv(n, "tr_env-v0", model="uneven", terrain=img, seed=5)
+        env.reset_tensors()
+        g = torch.Generator(device="cuda"); g.manual_seed(1)
+        done = torch.zeros(n, dtype=torch.bool, device="cuda")
+        for t in range(12):
+            o, r, te, tr, _, _ = env.step_tensors(torch.rand((n, 6), device="cuda", generator=g) * 0.6 - 0.45)
+            done |= (te | tr).bool()
+        assert torch.isfinite(o).all() and torch.isfinite(r).all()
+        outs.append((o.clone(), r.clone()))
+        st = env.get_state()
+        env.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    q = st["qpos"].reshape(n, 3, 7)
+    assert np.abs(np.linalg.norm(q[:, :, 3:], axis=2) - 1).max() < 1e-5
+    assert q[:, :, 2].max() < 0.5 and q[:, :, 2].min() > -1.5
