@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=60)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--env-id", default="tensegrity_env-v0")
+    ap.add_argument("--model", default="flat", choices=["flat", "uneven"],
+                    help="uneven: BASELINE config #4 (heightfield floor, tests/golden/terrain_100.npy); not the headline metric")
     ap.add_argument("--donors", type=int, default=-1)
     ap.add_argument("--gather-every", type=int, default=16)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -115,8 +117,12 @@ def main():
     n_local = args.envs_per_gpu
     n_total = n_local * world
     lo, hi = shard_range(rank, world, n_total)
+    extra = {}
+    if args.model == "uneven":
+        import numpy as np
+        extra = dict(model="uneven", terrain=np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "terrain_100.npy")))
     env = TensegrityVecEnv(n_local, args.env_id, device=local_rank, desired_action="straight", desired_direction=1,
-                           seed=1234, first_env_id=lo, n_donors=args.donors)
+                           seed=1234, first_env_id=lo, n_donors=args.donors, **extra)
     env.reset_tensors()
     g = torch.Generator(device=dev); g.manual_seed(rank)
     acts = [(torch.rand((n_local, 6), device=dev, generator=g) * 0.6 - 0.45).contiguous() for _ in range(32)]
@@ -161,7 +167,7 @@ def main():
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"3-bar flat-ground {args.env_id} straight/+1, N_envs={n_local} per GPU ({n_total} total), "
+            "config": {"workload": f"3-bar {'uneven-ground (heightfield)' if args.model == 'uneven' else 'flat-ground'} {args.env_id} straight/+1, N_envs={n_local} per GPU ({n_total} total), "
                                    "random-action rollout U[-0.45,0.15]^6, auto-reset via donor lanes, 20 sub-steps of 1 ms per step",
                        "envs_per_gpu": n_local, "donor_lanes_per_gpu": env.cfg.n_donors if env.cfg.n_donors >= 0 else 2 * n_local,
                        "gather_every": args.gather_every if world > 1 else None,

@@ -13,19 +13,13 @@ import numpy as np
 from . import oracle as O
 
 
-def tables():
-    L = O.lib()
-    sg = np.zeros((6, 3)); te = np.zeros((9, 4), dtype=np.int32)
-    for s in range(6):
-        L.tgo_site_sign(s, O.dptr(sg[s]))
-    for t in range(9):
-        L.tgo_tendon_ends(t, te[t].ctypes.data_as(C.POINTER(C.c_int)))
-    return sg, te
-
-
-def emit_mjcf(m=None):
+def emit_mjcf(m=None, hfield_file="terrain.png"):
+    """m: tgo_model (flat: O.default_model(), uneven ground: O.uneven_model(...)).  For the uneven model the heightfield asset
+    refers to `hfield_file` (an image next to the document); the elevations themselves are data, not part of the model text."""
     m = m or O.default_model()
-    sg, te = tables()
+    sl = np.array(m.site_local)                      # [6][3] local site positions
+    te = np.array(m.ten_ends, dtype=np.int32)        # [9][4] {bar_a, site_a, bar_b, site_b}
+    uneven = m.model_kind == 1
     f = lambda *v: " ".join(repr(float(x)) for x in v)
     q0 = np.array(m.qpos0).reshape(3, 7)
     out = ['<mujoco model="tensegrity-3bar (generated from the oracle constants)">',
@@ -35,11 +29,16 @@ def emit_mjcf(m=None):
            '  <default>',
            f'    <geom contype="1" conaffinity="1" condim="6" solref="{f(*m.solref)}" solimp="{f(*m.solimp)}" '
            f'friction="{f(m.friction[0], m.friction[2], m.friction[3])}"/>',
-           f'    <general ctrllimited="true" ctrlrange="{f(m.ctrl_lo, m.ctrl_hi)}" dyntype="none" gainprm="{f(m.gain)} 0 0" biastype="affine" '
-           f'biasprm="{f(m.bias0, m.bias1, m.bias2)}" forcelimited="true" forcerange="{f(m.force_lo, m.force_hi)}"/>',
-           '  </default>',
-           '  <worldbody>',
-           '    <geom name="floor" type="plane" size="10 10 1" pos="0 0 0"/>']
+           (f'    <general ctrllimited="true" ctrlrange="{f(m.ctrl_lo, m.ctrl_hi)}" dyntype="filter" dynprm="{f(m.act_tau)} 0 0" '
+            f'gainprm="{f(m.gain)} 0 0" biastype="none" biasprm="0 0 0"/>') if uneven else
+           (f'    <general ctrllimited="true" ctrlrange="{f(m.ctrl_lo, m.ctrl_hi)}" dyntype="none" gainprm="{f(m.gain)} 0 0" biastype="affine" '
+            f'biasprm="{f(m.bias0, m.bias1, m.bias2)}" forcelimited="true" forcerange="{f(m.force_lo, m.force_hi)}"/>'),
+           '  </default>']
+    if uneven:
+        out += ['  <asset>', f'    <hfield name="terrain" file="{hfield_file}" nrow="0" ncol="0" size="{f(*m.hf_size)}"/>', '  </asset>']
+    out += ['  <worldbody>',
+            (f'    <geom name="floor" type="hfield" hfield="terrain" condim="3" pos="{f(*m.hf_pos)}"/>' if uneven else
+             '    <geom name="floor" type="plane" size="10 10 1" pos="0 0 0"/>')]
     # geom masses behind the oracle's mass/inertia: cylinder 1.0, caps 0.5, end cylinders 1.0 (total 4.0)
     for b in range(3):
         out.append(f'    <body name="bar{b}" pos="{f(*q0[b, :3])}" quat="{f(*q0[b, 3:])}">')
@@ -50,7 +49,7 @@ def emit_mjcf(m=None):
             out.append(f'      <geom name="b{2 * b + e}" type="cylinder" size="{f(m.bcyl_radius)}" '
                        f'fromto="0 0 {f(sgn * m.bcyl_hi)} 0 0 {f(sgn * m.bcyl_lo)}" mass="1.0"/>')
         for s in range(6):
-            out.append(f'      <site name="bar{b}_site{s}" pos="{f(sg[s, 0] * m.site_off, sg[s, 1] * m.site_off, sg[s, 2] * m.site_z)}" size="0.01"/>')
+            out.append(f'      <site name="bar{b}_site{s}" pos="{f(*sl[s])}" size="0.01"/>')
         out.append('    </body>')
     out.append('  </worldbody>')
     out.append('  <tendon>')

@@ -21,7 +21,7 @@ class _GymEnvBase:
         self.render_mode = None
         self.xml_file = xml_file
         self._venv = TensegrityVecEnv(1, self._env_id, device=device, precision=precision, auto_reset=False,
-                                      max_episode_steps=max_episode_steps, seed=seed, info_mode="full", **kwargs)
+                                      max_episode_steps=max_episode_steps, seed=seed, info_mode="full", xml_file=xml_file, **kwargs)
         self.observation_space = self._venv.observation_space
         self.action_space = self._venv.action_space
         self.frame_skip = self._venv.frame_skip

@@ -40,6 +40,20 @@ def heights_from_image(img):
     return np.ascontiguousarray(a[::-1], dtype=np.float32)
 
 
+def _terrain_next_to(xml_file):
+    """the <hfield file=...> image the model document refers to, when the caller points at a real checkout of the XML"""
+    if not isinstance(xml_file, str) or not os.path.isfile(xml_file):
+        return None
+    try:
+        import xml.etree.ElementTree as ET
+        from PIL import Image
+        node = ET.parse(xml_file).getroot().find("asset/hfield")
+        path = os.path.join(os.path.dirname(xml_file), node.get("file"))
+        return np.array(Image.open(path))
+    except Exception:
+        return None
+
+
 def is_uneven_xml(xml_file):
     return isinstance(xml_file, str) and "uneven" in os.path.basename(xml_file)
 
@@ -113,6 +127,8 @@ class TensegrityVecEnv:
         rc = self.lib.tgr_create(C.byref(self.cfg), self.num_envs, self.device_index, C.byref(self.handle))
         N.check(self.handle if self.handle else None, rc, "tgr_create")
         if self.cfg.model_kind == 1:
+            if terrain is None:
+                terrain = _terrain_next_to(kwargs.get("xml_file"))
             if terrain is None:
                 raise ValueError("the uneven-ground model needs terrain= (the heightfield image or normalised elevations)")
             t_ = np.asarray(terrain)

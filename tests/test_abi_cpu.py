@@ -65,6 +65,10 @@ def test_make_config_kwargs_follow_reference_signatures():
         make_config("nope-v0")
     c = make_config("tr_env-v0", use_obs_noise=True, obs_noise_tendon_stdev=0.03)
     assert c.use_obs_noise == 1 and c.obs_noise_tendon_stdev == 0.03 and c.obs_noise_cap_pos_stdev == 0.05
+    c = make_config("tr_env-v0", xml_file="/somewhere/3prism_jonathan_steady_side_uneven_ground.xml")   # run.py --env_xml
+    assert c.model_kind == 1 and c.cap_radius == 0.05 and c.site_offset == 0.05 and c.gain == 15000 and list(c.bias) == [0, 0, 0]
+    assert list(c.ten_stiffness) == [10000.0] * 9 and list(c.ten_springlength) == [0.5] * 6 + [0.8] * 3 and list(c.hf_size) == [50, 50, 1, 0.1]
+    assert make_config("tr_env-v0", xml_file="/somewhere/3prism_jonathan_steady_side.xml").model_kind == 0
     with pytest.raises(NotImplementedError):
         make_config("tr_env-v0", use_cap_size_noise=True)
 
