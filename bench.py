@@ -23,10 +23,10 @@ sys.path.insert(0, ROOT)
 
 def profiled_traffic():
     """HBM bytes per step_kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/round1_bench_rocprofv3_summary_v3.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB per
+    (profiles/round1_bench_rocprofv3_summary_v4.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB per
     dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).  None when the profile is not there."""
     import json as _j, os as _o
-    f = _o.path.join(_o.path.dirname(_o.path.abspath(__file__)), "profiles", "round1_bench_rocprofv3_summary_v3.json")
+    f = _o.path.join(_o.path.dirname(_o.path.abspath(__file__)), "profiles", "round1_bench_rocprofv3_summary_v4.json")
     try:
         d = _j.load(open(f))
         fe, wr = d["fetch"]["tgr::step_kernel"], d["write"]["tgr::step_kernel"]
