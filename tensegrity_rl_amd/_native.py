@@ -52,6 +52,13 @@ def load():
     path = os.environ.get("TGR_LIB") or _build.lib_path()
     if not os.environ.get("TGR_LIB") and _build.needs_build():
         path = _build.build()
+    try:
+        # torch ships its own libamdhip64; the library must bind to the HIP runtime torch uses (same device state, same
+        # streams), so torch goes first.  Loaded the other way round the process ends up with two runtimes and
+        # hipGetDeviceCount fails inside the library (seen on MI355X when build() and smoke() ran in one process).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp = C.c_void_p
     L.tgr_default_config.argtypes = [C.POINTER(Config), C.c_int, C.c_int]
