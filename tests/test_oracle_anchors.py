@@ -181,3 +181,38 @@ def test_mujoco_trained_tracking_policy_closes_in_on_its_waypoint(oracle, golden
     assert not wrench_trip.any()
     assert int(np.sum(d0 - dmin > 1.0)) >= 3 and dmin.min() < 0.5, (d0 - dmin)
     ob.close()
+
+
+def test_uneven_model_settles_on_the_heightfield_and_carries_its_weight(oracle, golden_dir):
+    """uneven-ground model: reset_model() drops the robot ~0.8 m onto terrain_image_100.png's heightfield; after
+    the 50 settle periods plus 2 s at constant tendon targets it stands on the terrain (caps within a cap radius of the surface
+    between z = -1 and 0, never on a z = 0 plane), nearly at rest, and the contact forces balance gravity."""
+    import os
+    import ctypes as C
+    from tensegrity_rl_amd.vec_env import heights_from_image
+    O = oracle
+    h = heights_from_image(np.load(os.path.join(golden_dir, "terrain_100.npy")))
+    assert h.shape == (100, 100) and h.min() == 0.0 and h.max() == 1.0
+    cfg = O.make_cfg("tensegrity_env", "straight", heights=h, model_kind=1, terminate_when_unhealthy=0)
+    for seed in (0, 1):
+        e = O.OracleEnv(cfg)
+        e.reset_seeded(7, seed, 0)
+        d = e.data
+        a = O.arr(d.ctrl).astype(np.float32).copy()
+        for _ in range(100):
+            e.step(a)
+        z = O.arr(d.qpos).reshape(3, 7)[:, 2]
+        assert z.max() < 0.2 and z.min() > -1.1
+        assert np.abs(O.arr(d.qvel).reshape(3, 6)[:, :3]).max() < 0.05 and np.abs(O.arr(d.qvel)).max() < 0.3  # the activations are still creeping
+        fzs = []
+        for _ in range(25):   # soft contacts chatter from sub-step to sub-step: average the snapshots of 25 control periods
+            e.step(a)
+            fz = 0.0
+            for i in range(d.ncon):
+                c = d.con[i]
+                if c.body1 == -1:  # terrain contact: world force on the bar = sum_j force_j * frame_row_j
+                    fr = np.array(list(c.frame)).reshape(3, 3)
+                    fz += c.force[0] * fr[0, 2] + c.force[1] * fr[1, 2] + c.force[2] * fr[2, 2]
+            fzs.append(fz)
+        assert abs(np.mean(fzs) - 12 * 9.81) < 0.05 * 12 * 9.81, (np.mean(fzs), fzs[:5])
+        assert np.abs(O.arr(d.act) - np.clip(a, -0.45, 0.15)).max() < 0.1   # activations have followed the targets (tau = 1 s, 3 s)
