@@ -439,9 +439,65 @@ static void hfield_caps(const tgo_model* m, tgo_data* d) {
   }
 }
 
+/* The r-cylinder of a bar against the heightfield.  A thin rod over piecewise-planar terrain touches it either with an end --
+ * which the cap sphere around that end reaches first -- or where it crosses a convex ridge, i.e. a grid edge.  So the bar is
+ * tested, as a capsule of the cylinder's radius around its axis, against the grid edges under its bounding box (cell sides and
+ * the strip diagonal); the deepest one is kept (one contact per bar).  MuJoCo runs its convex test on every prism under the
+ * geom instead; the b-cylinders (radially inside the r-cylinder) are not tested. */
+static void hfield_bars(const tgo_model* m, tgo_data* d) {
+  const int nr = m->hf_nrow, nc = m->hf_ncol;
+  const double rx = m->hf_size[0], ry = m->hf_size[1], ez = m->hf_size[2];
+  const double dx = 2 * rx / (nc - 1), dy = 2 * ry / (nr - 1), rad = m->rcyl_radius, H = m->bar_half;
+  for (int b = 0; b < TGO_NBAR; b++) {
+    const double* R = d->xmat[b];
+    double a[3] = {R[2], R[5], R[8]};
+    double c[3] = {d->xpos[b][0] - m->hf_pos[0], d->xpos[b][1] - m->hf_pos[1], d->xpos[b][2] - m->hf_pos[2]};
+    double ex = fabs(a[0]) * H + rad, ey = fabs(a[1]) * H + rad;
+    if (c[0] + ex < -rx || c[0] - ex > rx || c[1] + ey < -ry || c[1] - ey > ry) continue;
+    if (c[2] - fabs(a[2]) * H - rad > ez) continue;
+    int c0 = (int)floor((c[0] - ex + rx) / dx), c1 = (int)floor((c[0] + ex + rx) / dx) + 1;
+    int r0 = (int)floor((c[1] - ey + ry) / dy), r1 = (int)floor((c[1] + ey + ry) / dy) + 1;
+    if (c0 < 0) c0 = 0;
+    if (r0 < 0) r0 = 0;
+    if (c1 > nc - 1) c1 = nc - 1;
+    if (r1 > nr - 1) r1 = nr - 1;
+    double best = 0, bpa[3] = {0, 0, 0}, bpb[3] = {0, 0, 0}; int have = 0;
+    for (int r = r0; r <= r1; r++)
+      for (int cc = c0; cc <= c1; cc++) {
+        /* edges starting at vertex (cc, r): to (cc+1, r), to (cc, r+1), and the strip diagonal (cc, r+1)-(cc+1, r) */
+        static const int E[3][4] = {{0, 0, 1, 0}, {0, 0, 0, 1}, {0, 1, 1, 0}};
+        for (int k = 0; k < 3; k++) {
+          int ca = cc + E[k][0], ra = r + E[k][1], cb = cc + E[k][2], rb = r + E[k][3];
+          if (ca > nc - 1 || cb > nc - 1 || ra > nr - 1 || rb > nr - 1) continue;
+          double va[3] = {ca * dx - rx, ra * dy - ry, (double)m->hf_data[ra * nc + ca] * ez};
+          double vb[3] = {cb * dx - rx, rb * dy - ry, (double)m->hf_data[rb * nc + cb] * ez};
+          double mid[3], ed[3];
+          for (int i = 0; i < 3; i++) { mid[i] = 0.5 * (va[i] + vb[i]); ed[i] = vb[i] - va[i]; }
+          double el = norm3(ed);
+          if (el < MINVAL) continue;
+          for (int i = 0; i < 3; i++) ed[i] /= el;
+          double s_, t_;
+          seg_seg(c, a, H, mid, ed, 0.5 * el, &s_, &t_);
+          double pa[3], pb[3], df[3];
+          for (int i = 0; i < 3; i++) { pa[i] = c[i] + s_ * a[i]; pb[i] = mid[i] + t_ * ed[i]; df[i] = pa[i] - pb[i]; }
+          double dist = norm3(df) - rad;
+          if (dist < 0 && (!have || dist < best)) { have = 1; best = dist; memcpy(bpa, pa, 24); memcpy(bpb, pb, 24); }
+        }
+      }
+    if (!have) continue;
+    double n[3] = {bpa[0] - bpb[0], bpa[1] - bpb[1], bpa[2] - bpb[2]};
+    double nn = norm3(n);
+    if (nn < MINVAL) { d->flags |= TGO_FLAG_DEEP; continue; }
+    for (int i = 0; i < 3; i++) n[i] /= nn;
+    double pos[3];
+    for (int i = 0; i < 3; i++) pos[i] = bpa[i] + m->hf_pos[i] - n[i] * (rad + 0.5 * best);
+    add_contact(d, pos, n, best, -1, b, 0, 1 + 5 * b);
+  }
+}
+
 static void collision(const tgo_model* m, tgo_data* d) {
   d->ncon = 0;
-  if (m->hf_data) hfield_caps(m, d);
+  if (m->hf_data) { hfield_caps(m, d); hfield_bars(m, d); }
   /* floor plane (geom 0, z=0, normal +z) vs the 6 cap spheres: mjc_PlaneSphere */
   for (int b = 0; b < TGO_NBAR && !m->hf_data; b++) {
     for (int e = 0; e < 2; e++) {

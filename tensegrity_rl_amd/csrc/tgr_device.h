@@ -108,8 +108,13 @@ enum : int {
   L_RED = L_X + 9,      // cross-wave partial sums and exchange slots (50)
   L_TOTAL = L_RED + 50  // 545
 };
-constexpr int L_FN = L_TOTAL;  // MODEL = 1 only: normals of the six floor contacts (18)
-template <int MODEL> constexpr __host__ __device__ int lds_slots() { return MODEL ? L_TOTAL + 18 : L_TOTAL; }
+// MODEL = 1 only (heightfield floor): normals of the six cap contacts, and one bar(cylinder)-terrain contact per bar
+constexpr int L_FN = L_TOTAL;       // 6 x n(3)
+constexpr int L_FR = L_FN + 18;     // 3 x {rB(3), c0, Dn, active}
+constexpr int L_FRN = L_FR + 18;    // 3 x n(3)
+template <int MODEL> constexpr __host__ __device__ int lds_slots() { return MODEL ? L_FRN + 9 : L_TOTAL; }
+template <int MODEL> constexpr __host__ __device__ int n_floor() { return MODEL ? 3 : 2; }  // floor contacts per bar wave
+template <int MODEL> constexpr __host__ __device__ int num_ls() { return MODEL ? 4 : 3; }     // line-search slots per wave
 constexpr __host__ __device__ int H_D(int b) { return L_H + 21 * b; }
 constexpr int H_O10 = L_H + 63, H_O20 = L_H + 99, H_O21 = L_H + 135;
 
@@ -199,10 +204,11 @@ template <typename T> TGR_DEV void contact_params(const Params<T>& P, T dist, in
   c.Dn = rcp_(R0);
   c.c0 = P.K * imp * dist;
 }
+// floor contact k: 0..5 = cap k; MODEL = 1 additionally 6..8 = the cylinder of bar k - 6 against the terrain
 template <typename T, int LW, int MODEL = 0> TGR_DEV Contact<T> load_floor(const T* lds, int k) {
   Contact<T> c;
-  const int s = L_CF + 6 * k;
-  c.n = MODEL ? ld3<T, LW>(lds, L_FN + 3 * k) : mk(T(0), T(0), T(1));
+  const int s = (MODEL && k >= 6) ? L_FR + 6 * (k - 6) : L_CF + 6 * k;
+  c.n = MODEL ? ld3<T, LW>(lds, k >= 6 ? L_FRN + 3 * (k - 6) : L_FN + 3 * k) : mk(T(0), T(0), T(1));
   c.rA = mk(T(0), T(0), T(0));
   c.rB = ld3<T, LW>(lds, s);
   c.c0 = lds[(s + 3) * LW]; c.Dn = lds[(s + 4) * LW]; c.active = lds[(s + 5) * LW] != T(0);
@@ -688,8 +694,8 @@ TGR_DEV T newton_assemble(const Params<T>& P, T* lds, int wid, unsigned cpl, T& 
     V3<T> ya = aa + ld3<T, LW>(lds, L_BV + 6 * b + 3);
     V3<T> fl = mk(T(0), T(0), T(0)), fa = fl;
 #pragma unroll 1
-    for (int e = 0; e < 2; e++) {
-      Contact<T> c = load_floor<T, LW, MODEL>(lds, 2 * b + e);
+    for (int e = 0; e < n_floor<MODEL>(); e++) {
+      Contact<T> c = load_floor<T, LW, MODEL>(lds, e < 2 ? 2 * b + e : 6 + b);
       if (__any(c.active)) {
         V3<T> jl = yl + cross(ya, c.rB);
         if (MODEL) jl = jl + c.c0 * c.n; else jl.z += c.c0;
@@ -956,19 +962,19 @@ TGR_DEV LSlot<T> ls_pair_slot(const Params<T>& P, const T* lds, int p, int s) {
 template <typename T, int LW, int MODEL>
 TGR_DEV void ls_setup(const Params<T>& P, const T* lds, int wid, unsigned cpl, LSlot<T>* ls) {
 #pragma unroll
-  for (int k = 0; k < 3; k++) { ls[k].act = false; ls[k].A0 = ls[k].A1 = ls[k].A2 = ls[k].B0 = ls[k].B1 = ls[k].B2 = T(0); ls[k].jn0 = ls[k].qn = ls[k].jo0 = ls[k].qo = T(0); ls[k].Dn = T(0); }
+  for (int k = 0; k < num_ls<MODEL>(); k++) { ls[k].act = false; ls[k].A0 = ls[k].A1 = ls[k].A2 = ls[k].B0 = ls[k].B1 = ls[k].B2 = T(0); ls[k].jn0 = ls[k].qn = ls[k].jo0 = ls[k].qo = T(0); ls[k].Dn = T(0); }
   if (wid < 3) {
     const int b = wid;
     V3<T> pl = ld3<T, LW>(lds, L_P + 6 * b), pa = ld3<T, LW>(lds, L_P + 6 * b + 3);
     V3<T> yl = ld3<T, LW>(lds, L_A + 6 * b) + ld3<T, LW>(lds, L_BV + 6 * b);
     V3<T> ya = ld3<T, LW>(lds, L_A + 6 * b + 3) + ld3<T, LW>(lds, L_BV + 6 * b + 3);
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-      Contact<T> c = load_floor<T, LW, MODEL>(lds, 2 * b + e);
+    for (int e = 0; e < n_floor<MODEL>(); e++) {
+      Contact<T> c = load_floor<T, LW, MODEL>(lds, e < 2 ? 2 * b + e : 6 + b);
       V3<T> jl = yl + cross(ya, c.rB);
       if (MODEL) jl = jl + c.c0 * c.n; else jl.z += c.c0;
       V3<T> ql = pl + cross(pa, c.rB);
-      ls[e] = ls_make(c, jl, ya, ql, pa);
+      ls[e < 2 ? e : 3] = ls_make(c, jl, ya, ql, pa);  // slot 2 is the wave's pair slot
     }
     if ((cpl >> b) & 1u) ls[2] = ls_pair_slot<T, LW>(P, lds, b, 0);
   } else {
@@ -979,11 +985,11 @@ TGR_DEV void ls_setup(const Params<T>& P, const T* lds, int wid, unsigned cpl, L
 }
 
 // one barrier per evaluation: partial sums go to alternating halves of the reduction area
-template <typename T, int LW>
+template <typename T, int LW, int NLS>
 TGR_DEV void newton_dphi(const Params<T>& P, T* lds, int wid, const LSlot<T>* ls, int parity, T alpha, T g1, T g2, T& d1, T& d2) {
   T p1 = T(0), p2 = T(0);
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < NLS; k++) {
     if (__any(ls[k].act)) {
       T a, b;
       ls_slot(P, ls[k], alpha, a, b);
@@ -1068,6 +1074,75 @@ template <typename T> TGR_DEV T hfield_cap(const Params<T>& P, V3<T> cw, V3<T>& 
   T nn = sqrt_(dot(df, df));
   if (!(nn > T(1e-12))) return T(1);
   n_out = rcp_(nn) * df;
+  return best;
+}
+
+// closest points of two segments c + s a (|s| <= ha) and c2 + t a2 (|t| <= hb), unit axes (Ericson 5.1.9)
+template <typename T> TGR_DEV void seg_seg_closest(V3<T> ca, V3<T> aa, T ha, V3<T> cb, V3<T> ab, T hb, T& s_out, T& t_out) {
+  V3<T> w = ca - cb;
+  T b = dot(aa, ab), dA = dot(aa, w), dB = dot(ab, w);
+  T den = T(1) - b * b;
+  T s, t;
+  bool interior = false;
+  if (den > T(1e-12)) {
+    s = (b * dB - dA) / den;
+    t = (dB - b * dA) / den;
+    interior = abs_(s) < ha && abs_(t) < hb;
+  } else {
+    s = T(0); t = dB;
+  }
+  if (!interior) {
+    s = clamp_(s, -ha, ha);
+    t = clamp_(dB + b * s, -hb, hb);
+    s = clamp_(b * t - dA, -ha, ha);
+  }
+  s_out = s; t_out = t;
+}
+// the r-cylinder of a bar (centre xc, axis az, world) against the heightfield: deepest grid edge under the bar, the bar taken
+// as a capsule of the cylinder's radius (a rod over piecewise-planar terrain touches it at a convex ridge or with an end, and
+// the ends belong to the cap spheres).  Returns dist (>= 0: none); n_out = normal, arm_out = contact point - bar centre.
+template <typename T> TGR_DEV T hfield_rod(const Params<T>& P, V3<T> xc, V3<T> az, V3<T>& n_out, V3<T>& arm_out) {
+  const T rad = P.rcyl_r, H = P.bar_half;
+  n_out = mk(T(0), T(0), T(1)); arm_out = mk(T(0), T(0), T(0));
+  V3<T> c = mk(xc.x - P.hf_x0, xc.y - P.hf_y0, xc.z - P.hf_z0);
+  const T ex = abs_(az.x) * H + rad, ey = abs_(az.y) * H + rad;
+  if (c.x + ex < -P.hf_rx || c.x - ex > P.hf_rx || c.y + ey < -P.hf_ry || c.y - ey > P.hf_ry) return T(1);
+  if (c.z - abs_(az.z) * H - rad > P.hf_ez) return T(1);
+  const T idx = rcp_(P.hf_dx), idy = rcp_(P.hf_dy);
+  int c0 = (int)floor(double((c.x - ex + P.hf_rx) * idx)), c1 = (int)floor(double((c.x + ex + P.hf_rx) * idx)) + 1;
+  int r0 = (int)floor(double((c.y - ey + P.hf_ry) * idy)), r1 = (int)floor(double((c.y + ey + P.hf_ry) * idy)) + 1;
+  c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
+  c1 = c1 > P.hf_ncol - 1 ? P.hf_ncol - 1 : c1; r1 = r1 > P.hf_nrow - 1 ? P.hf_nrow - 1 : r1;
+  T best = T(1);
+  V3<T> bpa = c, bpb = c;
+  for (int r = r0; r <= r1; r++)
+    for (int cc = c0; cc <= c1; cc++) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        // edges starting at vertex (cc, r): to (cc+1, r), to (cc, r+1), and the strip diagonal (cc, r+1)-(cc+1, r)
+        const int ca = cc + (k == 2 ? 0 : 0), ra = r + (k == 2 ? 1 : 0), cb = cc + (k == 1 ? 0 : 1), rb = r + (k == 1 ? 1 : 0);
+        if (ca > P.hf_ncol - 1 || cb > P.hf_ncol - 1 || ra > P.hf_nrow - 1 || rb > P.hf_nrow - 1) continue;
+        V3<T> va = mk(T(ca) * P.hf_dx - P.hf_rx, T(ra) * P.hf_dy - P.hf_ry, T(P.hf[ra * P.hf_ncol + ca]) * P.hf_ez);
+        V3<T> vb = mk(T(cb) * P.hf_dx - P.hf_rx, T(rb) * P.hf_dy - P.hf_ry, T(P.hf[rb * P.hf_ncol + cb]) * P.hf_ez);
+        V3<T> ed = vb - va;
+        T el = sqrt_(dot(ed, ed));
+        if (!(el > T(1e-12))) continue;
+        ed = rcp_(el) * ed;
+        V3<T> mid = T(0.5) * (va + vb);
+        T s_, t_;
+        seg_seg_closest(c, az, H, mid, ed, T(0.5) * el, s_, t_);
+        V3<T> pa = c + s_ * az, pb = mid + t_ * ed;
+        V3<T> df = pa - pb;
+        T dist = sqrt_(dot(df, df)) - rad;
+        if (dist < T(0) && dist < best) { best = dist; bpa = pa; bpb = pb; }
+      }
+    }
+  if (best >= T(0)) return T(1);
+  V3<T> df = bpa - bpb;
+  T nn = sqrt_(dot(df, df));
+  if (!(nn > T(1e-12))) return T(1);
+  n_out = rcp_(nn) * df;
+  arm_out = (bpa - c) - (rad + T(0.5) * best) * n_out;
   return best;
 }
 
@@ -1164,6 +1239,18 @@ TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* l
       lds[(s + 3) * LW] = c.c0; lds[(s + 4) * LW] = c.Dn; lds[(s + 5) * LW] = dist < T(0) ? T(1) : T(0);
     }
   }
+  if (MODEL) {  // the bar's cylinder against the terrain
+    V3<T> n, arm;
+    T dist = hfield_rod(P, S.x[B], R[B].ez, n, arm);
+    const bool hit = dist < T(0);
+    if (!hit) dist = T(0);
+    Contact<T> c;
+    contact_params(P, dist, 1, c);
+    const int s = L_FR + 6 * B;
+    st3<T, LW>(lds, s, arm);
+    st3<T, LW>(lds, L_FRN + 3 * B, n);
+    lds[(s + 3) * LW] = c.c0; lds[(s + 4) * LW] = c.Dn; lds[(s + 5) * LW] = hit ? T(1) : T(0);
+  }
   // bar pair B = (pA, pB)
   {
     constexpr int pA = B == 2 ? 1 : 0, pB = B == 0 ? 1 : 2;
@@ -1210,6 +1297,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, Lag<T>& lag
   T nact = T(0);  // the flags are 0/1: one batch of reads and a sum (a short-circuit `||` would expose twelve LDS round trips)
 #pragma unroll
   for (int k = 0; k < 6; k++) nact += lds[(L_CF + 6 * k + 5) * LW] + lds[(L_CP + 12 * k + 11) * LW];
+  if (MODEL) nact += lds[(L_FR + 5) * LW] + lds[(L_FR + 11) * LW] + lds[(L_FR + 17) * LW];
   const bool any_contact = nact != T(0);
   if (last) lag.overflow = (int)(lds[(L_RED + 32) * LW] + lds[(L_RED + 33) * LW] + lds[(L_RED + 34) * LW]);
   if (P.warm_start && wid < 3 && !any_contact) {
@@ -1255,13 +1343,13 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, Lag<T>& lag
       lds[(L_RED + 24 + 3 * b) * LW] = dot(pl, ld3<T, LW>(lds, L_G + 6 * b)) + dot(pa, ld3<T, LW>(lds, L_G + 6 * b + 3));
     }
     // the line-search slots, and their contribution at the first trial point alpha = 1, ride on the same barrier
-    LSlot<T> lsl[3];
+    LSlot<T> lsl[num_ls<MODEL>()];
     ls_setup<T, LW, MODEL>(P, lds, wid, cpl, lsl);
     n_ls++;
     {
       T p1 = T(0), p2 = T(0);
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
+      for (int k = 0; k < num_ls<MODEL>(); k++) {
         if (__any(lsl[k].act)) {
           T a, b;
           ls_slot(P, lsl[k], T(1), a, b);
@@ -1306,7 +1394,7 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, Lag<T>& lag
       }
       if (__all(ls_done) || ls + 1 >= P.ls_iter) break;
       n_ls++;
-      newton_dphi<T, LW>(P, lds, wid, lsl, n_ls & 1, alpha, g1, g2, d1, d2);
+      newton_dphi<T, LW, num_ls<MODEL>()>(P, lds, wid, lsl, n_ls & 1, alpha, g1, g2, d1, d2);
     }
 #ifdef TGR_DEBUG_ENV
     if (wid == 0 && (int)(blockIdx.x * LW + (threadIdx.x & 63)) == TGR_DEBUG_ENV)

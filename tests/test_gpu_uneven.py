@@ -31,7 +31,7 @@ def test_uneven_fp64_matches_oracle(oracle, golden_dir, kind):
                            xml_file="3prism_jonathan_steady_side_uneven_ground.xml", terrain=img)
     assert env.cfg.model_kind == 1 and env.cfg.cap_radius == 0.05
     rng = np.random.default_rng(2)
-    ncon = 0
+    ncon = nrod = 0
     for t in range(6):
         oracle_to_gpu_state(ob, env)
         a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
@@ -44,7 +44,11 @@ def test_uneven_fp64_matches_oracle(oracle, golden_dir, kind):
         assert np.abs(st["aux"][:, 17:23] - ob.last_act).max() < 1e-12      # activations: act += h (ctrl - act) / tau
         assert np.abs(g_obs - o_obs).max() < 1e-5 and np.abs(g_rew - o_rew).max() < 1e-6 and not (g_term.astype(bool) != o_term).any()
         ncon += sum(ob.env(i).data.ncon for i in range(n))
+        for i in range(n):
+            dd = ob.env(i).data
+            nrod += sum(1 for j in range(dd.ncon) if dd.con[j].body1 == -1 and (dd.con[j].geom2 - 1) % 5 == 0)
     assert ncon > n  # the robots do stand on the terrain
+    assert nrod > 0  # ... and some bars lie across ridges (cylinder-terrain contacts are exercised)
     assert np.abs(ob.last_act).max() > 0.01
     z = q2.reshape(n, 3, 7)[:, :, 2]
     assert z.max() < 0.0 and z.min() > -1.2   # resting on the heightfield (surface between z = -1 and 0), not on a z = 0 plane
