@@ -107,7 +107,12 @@ def main():
     local_rank = 0 if rehearsal else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # TGR_BENCH_FORCE_DIST=1: run the N>1 code path (process group over RCCL, all-gathers, max-reduce of the time) with a single
+    # rank -- checks that RCCL comes up on a one-GPU box; costs a little, so it is never the default
+    force_dist = os.environ.get("TGR_BENCH_FORCE_DIST") == "1" and world == 1
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", "29531"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -126,7 +131,8 @@ def main():
     env.reset_tensors()
     g = torch.Generator(device=dev); g.manual_seed(rank)
     acts = [(torch.rand((n_local, 6), device=dev, generator=g) * 0.6 - 0.45).contiguous() for _ in range(32)]
-    gather = RolloutGatherer(n_local, env.obs_dim, args.gather_every, dev, world_size=world) if world > 1 else None
+    gather = (RolloutGatherer(n_local, env.obs_dim, args.gather_every, dev, world_size=world, always_collective=force_dist)
+              if (world > 1 or force_dist) else None)
 
     def one_step(i):
         obs, rew, term, trunc, _, _ = env.step_tensors(acts[i % 32])
@@ -138,7 +144,8 @@ def main():
     stats0 = env.stats()
     # kernel-only timing of the dominant kernel with HIP events on the launch stream (roofline.achieved)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    multi = world > 1 or force_dist
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -146,11 +153,11 @@ def main():
         evs[i][0].record()
         one_step(args.warmup + i)
         evs[i][1].record()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -188,7 +195,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
     env.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

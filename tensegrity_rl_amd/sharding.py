@@ -15,14 +15,16 @@ def shard_range(rank, world_size, n_total):
 class RolloutGatherer:
     """Collects K steps of per-rank rollout tensors and all-gathers them in one collective per field."""
 
-    def __init__(self, n_local, obs_dim, chunk, device, dtype=torch.float32, world_size=None):
+    def __init__(self, n_local, obs_dim, chunk, device, dtype=torch.float32, world_size=None, always_collective=False):
+        """always_collective: issue the all-gathers even for a world of one rank (exercises RCCL on a one-GPU box)"""
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.always = bool(always_collective)
         self.chunk = chunk
         self.i = 0
         self.obs = torch.zeros((chunk, n_local, obs_dim), dtype=dtype, device=device)
         self.rew = torch.zeros((chunk, n_local), dtype=dtype, device=device)
         self.done = torch.zeros((chunk, n_local), dtype=torch.uint8, device=device)
-        if self.world > 1:
+        if self.world > 1 or self.always:
             # concatenated along dim 0 (the layout both RCCL and gloo accept for all_gather_into_tensor)
             self.g_obs = torch.zeros((self.world * chunk, n_local, obs_dim), dtype=dtype, device=device)
             self.g_rew = torch.zeros((self.world * chunk, n_local), dtype=dtype, device=device)
@@ -37,7 +39,7 @@ class RolloutGatherer:
         if self.i < self.chunk:
             return None
         self.i = 0
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return self.obs.unsqueeze(0), self.rew.unsqueeze(0), self.done.unsqueeze(0)
         dist.all_gather_into_tensor(self.g_obs, self.obs)
         dist.all_gather_into_tensor(self.g_rew, self.rew)
