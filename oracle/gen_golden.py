@@ -77,10 +77,19 @@ class FakeData:
         return _Named(xpos=self._xpos[b])
 
 
+def terrain_heights():
+    """normalised elevations of tests/golden/terrain_100.npy (grey level, (h - min) / (max - min), rows flipped: top row = +y)"""
+    img = np.load(os.path.join(ROOT, "tests", "golden", "terrain_100.npy")).astype(np.float64)
+    return np.ascontiguousarray(((img - img.min()) / (img.max() - img.min()))[::-1], dtype=np.float32)
+
+
 class MujocoEnv:
     def __init__(self, model_path, frame_skip, observation_space=None, render_mode=None, **kw):
         self._L = O.lib()
-        self._m = O.default_model()
+        if "uneven" in os.path.basename(str(model_path)):   # run.py --env_xml 3prism_jonathan_steady_side_uneven_ground.xml
+            self._m = O.uneven_model(terrain_heights())
+        else:
+            self._m = O.default_model()
         self._dd = O.new_data(self._m)
         self._L.tgo_forward(C.byref(self._m), C.byref(self._dd))
         self.model = _Named(nq=O.NQ, nv=O.NV, opt=_Named(timestep=self._m.timestep))
@@ -170,7 +179,7 @@ def replay_draws(kind, seed, mean, std, lo, hi, action):
     return pose, theta, t, u_way
 
 
-def run_case(kind, action, seed, steps, direction=1, **kwargs):
+def run_case(kind, action, seed, steps, direction=1, model="flat", **kwargs):
     if kind == "tensegrity_env":
         from tensegrity_env.envs.tensegrity_env import tensegrity_env as cls
         mean, std, lo, hi = -0.15, 0.1, -0.45, -0.15
@@ -178,10 +187,11 @@ def run_case(kind, action, seed, steps, direction=1, **kwargs):
         from tr_env.envs.tr_env import tr_env as cls
         mean, std, lo, hi = 0.15, 0.2, -0.45, 0.15
     np.random.default_rng = lambda *a, **k: _real_default_rng(seed) if not a and not k else _real_default_rng(*a, **k)
-    env = cls(xml_file="unused.xml", desired_action=action, desired_direction=direction, **kwargs)
-    out = {"kind": kind, "action": action, "direction": direction}
+    xml = "3prism_jonathan_steady_side_uneven_ground.xml" if model == "uneven" else "unused.xml"
+    env = cls(xml_file=xml, desired_action=action, desired_direction=direction, **kwargs)
+    out = {"kind": kind, "action": action, "direction": direction, "model_kind": int(model == "uneven")}
     ep_resets = []
-    rec = {k: [] for k in ["obs", "reward", "terminated", "qpos", "qvel", "actions", "ctrl"] + INFO_SCALARS}
+    rec = {k: [] for k in ["obs", "reward", "terminated", "qpos", "qvel", "actions", "ctrl", "act"] + INFO_SCALARS}
     arng = _real_default_rng(1000 + seed)
     n_resets = 2
     for ep in range(n_resets):
@@ -192,6 +202,7 @@ def run_case(kind, action, seed, steps, direction=1, **kwargs):
         pose, theta, tendons, u_way = replay_draws(kind, s, mean, std, lo, hi, action)
         ep_resets.append(dict(pose=pose, theta=theta, tendons=tendons, u_way=u_way, obs=np.array(obs0, dtype=np.float64),
                               qpos=env.data.qpos.copy(), qvel=env.data.qvel.copy(), reset_psi=float(env._reset_psi), ctrl=env.data.ctrl.copy(),
+                              act=O.arr(env._dd.act).copy(),
                               xy_lag=np.array([np.mean([env.data.body(b).xpos[i] for b in ('r01_body', 'r23_body', 'r45_body')]) for i in range(2)]),
                               waypt=np.array(getattr(env, "_waypt", np.zeros(2)), dtype=np.float64).reshape(-1)[:2]
                               if np.size(getattr(env, "_waypt", np.zeros(0))) == 2 else np.zeros(2),
@@ -202,7 +213,7 @@ def run_case(kind, action, seed, steps, direction=1, **kwargs):
                 a = (a * 1.5).astype(np.float32)  # exercise ctrl clamping (values outside ctrlrange)
             obs, r, term, trunc, info = env.step(a)
             rec["obs"].append(np.array(obs, dtype=np.float64)); rec["reward"].append(float(r)); rec["terminated"].append(bool(term))
-            rec["qpos"].append(env.data.qpos.copy()); rec["qvel"].append(env.data.qvel.copy()); rec["actions"].append(a); rec["ctrl"].append(env.data.ctrl.copy())
+            rec["qpos"].append(env.data.qpos.copy()); rec["qvel"].append(env.data.qvel.copy()); rec["actions"].append(a); rec["ctrl"].append(env.data.ctrl.copy()); rec["act"].append(O.arr(env._dd.act).copy())
             for k in INFO_SCALARS:
                 rec[k].append(float(info[k]))
     for k, v in rec.items():
@@ -224,6 +235,8 @@ CASES = [
     ("tr_env", "tracking", 24, 8, 1, {}),
     ("tr_env", "aiming", 25, 8, 1, {}),
     ("tr_env", "vel_track", 26, 8, 1, {}),
+    ("tensegrity_env", "straight", 31, 6, 1, {}, "uneven"),
+    ("tr_env", "tracking", 32, 6, 1, {}, "uneven"),
 ]
 
 
@@ -275,10 +288,12 @@ def main():
     install_stubs()
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    for kind, action, seed, steps, direction, kw in CASES:
-        res = run_case(kind, action, seed, steps, direction, **kw)
+    for case in CASES:
+        kind, action, seed, steps, direction, kw = case[:6]
+        model = case[6] if len(case) > 6 else "flat"
+        res = run_case(kind, action, seed, steps, direction, model=model, **kw)
         tag = "_".join(f"{k}-{int(v) if isinstance(v, bool) else v}" for k, v in kw.items())
-        name = f"{kind}_{action}_d{direction}" + (f"_{tag}" if tag else "") + ".npz"
+        name = ("uneven_" if model == "uneven" else "") + f"{kind}_{action}_d{direction}" + (f"_{tag}" if tag else "") + ".npz"
         res["kwargs_keys"] = np.array(list(kw.keys()), dtype="U64")
         res["kwargs_vals"] = np.array([float(v) for v in kw.values()])
         np.savez_compressed(os.path.join(outdir, name), **res)

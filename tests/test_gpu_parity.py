@@ -88,17 +88,22 @@ def test_reward_obs_epilogue_against_reference_fixture(oracle, golden_dir):
     import os
     from tensegrity_rl_amd import TensegrityVecEnv
     for fname, kind in (("tensegrity_env_straight_d1.npz", "tensegrity_env"), ("tr_env_straight_d1.npz", "tr_env"),
-                        ("tr_env_straight_d1_use_cap_velocity-0.npz", "tr_env")):
+                        ("tr_env_straight_d1_use_cap_velocity-0.npz", "tr_env"), ("uneven_tensegrity_env_straight_d1.npz", "tensegrity_env"),
+                        ("uneven_tr_env_tracking_d1.npz", "tr_env")):
         g = np.load(os.path.join(golden_dir, fname))
         kw = {k: int(v) for k, v in zip(g["kwargs_keys"], g["kwargs_vals"])}
+        if int(g["model_kind"]) == 1:
+            kw.update(model="uneven", terrain=np.load(os.path.join(golden_dir, "terrain_100.npy")))
         T = int(g["steps_per_episode"])
-        env = TensegrityVecEnv(1, kind + "-v0", desired_action="straight", precision="f64", auto_reset=False, **kw)
+        env = TensegrityVecEnv(1, kind + "-v0", desired_action=str(g["action"]), precision="f64", auto_reset=False, **kw)
         k = 0
         for ep in range(len(g["reset_theta"])):
             qpos, qvel, ctrl = g["reset_qpos"][ep], g["reset_qvel"][ep], g["reset_ctrl"][ep]
             xy = g["reset_xy_lag"][ep]
+            act = g["reset_act"][ep]
             for t in range(T):
                 A = np.zeros((1, 23)); A[0, 0], A[0, 1], A[0, 3] = xy[0], xy[1], g["reset_reset_psi"][ep]
+                A[0, 9:11] = g["reset_waypt"][ep]; A[0, 11:13] = g["reset_oripoint"][ep]; A[0, 17:23] = act
                 env.set_state(qpos[None], qvel[None], ctrl[None], None, A)
                 obs, rew, term, trunc, _, info = [x.cpu().numpy() for x in env.step_tensors(g["actions"][k][None])]
                 np.testing.assert_allclose(obs[0], g["obs"][k], atol=2e-6, err_msg=f"{fname} step {k}")
@@ -106,7 +111,7 @@ def test_reward_obs_epilogue_against_reference_fixture(oracle, golden_dir):
                 for j, name in enumerate(["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
                                           "distance_from_origin", "x_velocity", "y_velocity", "forward_reward"]):
                     assert abs(info[0, j] - g[name][k]) < 2e-6, (fname, k, name)
-                qpos, qvel, ctrl = g["qpos"][k], g["qvel"][k], g["ctrl"][k]
+                qpos, qvel, ctrl, act = g["qpos"][k], g["qvel"][k], g["ctrl"][k], g["act"][k]
                 xy = np.array([g["x_position"][k], g["y_position"][k]])
                 k += 1
         env.close()

@@ -31,14 +31,18 @@ def load_cases(golden_dir):
 def cfg_from_fixture(O, g):
     kw = {k: v for k, v in zip(g["kwargs_keys"], g["kwargs_vals"])}
     kw = {k: (int(v) if k in ("terminate_when_unhealthy", "use_contact_forces", "use_cap_velocity") else float(v)) for k, v in kw.items()}
+    if "model_kind" in g.files and int(g["model_kind"]) == 1:   # the uneven-ground XML: heightfield from the committed terrain array
+        img = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "terrain_100.npy")).astype(np.float64)
+        kw["heights"] = np.ascontiguousarray(((img - img.min()) / (img.max() - img.min()))[::-1], dtype=np.float32)
+        kw["model_kind"] = 1
     return O.make_cfg(str(g["kind"]), str(g["action"]), desired_direction=float(g["direction"]), **kw)
 
 
 def test_fixtures_present(golden_dir):
-    assert len(load_cases(golden_dir)) >= 10
+    assert len(load_cases(golden_dir)) == 12
 
 
-@pytest.mark.parametrize("idx", range(10))
+@pytest.mark.parametrize("idx", range(12))
 def test_oracle_env_matches_reference_classes(oracle, golden_dir, idx):
     O = oracle
     path = load_cases(golden_dir)[idx]
