@@ -395,9 +395,9 @@ static void closest_on_triangle(const double* p, const double* a, const double* 
 /* Cap sphere against the heightfield floor.  MuJoCo (mjc_ConvexHField [ext]) walks the grid cells under the geom's bounding
  * box, turns every grid triangle into a prism and runs its convex penetration test on each; for a sphere that is shallowly
  * in contact this yields, per triangle, the closest point of the triangle, the direction from it to the centre as normal and
- * radius - distance as depth.  Restated analytically with two simplifications that DESIGN.md records: only the deepest
- * triangle of a cap is kept (one contact per cap, as on the plane), and the cell diagonal runs from (c, r+1) to (c+1, r)
- * (the order in which mujoco strips the vertices of a grid row).  Cylinders are not tested against the terrain. */
+ * radius - distance as depth.  Restated analytically with two simplifications that DESIGN.md records: only the two
+ * deepest triangles of a cap are kept, and the cell diagonal runs from (c, r+1) to (c+1, r) (the order in which mujoco
+ * strips the vertices of a grid row).  Cylinders are not tested against the terrain. */
 static void hfield_caps(const tgo_model* m, tgo_data* d) {
   const int nr = m->hf_nrow, nc = m->hf_ncol;
   const double rx = m->hf_size[0], ry = m->hf_size[1], ez = m->hf_size[2];
@@ -412,7 +412,9 @@ static void hfield_caps(const tgo_model* m, tgo_data* d) {
     if (r0 < 0) r0 = 0;
     if (c1 > nc - 2) c1 = nc - 2;
     if (r1 > nr - 2) r1 = nr - 2;
-    double best = 0, bq[3] = {0, 0, 0}; int have = 0;
+    /* the two deepest triangles touched (MuJoCo emits one contact per prism the sphere penetrates; two is what a cap resting
+     * in a fold of the terrain needs, and what it gets on the shared diagonal of a flat cell) */
+    double bd[2] = {0, 0}, bq[2][3] = {{0, 0, 0}, {0, 0, 0}}; int have = 0;
     for (int r = r0; r <= r1; r++)
       for (int c = c0; c <= c1; c++) {
         double v[4][3]; /* (c,r) (c,r+1) (c+1,r) (c+1,r+1) */
@@ -425,17 +427,26 @@ static void hfield_caps(const tgo_model* m, tgo_data* d) {
           closest_on_triangle(p, v[tri], v[tri + 1], v[tri + 2], q);
           double dif[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
           double dist = norm3(dif) - rad;
-          if (dist < 0 && (!have || dist < best)) { have = 1; best = dist; memcpy(bq, q, 24); }
+          if (!(dist < 0)) continue;
+          if (have < 1 || dist < bd[0]) {
+            bd[1] = bd[0]; memcpy(bq[1], bq[0], 24);
+            bd[0] = dist; memcpy(bq[0], q, 24);
+            have = have < 2 ? have + 1 : 2;
+          } else if (have < 2 || dist < bd[1]) {
+            bd[1] = dist; memcpy(bq[1], q, 24);
+            have = 2;
+          }
         }
       }
-    if (!have) continue;
-    double n[3] = {p[0] - bq[0], p[1] - bq[1], p[2] - bq[2]};
-    double nn = norm3(n);
-    if (nn < MINVAL) { d->flags |= TGO_FLAG_DEEP; continue; }
-    for (int i = 0; i < 3; i++) n[i] /= nn;
-    double pos[3];
-    for (int i = 0; i < 3; i++) pos[i] = cw[i] - n[i] * (rad + 0.5 * best);
-    add_contact(d, pos, n, best, -1, k / 2, 0, 1 + 5 * (k / 2) + 1 + (k % 2));
+    for (int j = 0; j < have; j++) {
+      double n[3] = {p[0] - bq[j][0], p[1] - bq[j][1], p[2] - bq[j][2]};
+      double nn = norm3(n);
+      if (nn < MINVAL) { d->flags |= TGO_FLAG_DEEP; continue; }
+      for (int i = 0; i < 3; i++) n[i] /= nn;
+      double pos[3];
+      for (int i = 0; i < 3; i++) pos[i] = cw[i] - n[i] * (rad + 0.5 * bd[j]);
+      add_contact(d, pos, n, bd[j], -1, k / 2, 0, 1 + 5 * (k / 2) + 1 + (k % 2));
+    }
   }
 }
 

@@ -105,16 +105,22 @@ enum : int {
   L_FC = L_P + 18,      // constraint wrench per bar (J^T f) == cfrc_ext
   L_EZ = L_FC + 18,     // bar axes (3 x 3)
   L_X = L_EZ + 9,       // bar COM positions (3 x 3)
-  L_RED = L_X + 9,      // cross-wave partial sums and exchange slots (50)
-  L_TOTAL = L_RED + 50  // 545
+  L_RED = L_X + 9,      // cross-wave partial sums (35)
+  L_TOTAL = L_RED + 35  // 530
 };
-// MODEL = 1 only (heightfield floor): normals of the six cap contacts, and one bar(cylinder)-terrain contact per bar
-constexpr int L_FN = L_TOTAL;       // 6 x n(3)
-constexpr int L_FR = L_FN + 18;     // 3 x {rB(3), c0, Dn, active}
+// MODEL = 1 only (heightfield floor).  Floor contact index k: 0..5 = deepest contact of cap k (data in L_CF, as on the plane),
+// 6..8 = the cylinder of bar k-6 against the terrain, 9..14 = second contact of cap k-9
+constexpr int L_FN = L_TOTAL;       // 6 x n(3)                          normals of contacts 0..5
+constexpr int L_FR = L_FN + 18;     // 3 x {rB(3), c0, Dn, active}       contacts 6..8
 constexpr int L_FRN = L_FR + 18;    // 3 x n(3)
-template <int MODEL> constexpr __host__ __device__ int lds_slots() { return MODEL ? L_FRN + 9 : L_TOTAL; }
-template <int MODEL> constexpr __host__ __device__ int n_floor() { return MODEL ? 3 : 2; }  // floor contacts per bar wave
-template <int MODEL> constexpr __host__ __device__ int num_ls() { return MODEL ? 4 : 3; }     // line-search slots per wave
+constexpr int L_F2 = L_FRN + 9;     // 6 x {rB(3), c0, Dn, active}       contacts 9..14
+constexpr int L_F2N = L_F2 + 36;    // 6 x n(3)
+template <int MODEL> constexpr __host__ __device__ int lds_slots() { return MODEL ? L_F2N + 18 : L_TOTAL; }
+template <int MODEL> constexpr __host__ __device__ int n_floor() { return MODEL ? 5 : 2; }  // floor contacts per bar wave
+template <int MODEL> constexpr __host__ __device__ int num_ls() { return MODEL ? 6 : 3; }   // line-search slots per wave
+// e-th floor contact of bar b: its two caps; MODEL = 1: then the bar's cylinder, then the caps' second contacts
+TGR_DEV int floor_index(int b, int e) { return e < 2 ? 2 * b + e : (e == 2 ? 6 + b : 9 + 2 * b + (e - 3)); }
+static_assert(L_F2N + 18 <= 640, "one block's LDS columns must fit 160 KB");
 constexpr __host__ __device__ int H_D(int b) { return L_H + 21 * b; }
 constexpr int H_O10 = L_H + 63, H_O20 = L_H + 99, H_O21 = L_H + 135;
 
@@ -207,8 +213,8 @@ template <typename T> TGR_DEV void contact_params(const Params<T>& P, T dist, in
 // floor contact k: 0..5 = cap k; MODEL = 1 additionally 6..8 = the cylinder of bar k - 6 against the terrain
 template <typename T, int LW, int MODEL = 0> TGR_DEV Contact<T> load_floor(const T* lds, int k) {
   Contact<T> c;
-  const int s = (MODEL && k >= 6) ? L_FR + 6 * (k - 6) : L_CF + 6 * k;
-  c.n = MODEL ? ld3<T, LW>(lds, k >= 6 ? L_FRN + 3 * (k - 6) : L_FN + 3 * k) : mk(T(0), T(0), T(1));
+  const int s = !MODEL || k < 6 ? L_CF + 6 * k : (k < 9 ? L_FR + 6 * (k - 6) : L_F2 + 6 * (k - 9));
+  c.n = MODEL ? ld3<T, LW>(lds, k < 6 ? L_FN + 3 * k : (k < 9 ? L_FRN + 3 * (k - 6) : L_F2N + 3 * (k - 9))) : mk(T(0), T(0), T(1));
   c.rA = mk(T(0), T(0), T(0));
   c.rB = ld3<T, LW>(lds, s);
   c.c0 = lds[(s + 3) * LW]; c.Dn = lds[(s + 4) * LW]; c.active = lds[(s + 5) * LW] != T(0);
@@ -695,7 +701,7 @@ TGR_DEV T newton_assemble(const Params<T>& P, T* lds, int wid, unsigned cpl, T& 
     V3<T> fl = mk(T(0), T(0), T(0)), fa = fl;
 #pragma unroll 1
     for (int e = 0; e < n_floor<MODEL>(); e++) {
-      Contact<T> c = load_floor<T, LW, MODEL>(lds, e < 2 ? 2 * b + e : 6 + b);
+      Contact<T> c = load_floor<T, LW, MODEL>(lds, floor_index(b, e));
       if (__any(c.active)) {
         V3<T> jl = yl + cross(ya, c.rB);
         if (MODEL) jl = jl + c.c0 * c.n; else jl.z += c.c0;
@@ -970,11 +976,11 @@ TGR_DEV void ls_setup(const Params<T>& P, const T* lds, int wid, unsigned cpl, L
     V3<T> ya = ld3<T, LW>(lds, L_A + 6 * b + 3) + ld3<T, LW>(lds, L_BV + 6 * b + 3);
 #pragma unroll
     for (int e = 0; e < n_floor<MODEL>(); e++) {
-      Contact<T> c = load_floor<T, LW, MODEL>(lds, e < 2 ? 2 * b + e : 6 + b);
+      Contact<T> c = load_floor<T, LW, MODEL>(lds, floor_index(b, e));
       V3<T> jl = yl + cross(ya, c.rB);
       if (MODEL) jl = jl + c.c0 * c.n; else jl.z += c.c0;
       V3<T> ql = pl + cross(pa, c.rB);
-      ls[e < 2 ? e : 3] = ls_make(c, jl, ya, ql, pa);  // slot 2 is the wave's pair slot
+      ls[e < 2 ? e : e + 1] = ls_make(c, jl, ya, ql, pa);  // slot 2 is the wave's pair slot
     }
     if ((cpl >> b) & 1u) ls[2] = ls_pair_slot<T, LW>(P, lds, b, 0);
   } else {
@@ -1041,18 +1047,20 @@ template <typename T> TGR_DEV V3<T> closest_on_triangle(V3<T> p, V3<T> a, V3<T> 
 // cap sphere (centre cw, world) against the heightfield floor: deepest triangle of the (at most 2x2) cells under the cap.
 // Each grid cell is two triangles of the strip (c,r) (c,r+1) (c+1,r) (c+1,r+1).  Returns dist (>= 0: no contact), normal, and
 // the surface point.
-template <typename T> TGR_DEV T hfield_cap(const Params<T>& P, V3<T> cw, V3<T>& n_out) {
+template <typename T> TGR_DEV void hfield_cap(const Params<T>& P, V3<T> cw, T* dist_out, V3<T>* n_out) {
   const T rad = P.cap_r;
   V3<T> p = mk(cw.x - P.hf_x0, cw.y - P.hf_y0, cw.z - P.hf_z0);
-  n_out = mk(T(0), T(0), T(1));
-  if (p.x < -P.hf_rx - rad || p.x > P.hf_rx + rad || p.y < -P.hf_ry - rad || p.y > P.hf_ry + rad || p.z > P.hf_ez + rad) return T(1);
+  dist_out[0] = dist_out[1] = T(1);
+  n_out[0] = n_out[1] = mk(T(0), T(0), T(1));
+  if (p.x < -P.hf_rx - rad || p.x > P.hf_rx + rad || p.y < -P.hf_ry - rad || p.y > P.hf_ry + rad || p.z > P.hf_ez + rad) return;
   const T idx = rcp_(P.hf_dx), idy = rcp_(P.hf_dy);
   int c0 = (int)floor(double((p.x - rad + P.hf_rx) * idx)), c1 = (int)floor(double((p.x + rad + P.hf_rx) * idx));
   int r0 = (int)floor(double((p.y - rad + P.hf_ry) * idy)), r1 = (int)floor(double((p.y + rad + P.hf_ry) * idy));
   c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
   c1 = c1 > P.hf_ncol - 2 ? P.hf_ncol - 2 : c1; r1 = r1 > P.hf_nrow - 2 ? P.hf_nrow - 2 : r1;
-  T best = T(1);
-  V3<T> bq = p;
+  // the two deepest triangles touched (mujoco: one contact per prism penetrated; two is what a cap in a fold needs)
+  T bd0 = T(1), bd1 = T(1);
+  V3<T> bq0 = p, bq1 = p;
   for (int r = r0; r <= r1; r++)
     for (int c = c0; c <= c1; c++) {
       V3<T> v[4];
@@ -1066,17 +1074,22 @@ template <typename T> TGR_DEV T hfield_cap(const Params<T>& P, V3<T> cw, V3<T>& 
         V3<T> q = closest_on_triangle(p, v[tri], v[tri + 1], v[tri + 2]);
         V3<T> df = p - q;
         T dist = sqrt_(dot(df, df)) - rad;
-        if (dist < T(0) && dist < best) { best = dist; bq = q; }
+        if (!(dist < T(0))) continue;
+        if (dist < bd0) { bd1 = bd0; bq1 = bq0; bd0 = dist; bq0 = q; }
+        else if (dist < bd1) { bd1 = dist; bq1 = q; }
       }
     }
-  if (best >= T(0)) return T(1);
-  V3<T> df = p - bq;
-  T nn = sqrt_(dot(df, df));
-  if (!(nn > T(1e-12))) return T(1);
-  n_out = rcp_(nn) * df;
-  return best;
+  {
+    V3<T> df = p - bq0;
+    T nn = sqrt_(dot(df, df));
+    if (bd0 < T(0) && nn > T(1e-12)) { dist_out[0] = bd0; n_out[0] = rcp_(nn) * df; }
+  }
+  {
+    V3<T> df = p - bq1;
+    T nn = sqrt_(dot(df, df));
+    if (bd1 < T(0) && nn > T(1e-12)) { dist_out[1] = bd1; n_out[1] = rcp_(nn) * df; }
+  }
 }
-
 // closest points of two segments c + s a (|s| <= ha) and c2 + t a2 (|t| <= hb), unit axes (Ericson 5.1.9)
 template <typename T> TGR_DEV void seg_seg_closest(V3<T> ca, V3<T> aa, T ha, V3<T> cb, V3<T> ab, T hb, T& s_out, T& t_out) {
   V3<T> w = ca - cb;
@@ -1223,15 +1236,20 @@ TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* l
     const int s = L_CF + 6 * (2 * B + e);
     Contact<T> c;
     if (MODEL) {
-      V3<T> n;
-      T dist = hfield_cap(P, S.x[B] + arm, n);
-      const bool hit = dist < T(0);
-      if (!hit) dist = T(0);
-      contact_params(P, dist, 1, c);
-      V3<T> rB = arm - (P.cap_r + T(0.5) * dist) * n;
-      st3<T, LW>(lds, s, rB);
-      st3<T, LW>(lds, L_FN + 3 * (2 * B + e), n);
-      lds[(s + 3) * LW] = c.c0; lds[(s + 4) * LW] = c.Dn; lds[(s + 5) * LW] = hit ? T(1) : T(0);
+      V3<T> n2[2];
+      T d2[2];
+      hfield_cap(P, S.x[B] + arm, d2, n2);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const bool hit = d2[j] < T(0);
+        const T dist = hit ? d2[j] : T(0);
+        contact_params(P, dist, 1, c);
+        V3<T> rB = arm - (P.cap_r + T(0.5) * dist) * n2[j];
+        const int sj = j == 0 ? s : L_F2 + 6 * (2 * B + e);
+        st3<T, LW>(lds, sj, rB);
+        st3<T, LW>(lds, (j == 0 ? L_FN : L_F2N) + 3 * (2 * B + e), n2[j]);
+        lds[(sj + 3) * LW] = c.c0; lds[(sj + 4) * LW] = c.Dn; lds[(sj + 5) * LW] = hit ? T(1) : T(0);
+      }
     } else {
       T dist = S.x[B].z + arm.z - P.cap_r;
       contact_params(P, dist, 1, c);
@@ -1297,7 +1315,11 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, Lag<T>& lag
   T nact = T(0);  // the flags are 0/1: one batch of reads and a sum (a short-circuit `||` would expose twelve LDS round trips)
 #pragma unroll
   for (int k = 0; k < 6; k++) nact += lds[(L_CF + 6 * k + 5) * LW] + lds[(L_CP + 12 * k + 11) * LW];
-  if (MODEL) nact += lds[(L_FR + 5) * LW] + lds[(L_FR + 11) * LW] + lds[(L_FR + 17) * LW];
+  if (MODEL) {
+    nact += lds[(L_FR + 5) * LW] + lds[(L_FR + 11) * LW] + lds[(L_FR + 17) * LW];
+#pragma unroll
+    for (int k = 0; k < 6; k++) nact += lds[(L_F2 + 6 * k + 5) * LW];
+  }
   const bool any_contact = nact != T(0);
   if (last) lag.overflow = (int)(lds[(L_RED + 32) * LW] + lds[(L_RED + 33) * LW] + lds[(L_RED + 34) * LW]);
   if (P.warm_start && wid < 3 && !any_contact) {
