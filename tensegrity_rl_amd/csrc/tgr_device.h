@@ -1058,17 +1058,27 @@ template <typename T> TGR_DEV void hfield_cap(const Params<T>& P, V3<T> cw, T* d
   int r0 = (int)floor(double((p.y - rad + P.hf_ry) * idy)), r1 = (int)floor(double((p.y + rad + P.hf_ry) * idy));
   c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
   c1 = c1 > P.hf_ncol - 2 ? P.hf_ncol - 2 : c1; r1 = r1 > P.hf_nrow - 2 ? P.hf_nrow - 2 : r1;
+  // a cap (5 cm) spans at most 2x2 cells of the 1 m grid: fetch the 3x3 vertices in one batch (a lone wave cannot hide the
+  // latency of loads issued one cell at a time), then walk the cells with predicates
+  T hz[3][3];
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int cc = min(c0 + i, P.hf_ncol - 1), rr = min(r0 + j, P.hf_nrow - 1);
+      hz[j][i] = T(P.hf[rr * P.hf_ncol + cc]) * P.hf_ez;
+    }
   // the two deepest triangles touched (mujoco: one contact per prism penetrated; two is what a cap in a fold needs)
   T bd0 = T(1), bd1 = T(1);
   V3<T> bq0 = p, bq1 = p;
-  for (int r = r0; r <= r1; r++)
-    for (int c = c0; c <= c1; c++) {
-      V3<T> v[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int cc = c + (j >> 1), rr = r + (j & 1);
-        v[j] = mk(T(cc) * P.hf_dx - P.hf_rx, T(rr) * P.hf_dy - P.hf_ry, T(P.hf[rr * P.hf_ncol + cc]) * P.hf_ez);
-      }
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      if (c0 + i > c1 || r0 + j > r1) continue;
+      const T x0 = T(c0 + i) * P.hf_dx - P.hf_rx, y0 = T(r0 + j) * P.hf_dy - P.hf_ry;
+      const V3<T> v[4] = {mk(x0, y0, hz[j][i]), mk(x0, y0 + P.hf_dy, hz[j + 1][i]), mk(x0 + P.hf_dx, y0, hz[j][i + 1]),
+                          mk(x0 + P.hf_dx, y0 + P.hf_dy, hz[j + 1][i + 1])};  // (c,r) (c,r+1) (c+1,r) (c+1,r+1)
 #pragma unroll
       for (int tri = 0; tri < 2; tri++) {
         V3<T> q = closest_on_triangle(p, v[tri], v[tri + 1], v[tri + 2]);
@@ -1122,24 +1132,36 @@ template <typename T> TGR_DEV T hfield_rod(const Params<T>& P, V3<T> xc, V3<T> a
   if (c.x + ex < -P.hf_rx || c.x - ex > P.hf_rx || c.y + ey < -P.hf_ry || c.y - ey > P.hf_ry) return T(1);
   if (c.z - abs_(az.z) * H - rad > P.hf_ez) return T(1);
   const T idx = rcp_(P.hf_dx), idy = rcp_(P.hf_dy);
-  int c0 = (int)floor(double((c.x - ex + P.hf_rx) * idx)), c1 = (int)floor(double((c.x + ex + P.hf_rx) * idx)) + 1;
-  int r0 = (int)floor(double((c.y - ey + P.hf_ry) * idy)), r1 = (int)floor(double((c.y + ey + P.hf_ry) * idy)) + 1;
+  // cells under the bar's bounding box: at most 3x3 of the 1 m grid for a 1.38 m bar (the far sides of the last cells lie
+  // outside the box, so the cells' own three edges -- bottom, left, diagonal -- are all that can touch)
+  int c0 = (int)floor(double((c.x - ex + P.hf_rx) * idx)), c1 = (int)floor(double((c.x + ex + P.hf_rx) * idx));
+  int r0 = (int)floor(double((c.y - ey + P.hf_ry) * idy)), r1 = (int)floor(double((c.y + ey + P.hf_ry) * idy));
   c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
-  c1 = c1 > P.hf_ncol - 1 ? P.hf_ncol - 1 : c1; r1 = r1 > P.hf_nrow - 1 ? P.hf_nrow - 1 : r1;
+  c1 = c1 > P.hf_ncol - 2 ? P.hf_ncol - 2 : c1; r1 = r1 > P.hf_nrow - 2 ? P.hf_nrow - 2 : r1;
+  c1 = c1 > c0 + 2 ? c0 + 2 : c1; r1 = r1 > r0 + 2 ? r0 + 2 : r1;
+  T hz[4][4];  // the 4x4 vertices of those cells, fetched in one batch
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int cc = min(c0 + i, P.hf_ncol - 1), rr = min(r0 + j, P.hf_nrow - 1);
+      hz[j][i] = T(P.hf[rr * P.hf_ncol + cc]) * P.hf_ez;
+    }
   T best = T(1);
   V3<T> bpa = c, bpb = c;
-  for (int r = r0; r <= r1; r++)
-    for (int cc = c0; cc <= c1; cc++) {
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (c0 + i > c1 || r0 + j > r1) continue;
+      const T x0 = T(c0 + i) * P.hf_dx - P.hf_rx, y0 = T(r0 + j) * P.hf_dy - P.hf_ry;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        // edges starting at vertex (cc, r): to (cc+1, r), to (cc, r+1), and the strip diagonal (cc, r+1)-(cc+1, r)
-        const int ca = cc + (k == 2 ? 0 : 0), ra = r + (k == 2 ? 1 : 0), cb = cc + (k == 1 ? 0 : 1), rb = r + (k == 1 ? 1 : 0);
-        if (ca > P.hf_ncol - 1 || cb > P.hf_ncol - 1 || ra > P.hf_nrow - 1 || rb > P.hf_nrow - 1) continue;
-        V3<T> va = mk(T(ca) * P.hf_dx - P.hf_rx, T(ra) * P.hf_dy - P.hf_ry, T(P.hf[ra * P.hf_ncol + ca]) * P.hf_ez);
-        V3<T> vb = mk(T(cb) * P.hf_dx - P.hf_rx, T(rb) * P.hf_dy - P.hf_ry, T(P.hf[rb * P.hf_ncol + cb]) * P.hf_ez);
+        // edges of cell (c, r): (c,r)-(c+1,r), (c,r)-(c,r+1), and the strip diagonal (c,r+1)-(c+1,r)
+        const V3<T> va = k == 2 ? mk(x0, y0 + P.hf_dy, hz[j + 1][i]) : mk(x0, y0, hz[j][i]);
+        const V3<T> vb = k == 1 ? mk(x0, y0 + P.hf_dy, hz[j + 1][i]) : mk(x0 + P.hf_dx, y0, hz[j][i + 1]);
         V3<T> ed = vb - va;
         T el = sqrt_(dot(ed, ed));
-        if (!(el > T(1e-12))) continue;
         ed = rcp_(el) * ed;
         V3<T> mid = T(0.5) * (va + vb);
         T s_, t_;
