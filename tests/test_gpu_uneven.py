@@ -79,3 +79,30 @@ def test_uneven_full_size_rollout_fp32(golden_dir):
     q = st["qpos"].reshape(n, 3, 7)
     assert np.abs(np.linalg.norm(q[:, :, 3:], axis=2) - 1).max() < 1e-5
     assert q[:, :, 2].max() < 0.5 and q[:, :, 2].min() > -1.5
+
+
+def test_uneven_fp32_close_to_oracle(oracle, golden_dir):
+    """the fp32 instantiation of the MODEL = 1 kernels on identical (state, action): same tolerance statement as the flat model"""
+    from tensegrity_rl_amd import TensegrityVecEnv
+    from tensegrity_rl_amd.vec_env import heights_from_image
+    O = oracle
+    img = terrain(golden_dir)
+    n = 128
+    ob = O.OracleBatch(O.make_cfg("tr_env", "straight", heights=heights_from_image(img), model_kind=1), n, seed=4)
+    ob.reset()
+    env = TensegrityVecEnv(n, "tr_env-v0", precision="f32", auto_reset=False, seed=4, model="uneven", terrain=img)
+    rng = np.random.default_rng(5)
+    eq, ev = [], []
+    for t in range(4):
+        oracle_to_gpu_state(ob, env)
+        a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+        ob.step(a, auto_reset=False)
+        env.step_tensors(a)
+        st = env.get_state()
+        q2, v2, _, _, _ = ob.get_state()
+        eq.append(rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3)); ev.append(rel_env(st["qvel"] - v2, v2, 1e-2))
+    eq, ev = np.concatenate(eq), np.concatenate(ev)
+    print("uneven fp32: qpos median %.1e frac<1e-4 %.3f ; qvel median %.1e frac<1e-4 %.3f" % (np.median(eq), (eq < 1e-4).mean(), np.median(ev), (ev < 1e-4).mean()))
+    assert np.median(eq) < 1e-5 and (eq < 1e-4).mean() > 0.85
+    assert np.median(ev) < 1e-3
+    env.close(); ob.close()
