@@ -8,7 +8,7 @@ from gpu_common import oracle_to_gpu_state, qfix, rel_env
 from tensegrity_rl_amd import TensegrityVecEnv
 n = 512
 kind = sys.argv[1] if len(sys.argv) > 1 else "tensegrity_env"
-variants = [dict(), dict(solver_tolerance=3e-6), dict(solver_tolerance=1e-6), dict(solver_tolerance=1e-6, solver_iterations=12), dict(solver_tolerance=1e-7, solver_iterations=20)]
+variants = [dict(), dict(solver_tolerance=1e-5), dict(solver_tolerance=1e-6), dict(solver_iterations=6)]
 ob = O.OracleBatch(O.make_cfg(kind, "straight"), n, seed=1234); ob.reset()
 envs = [TensegrityVecEnv(n, kind + "-v0", precision="f32", auto_reset=False, **kw) for kw in variants]
 rng = np.random.default_rng(0)
