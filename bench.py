@@ -131,7 +131,7 @@ def main():
     env.reset_tensors()
     g = torch.Generator(device=dev); g.manual_seed(rank)
     acts = [(torch.rand((n_local, 6), device=dev, generator=g) * 0.6 - 0.45).contiguous() for _ in range(32)]
-    gather = (RolloutGatherer(n_local, env.obs_dim, args.gather_every, dev, world_size=world, always_collective=force_dist)
+    gather = (RolloutGatherer(n_local, env.obs_dim, args.gather_every, dev, world_size=world, always_collective=force_dist, overlap=True)
               if (world > 1 or force_dist) else None)
 
     def one_step(i):
@@ -153,6 +153,8 @@ def main():
         evs[i][0].record()
         one_step(args.warmup + i)
         evs[i][1].record()
+    if gather is not None:
+        gather.flush()  # the last chunk's all-gather belongs to the timed region
     if multi:
         dist.barrier()
     torch.cuda.synchronize()

@@ -46,6 +46,41 @@ def _worker(rank, world, port, n_total, D, chunk, out):
     dist.destroy_process_group()
 
 
+def _worker_overlap(rank, world, port, n_total, D, chunk, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(rank, world, n_total)
+    g = RolloutGatherer(hi - lo, D, chunk, torch.device("cpu"), overlap=True)
+    got = []
+    for t in range(3 * chunk):
+        ids = torch.arange(lo, hi, dtype=torch.float32)
+        obs = ids[:, None] * 100 + t + torch.arange(D, dtype=torch.float32)[None, :] * 0.01
+        res = g.push(obs, ids + 0.5 * t, torch.zeros(hi - lo, dtype=torch.uint8), torch.zeros(hi - lo, dtype=torch.uint8))
+        if (t + 1) % chunk == 0:
+            assert (res is None) == (t + 1 == chunk)      # results arrive one chunk late
+        else:
+            assert res is None
+        if res is not None:
+            got.append(RolloutGatherer.to_global(res[0]).clone())
+    got.append(RolloutGatherer.to_global(g.flush()[0]).clone())
+    if rank == 0:
+        torch.save(torch.cat(got), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_overlapped_allgather_returns_every_chunk_once_in_order(tmp_path):
+    n_total, D, chunk = 10, 3, 2
+    out = str(tmp_path / "o.pt")
+    mp.spawn(_worker_overlap, args=(2, _free_port(), n_total, D, chunk, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    ids = torch.arange(n_total, dtype=torch.float32)
+    assert got.shape == (3 * chunk, n_total, D)
+    for t in range(3 * chunk):
+        assert torch.equal(got[t], ids[:, None] * 100 + t + torch.arange(D, dtype=torch.float32)[None, :] * 0.01)
+
+
 @pytest.mark.timeout(120)
 def test_rollout_allgather_world2_matches_single_rank(tmp_path):
     n_total, D, chunk = 64, 5, 4
