@@ -164,6 +164,7 @@ def test_mujoco_trained_tracking_policy_closes_in_on_its_waypoint(oracle, golden
     ob = O.OracleBatch(O.make_cfg("tr_env", "tracking", is_test=1), n, seed=1234)
     obs = ob.reset()
     d0 = dmin = None
+    tend = []
     wrench_trip = np.zeros(n, bool)
     for t in range(300):
         h = obs
@@ -172,6 +173,8 @@ def test_mujoco_trained_tracking_policy_closes_in_on_its_waypoint(oracle, golden
         a = (lo + 0.5 * (np.tanh(h @ W[2].T + B[2]) + 1) * (hi - lo)).astype(np.float32)
         obs, rew, term, trunc, tobs, info = ob.step(a, auto_reset=False)
         d = np.linalg.norm(info[:, 10:12] - info[:, 3:5], axis=1)
+        if t >= 100:
+            tend.append(info[:, 16:25].copy())
         if d0 is None:
             d0, dmin = d.copy(), d.copy()
         dmin = np.minimum(dmin, d)
@@ -180,6 +183,13 @@ def test_mujoco_trained_tracking_policy_closes_in_on_its_waypoint(oracle, golden
     assert np.all(np.abs(d0 - 3.0) < 0.1)
     assert not wrench_trip.any()
     assert int(np.sum(d0 - dmin > 1.0)) >= 3 and dmin.min() < 0.5, (d0 - dmin)
+    # the one real MuJoCo state of this gait the reference ships: the checkpoint's `_last_obs` -- tendon
+    # lengths of the robot mid-gait.  They must be ordinary values of the same gait in this simulator.
+    mj_act = np.array([.322809, .490437, .448440, .385049, .364695, .544164]); mj_pas = np.array([1.207020, 1.200822, 1.198159])
+    T = np.concatenate(tend)
+    lo_a, hi_a = np.quantile(T[:, :6], [0.05, 0.95]); lo_p, hi_p = np.quantile(T[:, 6:], [0.05, 0.95])
+    assert lo_a < mj_act.min() and mj_act.max() < hi_a, (lo_a, hi_a)
+    assert lo_p < mj_pas.min() and mj_pas.max() < hi_p and abs(T[:, 6:].mean() - mj_pas.mean()) < 0.03, (lo_p, hi_p, T[:, 6:].mean())
     ob.close()
 
 
