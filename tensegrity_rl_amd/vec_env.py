@@ -215,6 +215,12 @@ class TensegrityVecEnv:
         if self.info_mode == "full":
             ih = info.cpu().numpy().astype(np.float64)
             infos = [dict(zip(N.INFO_KEYS, ih[i, :10])) for i in range(n)]
+            tr = self.cfg.env_kind == N.ENV_TR
+            for i in range(n):
+                if tr:  # tr_env.py:506-511
+                    infos[i]["waypt"] = ih[i, 10:12].copy(); infos[i]["oripoint"] = ih[i, 12:14].copy()
+                    infos[i]["tendon_length"] = ih[i, N.INFO_TENDON_LENGTH:N.INFO_TENDON_LENGTH + 9].copy()
+                infos[i]["total_bar_contact"] = float(ih[i, N.INFO_BAR_CONTACT])  # what run.py:149-155 computes from data.contact
         else:
             infos = [{} for _ in range(n)]
             ih = None
