@@ -119,13 +119,18 @@ typedef struct tgr_config {
 
 typedef struct tgr_handle tgr_handle;
 
-/* fills *cfg with the reference defaults of the given env class / desired_action */
+/* fills *cfg with the reference defaults of the given env class / desired_action.
+ * replaces: the constructor defaults of tensegrity_env.__init__ (tensegrity_env/tensegrity_env/envs/tensegrity_env.py:160-181) and
+ * tr_env.__init__ (tr_env/tr_env/envs/tr_env.py:137-173), and the model constants of 3prism_jonathan_steady_side.xml:13-40,56-164 */
 int tgr_default_config(tgr_config* cfg, int env_kind, int desired_action);
-/* switches an already filled *cfg to the uneven-ground model (what xml_file=..._uneven_ground.xml selects in the reference) */
+/* switches an already filled *cfg to the uneven-ground model.
+ * replaces: xml_file=3prism_jonathan_steady_side_uneven_ground.xml (run.py:377 --env_xml, tr_env.py:139) -> MjModel.from_xml_path */
 int tgr_uneven_config(tgr_config* cfg);
 /* heightfield of model_kind 1: normalised elevations in [0,1], host pointer, [nrow][ncol], row 0 at y = -radius_y, column 0 at
  * x = -radius_x (mujoco's hfield_data layout [ext]); copied to the device */
 int tgr_set_hfield(tgr_handle* h, const float* heights_host, int nrow, int ncol);
+/* N envs on `device`.  replaces: gym.make(id, ...) (run.py:413-418) -> tensegrity_env/tr_env.__init__ -> MujocoEnv.__init__
+ * (MjModel.from_xml_path + MjData), N times, and SB3's DummyVecEnv around them (run.py:41-85) */
 int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_handle** out);
 int tgr_destroy(tgr_handle* h);
 int tgr_num_envs(const tgr_handle* h);
@@ -133,10 +138,15 @@ int tgr_obs_dim(const tgr_handle* h);
 int tgr_precision(const tgr_handle* h);
 
 /* reset envs with mask[i] != 0 (mask: HOST uint8[N] or NULL = all); obs: DEVICE [N][obs_dim]
- * of the handle's precision (float or double), rows of reset envs are written; may be NULL */
+ * of the handle's precision (float or double), rows of reset envs are written; may be NULL.
+ * replaces: Env.reset() -> mj_resetData + reset_model() (tensegrity_env.py:433-512, tr_env.py:709-872: yaw-randomised pose, random
+ * tendon targets, 50 control periods of settling, way-point sampling) */
 int tgr_reset(tgr_handle* h, const uint8_t* mask_host, void* obs_dev, void* hip_stream);
 
-/* one control period for all envs (fp32 handle) */
+/* one control period for all envs (fp32 handle).
+ * replaces: Env.step() (tensegrity_env.py:291-410, tr_env.py:327-527) = do_simulation -> mj_step(nstep=20) + mj_rnePostConstraint,
+ * _get_obs (tensegrity_env.py:412-430, tr_env.py:529-646), reward / termination (tensegrity_env.py:245-289,308-372), and the
+ * auto-reset of SB3's DummyVecEnv.step_wait (terminal_obs = infos[i]["terminal_observation"], truncated = TimeLimit(5000)) */
 int tgr_step(tgr_handle* h, const float* actions /*[N][6]*/, float* obs /*[N][D]*/, float* reward /*[N]*/,
              uint8_t* terminated /*[N]*/, uint8_t* truncated /*[N]*/, float* terminal_obs /*[N][D] or NULL*/,
              float* info /*[N][TGR_INFO_K] or NULL*/, void* hip_stream);
@@ -145,7 +155,8 @@ int tgr_step_f64(tgr_handle* h, const float* actions, double* obs, double* rewar
                  uint8_t* truncated, double* terminal_obs, double* info, void* hip_stream);
 
 /* HOST arrays, any may be NULL: qpos[N][21], qvel[N][18] (MuJoCo convention: world linear,
- * body-frame angular), ctrl[N][6], qacc_warmstart[N][18], aux[N][TGR_AUX_K] */
+ * body-frame angular), ctrl[N][6], qacc_warmstart[N][18], aux[N][TGR_AUX_K].
+ * replaces: reads of env.data.qpos/qvel/ctrl/qacc_warmstart and MujocoEnv.set_state (tensegrity_env.py:448,484; tr_env.py:744,763,800) */
 #define TGR_AUX_K 23
 enum {
   TGR_AUX_XY_LAG_X = 0, TGR_AUX_XY_LAG_Y, TGR_AUX_PSI_LAG, TGR_AUX_RESET_PSI, TGR_AUX_EP_RETURN,
@@ -164,7 +175,8 @@ int tgr_set_state(tgr_handle* h, const double* qpos, const double* qvel, const d
  * (tgr_reset, or a finished env that found no ready donor), [2] envs reset from a donor lane, [3] Newton iterations,
  * [4] line-search evaluations, [5] sub-steps -- [3..5] summed over wavefronts (wave-uniform loop counts) */
 int tgr_stats(tgr_handle* h, uint64_t out[8]);
-/* re-key the reset RNG (Env.reset(seed=...)); takes effect for subsequent resets */
+/* re-key the reset RNG; takes effect for subsequent resets.  replaces: Env.reset(seed=...) (gym API; the reference's own draws at
+ * tensegrity_env.py:460,486 / tr_env.py:730,776 are unseeded) */
 int tgr_set_seed(tgr_handle* h, uint64_t seed);
 int tgr_synchronize(tgr_handle* h);
 const char* tgr_last_error(const tgr_handle* h);
