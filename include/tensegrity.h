@@ -176,7 +176,7 @@ int tgr_set_state(tgr_handle* h, const double* qpos, const double* qvel, const d
  * [4] line-search evaluations, [5] sub-steps -- [3..5] summed over wavefronts (wave-uniform loop counts) */
 int tgr_stats(tgr_handle* h, uint64_t out[8]);
 /* re-key the reset RNG; takes effect for subsequent resets.  replaces: Env.reset(seed=...) (gym API; the reference's own draws at
- * tensegrity_env.py:460,486 / tr_env.py:730,776 are unseeded) */
+ * tensegrity_env.py:460,486 / tr_env.py:730,775,802,831 are unseeded) */
 int tgr_set_seed(tgr_handle* h, uint64_t seed);
 int tgr_synchronize(tgr_handle* h);
 const char* tgr_last_error(const tgr_handle* h);
