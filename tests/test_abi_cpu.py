@@ -87,3 +87,15 @@ def test_spaces_fallback_box():
     b = Box(low=-0.45, high=0.15, shape=(6,), dtype=np.float32)
     x = b.sample()
     assert x.shape == (6,) and x.dtype == np.float32 and b.contains(x)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """the HIP path is the product: bench.py must fail loudly on a box without a device instead of timing anything else"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout) and "metric" not in r.stdout
