@@ -145,3 +145,29 @@ def test_full_size_free_flight_follows_the_ballistic_parabola(prec, tol):
     v_ref = v0.copy(); v_ref[:, 2] -= g * t
     assert np.abs(v1 - v_ref).max() < tol * 10 and np.abs(x1 - x_ref).max() < tol * 10, (np.abs(v1 - v_ref).max(), np.abs(x1 - x_ref).max())
     env.close()
+
+
+def test_fp64_clamped_actuator_derivative_option_matches_oracle(oracle):
+    """the other reading of SURVEY.md B.7 (skip d(force)/dv of actuators on their force limit): one switch on both sides"""
+    from tensegrity_rl_amd import TensegrityVecEnv
+    O = oracle
+    n = 48
+    ob = O.OracleBatch(O.make_cfg("tensegrity_env", "straight"), n, seed=9)
+    for i in range(n):
+        ob.env(i).model.actuator_deriv_skip_clamped = 1
+    ob.reset()
+    env = TensegrityVecEnv(n, "tensegrity_env-v0", precision="f64", auto_reset=False, seed=9, actuator_deriv_skip_clamped=1)
+    ref = TensegrityVecEnv(n, "tensegrity_env-v0", precision="f64", auto_reset=False, seed=9)
+    rng = np.random.default_rng(1)
+    differs = 0.0
+    for t in range(4):
+        oracle_to_gpu_state(ob, env); oracle_to_gpu_state(ob, ref)
+        a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+        ob.step(a, auto_reset=False)
+        env.step_tensors(a); ref.step_tensors(a)
+        q2, v2, _, _, _ = ob.get_state()
+        st = env.get_state()
+        assert rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3).max() < 1e-7 and rel_env(st["qvel"] - v2, v2, 1e-2).max() < 1e-5
+        differs = max(differs, np.abs(ref.get_state()["qvel"] - v2).max())
+    assert differs > 1e-6  # the switch does change the dynamics (actuators do sit on their limits under random actions)
+    env.close(); ref.close(); ob.close()
