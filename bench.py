@@ -21,6 +21,18 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def profiled_valu():
+    """wave-level VALU instructions per step_kernel launch from the committed SQ counter pass (same command as the traffic passes);
+    x 64 lanes / kernel time = lane-operations per second (an FMA counts once).  None when the profile is not there."""
+    import json as _j, os as _o
+    f = _o.path.join(_o.path.dirname(_o.path.abspath(__file__)), "profiles", "round1_bench_rocprofv3_summary_v4.json")
+    try:
+        sq = _j.load(open(f))["sq"]["tgr::step_kernel"]
+        return sq["SQ_INSTS_VALU"] / sq["dispatches"]
+    except Exception:
+        return None
+
+
 def profiled_traffic():
     """HBM bytes per step_kernel launch from the committed rocprofv3 PMC passes of this same command
     (profiles/round1_bench_rocprofv3_summary_v4.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB per
@@ -188,7 +200,10 @@ def main():
                          "note": "step_kernel: 674 algorithmic B per env-step x envs per launch / mean launch duration (HIP events around "
                                  "the step+match+settle launches of one step); the path is VALU-issue bound (~1e6 flop per env-step), "
                                  "not HBM bound: see DESIGN.md",
-                         "kernel_ms": kern_ms, "kernel_ms_p50": step_ms[len(step_ms) // 2]},
+                         "kernel_ms": kern_ms, "kernel_ms_p50": step_ms[len(step_ms) // 2],
+                         # the practical bound is VALU issue/latency of few resident waves, so report those too
+                         "resident_waves": 4 * ((n_local + (env.cfg.n_donors if env.cfg.n_donors >= 0 else 2 * n_local) + 63) // 64),
+                         "valu_lane_ops_per_s": (profiled_valu() * 64 / (kern_ms * 1e-3)) if profiled_valu() else None},
         }
         if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed once: rank 0 of the one-GPU run
             try:
