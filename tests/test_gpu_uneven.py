@@ -106,3 +106,19 @@ def test_uneven_fp32_close_to_oracle(oracle, golden_dir):
     assert np.median(eq) < 1e-5 and (eq < 1e-4).mean() > 0.85
     assert np.median(ev) < 1e-3
     env.close(); ob.close()
+
+
+def test_gym_wrapper_selects_the_model_from_xml_file(golden_dir):
+    """run.py --env_xml 3prism_jonathan_steady_side_uneven_ground.xml -> gym.make("tr_env-v0", xml_file=...)"""
+    from tensegrity_rl_amd import make
+    env = make("tr_env-v0", xml_file="/somewhere/3prism_jonathan_steady_side_uneven_ground.xml", terrain=terrain(golden_dir),
+               desired_action="straight")
+    assert env._venv.cfg.model_kind == 1
+    obs, _ = env.reset()
+    obs, r, term, trunc, info = env.step(np.full(6, -0.2, dtype=np.float32))
+    assert obs.shape == (45,) and np.isfinite(obs).all() and np.isfinite(r)
+    z = env.get_state()["qpos"].reshape(3, 7)[:, 2]
+    assert z.max() < 0.3 and z.min() > -1.2          # on the heightfield, ~0.8 m below where the XML pose starts
+    env.close()
+    with pytest.raises(ValueError):
+        make("tr_env-v0", xml_file="/somewhere/3prism_jonathan_steady_side_uneven_ground.xml")   # no terrain to load
