@@ -86,6 +86,61 @@ def cpu_baseline(seconds, envs):
             "sample": f"{envs} envs x {steps} steps ({dt:.1f} s), oracle/ fp64 CPU restatement with OpenMP over envs, auto-reset on"}
 
 
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` as a bare command: start N fresh rank processes through torch.distributed.run (one per GPU, RCCL
+    rendezvous on 127.0.0.1) BEFORE this process has touched the GPU, forward rank 0's JSON line, return the launcher's exit code.
+    This parent never initialises HIP (and never execs): it only waits for the children."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, TGR_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        try:
+            if "metric" in json.loads(ln):
+                line = ln
+                continue
+        except ValueError:
+            pass
+        print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {n_ranks}-rank launch failed (exit code {proc.returncode}, JSON line {'found' if line else 'missing'})", file=sys.stderr)
+        return proc.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def dry_run(args, rank, world):
+    """TGR_BENCH_DRYRUN=1: launcher / rendezvous / timing-protocol plumbing only, on CPU over gloo -- no env is built and nothing is
+    measured (`value` is null); used by tests/test_bench_launcher.py where there is no GPU."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        got = [None] * world
+        dist.all_gather_object(got, rank)
+        assert got == list(range(world))
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "env-steps/sec (whole node)", "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +156,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("TGR_BENCH_DRYRUN") == "1":
+        return dry_run(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+
     import torch
     import torch.distributed as dist
     from tensegrity_rl_amd import TensegrityVecEnv
@@ -110,7 +170,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: under torch.distributed.run use --nproc-per-node {args.gpus} "
+                         "(or run `python bench.py --gpus N` bare: it starts the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the HIP path is the product and there is no CPU fallback")
     # TGR_BENCH_REHEARSAL=1: all ranks share cuda:0 and talk over gloo -- exercises the N>1 code path on a one-GPU box

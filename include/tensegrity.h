@@ -115,6 +115,10 @@ typedef struct tgr_config {
   double act_tau;         /* dynprm[0] of the filter actuators */
   double hf_size[4];      /* heightfield: radius_x, radius_y, elevation_z, base_z (uneven xml:48) */
   double hf_pos[3];       /* position of the heightfield geom (uneven xml:56) */
+  /* reset_noise_scale (tensegrity_env.py:169,436-445; tr_env.py:152,734-743): before the yaw transform qpos += U(-s, s)^21 and
+   * qvel = s * N(0, 1)^18.  The reference draws from self.np_random; here philox keyed (seed; lane key, episode), counters 16..26
+   * (uniforms) and 32..40 (Box-Muller normals) */
+  double reset_noise_scale;
 } tgr_config;
 
 typedef struct tgr_handle tgr_handle;
@@ -157,14 +161,18 @@ int tgr_step_f64(tgr_handle* h, const float* actions, double* obs, double* rewar
 /* HOST arrays, any may be NULL: qpos[N][21], qvel[N][18] (MuJoCo convention: world linear,
  * body-frame angular), ctrl[N][6], qacc_warmstart[N][18], aux[N][TGR_AUX_K].
  * replaces: reads of env.data.qpos/qvel/ctrl/qacc_warmstart and MujocoEnv.set_state (tensegrity_env.py:448,484; tr_env.py:744,763,800) */
-#define TGR_AUX_K 23
+#define TGR_AUX_K 55
 enum {
   TGR_AUX_XY_LAG_X = 0, TGR_AUX_XY_LAG_Y, TGR_AUX_PSI_LAG, TGR_AUX_RESET_PSI, TGR_AUX_EP_RETURN,
   TGR_AUX_STEP_NUM, TGR_AUX_ELAPSED, TGR_AUX_EPISODE, TGR_AUX_RING_LEN, TGR_AUX_WAYPT_X, TGR_AUX_WAYPT_Y,
   TGR_AUX_ORI_X, TGR_AUX_ORI_Y, TGR_AUX_VCMD_X, TGR_AUX_VCMD_Y, TGR_AUX_VCMD_W,
   TGR_AUX_SRC, /* lane whose RNG key produced the current episode: the env itself or a donor lane; TGR_AUX_EPISODE is the episode index under that key */
-  TGR_AUX_ACT = 17 /* ..22: actuator activations (model_kind 1) */
+  TGR_AUX_ACT = 17, /* ..22: actuator activations (model_kind 1) */
+  /* 23..54: the heading deque self._heading_buffer (tensegrity_env.py:242-243,326-345; tr_env.py:278,376-378,430-432), oldest entry
+   * first, TGR_AUX_RING_LEN valid entries.  tgr_set_state with aux replaces the deque (TGR_AUX_RING_LEN entries) */
+  TGR_AUX_RING = 23
 };
+#define TGR_RING_CAPACITY 32
 int tgr_get_state(tgr_handle* h, double* qpos, double* qvel, double* ctrl, double* qacc_warmstart, double* aux);
 /* set_state: like MujocoEnv.set_state it also recomputes the derived (lagged) kinematics from qpos;
  * aux (if given) then overrides the stored aux fields */
@@ -173,11 +181,18 @@ int tgr_set_state(tgr_handle* h, const double* qpos, const double* qvel, const d
 
 /* counters since creation: [0] dropped bar-bar contacts (slot overflow), [1] episodes settled by the settle kernel
  * (tgr_reset, or a finished env that found no ready donor), [2] envs reset from a donor lane, [3] Newton iterations,
- * [4] line-search evaluations, [5] sub-steps -- [3..5] summed over wavefronts (wave-uniform loop counts) */
+ * [4] line-search evaluations, [5] sub-steps -- [3..5] summed over wavefronts (wave-uniform loop counts),
+ * [6] lane-sub-steps that left the Newton solver at its iteration cap, [7] lane-sub-steps run (live and settling lanes) */
 int tgr_stats(tgr_handle* h, uint64_t out[8]);
-/* re-key the reset RNG; takes effect for subsequent resets.  replaces: Env.reset(seed=...) (gym API; the reference's own draws at
- * tensegrity_env.py:460,486 / tr_env.py:730,775,802,831 are unseeded) */
+/* re-key the reset RNG and restart every lane's episode counter, so that reset(seed=s) twice gives the same episode twice; takes
+ * effect for subsequent resets (follow it with a full tgr_reset: donor lanes settled under the old key are not re-drawn).
+ * replaces: Env.reset(seed=...) (gym API; the reference's own draws at tensegrity_env.py:460,486 / tr_env.py:730,775,802,831 are unseeded) */
 int tgr_set_seed(tgr_handle* h, uint64_t seed);
+/* tr_env with use_obs_noise: step() returns observation_with_noise and puts the noise-free one into info["real_observation"]
+ * (tr_env.py:484-507, read by run.py:147).  Bind a DEVICE buffer [N][obs_dim] of the handle's precision (caller-owned, must stay
+ * valid until unbound with NULL or the handle is destroyed); every tgr_step then also writes the noise-free observation of the step
+ * (for an env that finished: of its last step, like terminal_obs) there.  Without observation noise it equals obs before auto-reset. */
+int tgr_bind_real_observation(tgr_handle* h, void* real_obs_dev);
 int tgr_synchronize(tgr_handle* h);
 const char* tgr_last_error(const tgr_handle* h);
 const char* tgr_version(void);

@@ -191,18 +191,28 @@ def run_case(kind, action, seed, steps, direction=1, model="flat", **kwargs):
     env = cls(xml_file=xml, desired_action=action, desired_direction=direction, **kwargs)
     out = {"kind": kind, "action": action, "direction": direction, "model_kind": int(model == "uneven")}
     ep_resets = []
-    rec = {k: [] for k in ["obs", "reward", "terminated", "qpos", "qvel", "actions", "ctrl", "act"] + INFO_SCALARS}
+    rec = {k: [] for k in ["obs", "reward", "terminated", "qpos", "qvel", "actions", "ctrl", "act", "ring", "ring_len", "step_num"] + INFO_SCALARS}
+    noise = float(kwargs.get("reset_noise_scale", 0.0))
+
+    def ring_of(env):  # self._heading_buffer (a deque that is never cleared), oldest first, padded to the 32 slots of the C-ABI
+        r = np.zeros(32); b = list(env._heading_buffer); r[:len(b)] = b
+        return r, len(b)
     arng = _real_default_rng(1000 + seed)
     n_resets = 2
     for ep in range(n_resets):
         s = seed + 17 * ep
         np.random.default_rng = (lambda ss: (lambda *a, **k: _real_default_rng(ss) if not a and not k else _real_default_rng(*a, **k)))(s)
         np.random.seed(s)
+        env.np_random = _real_default_rng(s + 5)  # what reset_noise_scale draws from (tensegrity_env.py:439-445)
         obs0, _ = env.reset()
         pose, theta, tendons, u_way = replay_draws(kind, s, mean, std, lo, hi, action)
+        gq = _real_default_rng(s + 5)
+        dq = gq.uniform(low=-noise, high=noise, size=21); dv = noise * gq.standard_normal(18)
+        ring0, ring_len0 = ring_of(env)
         ep_resets.append(dict(pose=pose, theta=theta, tendons=tendons, u_way=u_way, obs=np.array(obs0, dtype=np.float64),
                               qpos=env.data.qpos.copy(), qvel=env.data.qvel.copy(), reset_psi=float(env._reset_psi), ctrl=env.data.ctrl.copy(),
-                              act=O.arr(env._dd.act).copy(),
+                              act=O.arr(env._dd.act).copy(), dq=dq, dv=dv, ring=ring0, ring_len=ring_len0,
+                              step_num=int(getattr(env, "_step_num", 0)),
                               xy_lag=np.array([np.mean([env.data.body(b).xpos[i] for b in ('r01_body', 'r23_body', 'r45_body')]) for i in range(2)]),
                               waypt=np.array(getattr(env, "_waypt", np.zeros(2)), dtype=np.float64).reshape(-1)[:2]
                               if np.size(getattr(env, "_waypt", np.zeros(0))) == 2 else np.zeros(2),
@@ -213,6 +223,8 @@ def run_case(kind, action, seed, steps, direction=1, model="flat", **kwargs):
                 a = (a * 1.5).astype(np.float32)  # exercise ctrl clamping (values outside ctrlrange)
             obs, r, term, trunc, info = env.step(a)
             rec["obs"].append(np.array(obs, dtype=np.float64)); rec["reward"].append(float(r)); rec["terminated"].append(bool(term))
+            rg, rl = ring_of(env)
+            rec["ring"].append(rg); rec["ring_len"].append(rl); rec["step_num"].append(int(getattr(env, "_step_num", 0)))
             rec["qpos"].append(env.data.qpos.copy()); rec["qvel"].append(env.data.qvel.copy()); rec["actions"].append(a); rec["ctrl"].append(env.data.ctrl.copy()); rec["act"].append(O.arr(env._dd.act).copy())
             for k in INFO_SCALARS:
                 rec[k].append(float(info[k]))
@@ -237,6 +249,8 @@ CASES = [
     ("tr_env", "vel_track", 26, 8, 1, {}),
     ("tensegrity_env", "straight", 31, 6, 1, {}, "uneven"),
     ("tr_env", "tracking", 32, 6, 1, {}, "uneven"),
+    ("tensegrity_env", "straight", 41, 6, 1, {"reset_noise_scale": 0.05}),
+    ("tr_env", "straight", 42, 6, 1, {"reset_noise_scale": 0.05}),
 ]
 
 

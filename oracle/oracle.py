@@ -61,7 +61,7 @@ class EnvCfg(C.Structure):
                 ("waypt_reward_amplitude", d), ("waypt_reward_stdev", d), ("yaw_reward_weight", d),
                 ("frame_skip", C.c_int), ("max_episode_steps", C.c_int), ("use_obs_noise", C.c_int),
                 ("obs_noise_tendon_stdev", d), ("obs_noise_cap_pos_stdev", d), ("model_kind", C.c_int), ("hf_nrow", C.c_int),
-                ("hf_ncol", C.c_int), ("hf_data", C.c_void_p)]
+                ("hf_ncol", C.c_int), ("hf_data", C.c_void_p), ("reset_noise_scale", d)]
 
 
 class Env(C.Structure):
@@ -106,6 +106,8 @@ def lib():
     L.tgo_env_obs_dim.argtypes = [P(EnvCfg)]
     L.tgo_env_obs_dim.restype = C.c_int
     L.tgo_env_reset.argtypes = [P(Env), C.c_int, d, P(d), P(d), P(d)]
+    L.tgo_env_reset_noise.argtypes = [P(Env), C.c_int, d, P(d), P(d), P(d), P(d), P(d)]
+    L.tgo_reset_noise_draws.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, d, P(d), P(d)]
     L.tgo_env_step.argtypes = [P(Env), P(C.c_float), P(d), P(d), P(C.c_int), P(C.c_int), P(d)]
     L.tgo_env_get_obs.argtypes = [P(Env), P(d)]
     L.tgo_env_reset_seeded.argtypes = [P(Env), C.c_uint64, C.c_uint64, C.c_uint64, P(d)]
@@ -195,6 +197,15 @@ class OracleEnv:
         lib().tgo_env_reset(C.byref(self.e), int(pose_idx), float(theta), dptr(t), dptr(u), dptr(obs))
         return obs
 
+    def reset_noise(self, pose_idx, theta, tendons, dq, dv, u_way=(0.5, 0.5)):
+        """reset with explicit reset_noise_scale perturbations (dq: 21 uniforms already in [-s, s], dv: 18 normals times s)"""
+        t = np.ascontiguousarray(tendons, dtype=np.float64)
+        u = np.ascontiguousarray(u_way, dtype=np.float64)
+        q = np.ascontiguousarray(dq, dtype=np.float64); v = np.ascontiguousarray(dv, dtype=np.float64)
+        obs = np.zeros(self.obs_dim)
+        lib().tgo_env_reset_noise(C.byref(self.e), int(pose_idx), float(theta), dptr(t), dptr(u), dptr(q), dptr(v), dptr(obs))
+        return obs
+
     def reset_seeded(self, seed, env_id, episode):
         obs = np.zeros(self.obs_dim)
         lib().tgo_env_reset_seeded(C.byref(self.e), seed, env_id, episode, dptr(obs))
@@ -253,7 +264,8 @@ class OracleBatch:
         qpos = np.zeros((n, NQ)); qvel = np.zeros((n, NV)); ctrl = np.zeros((n, NU)); warm = np.zeros((n, NV))
         self.last_act = np.zeros((n, NU))  # actuator activations (uneven-ground model only)
         aux = {k: np.zeros(n) for k in ("xy_lag_x", "xy_lag_y", "psi_lag", "reset_psi", "step_num", "elapsed", "ep_return",
-                                        "waypt_x", "waypt_y", "ori_x", "ori_y", "vcmd_x", "vcmd_y", "vcmd_w")}
+                                        "waypt_x", "waypt_y", "ori_x", "ori_y", "vcmd_x", "vcmd_y", "vcmd_w", "ring_len")}
+        aux["ring"] = np.zeros((n, RING))  # heading deque, oldest first (tensegrity_env.py:242-243, tr_env.py:278)
         for i in range(n):
             e = self.env(i)
             qpos[i] = arr(e.data.qpos); qvel[i] = arr(e.data.qvel); ctrl[i] = arr(e.data.ctrl)
@@ -269,6 +281,10 @@ class OracleBatch:
             aux["vcmd_x"][i], aux["vcmd_y"][i], aux["vcmd_w"][i] = e.lin_vel_cmd[0], e.lin_vel_cmd[1], e.ang_vel_cmd
             aux["reset_psi"][i] = e.reset_psi; aux["step_num"][i] = e.step_num; aux["elapsed"][i] = e.elapsed
             aux["ep_return"][i] = e.ep_return
+            aux["ring_len"][i] = e.ring_len
+            rg = arr(e.ring)
+            for j in range(e.ring_len):
+                aux["ring"][i, j] = rg[(e.ring_head + j) % RING]
         return qpos, qvel, ctrl, warm, aux
 
     def close(self):

@@ -438,7 +438,32 @@ void tgo_yaw_pose(const double qpos_in[TGO_NQ], double theta, double qpos_out[TG
   }
 }
 
+void tgo_reset_noise_draws(uint64_t seed, uint64_t env_id, uint64_t episode, double scale, double dq[TGO_NQ], double dv[TGO_NV]) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)episode, 0};
+  uint32_t o[4];
+  for (int j = 0; j < 11; j++) {
+    ctr[3] = 16 + j;
+    tgo_philox4x32(ctr, key, o);
+    dq[2 * j] = -scale + u53(o[0], o[1]) * 2.0 * scale;
+    if (2 * j + 1 < TGO_NQ) dq[2 * j + 1] = -scale + u53(o[2], o[3]) * 2.0 * scale;
+  }
+  for (int j = 0; j < 9; j++) {
+    ctr[3] = 32 + j;
+    tgo_philox4x32(ctr, key, o);
+    double u1 = 1.0 - u53(o[0], o[1]), u2 = u53(o[2], o[3]);
+    double r = sqrt(-2.0 * log(u1));
+    dv[2 * j] = scale * r * cos(2 * PI * u2);
+    dv[2 * j + 1] = scale * r * sin(2 * PI * u2);
+  }
+}
+
 void tgo_env_reset(tgo_env* e, int pose_idx, double theta, const double tendons[6], const double u_way[2], double* obs) {
+  tgo_env_reset_noise(e, pose_idx, theta, tendons, u_way, NULL, NULL, obs);
+}
+
+void tgo_env_reset_noise(tgo_env* e, int pose_idx, double theta, const double tendons[6], const double u_way[2], const double dq[TGO_NQ],
+                         const double dv[TGO_NV], double* obs) {
   const tgo_env_cfg* c = &e->cfg;
   tgo_data* d = &e->data;
   int act = c->desired_action;
@@ -447,7 +472,16 @@ void tgo_env_reset(tgo_env* e, int pose_idx, double theta, const double tendons[
   double qpos[TGO_NQ];
   if (c->env_kind == TGO_ENV_TR) memcpy(qpos, tgo_rolling_qpos[pose_idx], sizeof(qpos));
   else memcpy(qpos, e->model.qpos0, sizeof(qpos));
+  if (dq) { /* tensegrity_env.py:439-441: the perturbed quaternion is re-normalised by scipy's Rotation.from_quat (:451-456) */
+    for (int i = 0; i < TGO_NQ; i++) qpos[i] += dq[i];
+    for (int b = 0; b < 3; b++) {
+      double* q = qpos + 7 * b + 3;
+      double nn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      for (int i = 0; i < 4; i++) q[i] /= nn;
+    }
+  }
   tgo_yaw_pose(qpos, theta, d->qpos);
+  if (dv) memcpy(d->qvel, dv, sizeof(double) * TGO_NV); /* qvel = init_qvel + s * N(0,1): not rotated (tensegrity_env.py:442-445,484) */
   tgo_forward(&e->model, d); /* set_state -> mj_forward */
   if (c->env_kind == TGO_ENV_TENSEGRITY) {
     double r; int t;
@@ -500,5 +534,11 @@ void tgo_env_reset_seeded(tgo_env* e, uint64_t seed, uint64_t env_id, uint64_t e
   tgo_rng_draws(seed, env_id, episode, c->env_kind, c->tendon_reset_mean, c->tendon_reset_stdev, c->tendon_min_length,
                 c->tendon_max_length, c->min_reset_heading, c->max_reset_heading, &pose, &theta, tendons, uw);
   e->rng_seed = seed; e->rng_key = env_id; e->rng_episode = episode;
-  tgo_env_reset(e, pose, theta, tendons, uw, obs);
+  if (c->reset_noise_scale != 0.0) {
+    double dq[TGO_NQ], dv[TGO_NV];
+    tgo_reset_noise_draws(seed, env_id, episode, c->reset_noise_scale, dq, dv);
+    tgo_env_reset_noise(e, pose, theta, tendons, uw, dq, dv, obs);
+  } else {
+    tgo_env_reset(e, pose, theta, tendons, uw, obs);
+  }
 }

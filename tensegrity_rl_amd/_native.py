@@ -10,12 +10,14 @@ i32, f64, u64 = C.c_int32, C.c_double, C.c_uint64
 ENV_TENSEGRITY, ENV_TR = 0, 1
 ACTIONS = {"straight": 0, "turn": 1, "aiming": 2, "tracking": 3, "vel_track": 4}
 PRECISION = {"f32": 0, "f64": 1, "float32": 0, "float64": 1}
-INFO_K, AUX_K, NQ, NV, NU = 26, 23, 21, 18, 6
+INFO_K, AUX_K, NQ, NV, NU = 26, 55, 21, 18, 6
+AUX_RING, RING_CAPACITY = 23, 32
 INFO_TENDON_LENGTH, INFO_BAR_CONTACT = 16, 25
 INFO_KEYS = ["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
              "distance_from_origin", "x_velocity", "y_velocity", "forward_reward"]
 AUX_KEYS = ["xy_lag_x", "xy_lag_y", "psi_lag", "reset_psi", "ep_return", "step_num", "elapsed", "episode", "ring_len",
-            "waypt_x", "waypt_y", "ori_x", "ori_y", "vcmd_x", "vcmd_y", "vcmd_w", "src"] + [f"act_{i}" for i in range(6)]
+            "waypt_x", "waypt_y", "ori_x", "ori_y", "vcmd_x", "vcmd_y", "vcmd_w", "src"] + [f"act_{i}" for i in range(6)] + \
+           [f"ring_{i}" for i in range(32)]
 
 
 class Config(C.Structure):
@@ -34,12 +36,13 @@ class Config(C.Structure):
         ("waypt_reward_amplitude", f64), ("waypt_reward_stdev", f64), ("yaw_reward_weight", f64), ("solver_warm_start", i32),
         ("use_obs_noise", i32), ("obs_noise_tendon_stdev", f64), ("obs_noise_cap_pos_stdev", f64),
         ("model_kind", i32), ("site_offset", f64), ("act_tau", f64), ("hf_size", f64 * 4), ("hf_pos", f64 * 3),
+        ("reset_noise_scale", f64),
     ]
 
 
 SYMBOLS = ["tgr_default_config", "tgr_create", "tgr_destroy", "tgr_num_envs", "tgr_obs_dim", "tgr_precision", "tgr_reset",
            "tgr_step", "tgr_step_f64", "tgr_get_state", "tgr_set_state", "tgr_stats", "tgr_set_seed", "tgr_synchronize",
-           "tgr_last_error", "tgr_version", "tgr_sizeof_config", "tgr_lane_key", "tgr_uneven_config", "tgr_set_hfield"]
+           "tgr_last_error", "tgr_version", "tgr_sizeof_config", "tgr_lane_key", "tgr_uneven_config", "tgr_set_hfield", "tgr_bind_real_observation"]
 
 _lib = None
 
@@ -83,6 +86,7 @@ def load():
     L.tgr_uneven_config.argtypes = [C.POINTER(Config)]
     L.tgr_set_hfield.argtypes = [vp, vp, C.c_int, C.c_int]
     L.tgr_lane_key.restype = C.c_uint64
+    L.tgr_bind_real_observation.argtypes = [vp, vp]
     if L.tgr_sizeof_config() != C.sizeof(Config):
         raise RuntimeError(f"tgr_config layout mismatch: C {L.tgr_sizeof_config()} vs ctypes {C.sizeof(Config)}")
     _lib = L

@@ -1015,7 +1015,11 @@ TGR_DEV void newton_dphi(const Params<T>& P, T* lds, int wid, const LSlot<T>* ls
 template <typename T, int LW> TGR_DEV void warm_to_lds(const Sim<T>& S, T* lds, int wid) {
 #pragma unroll
   for (int b = 0; b < 3; b++)
-    if (b == wid) { st3<T, LW>(lds, L_A + 6 * b, S.al[b]); st3<T, LW>(lds, L_A + 6 * b + 3, S.aa[b]); }
+    if (b == wid) {
+      st3<T, LW>(lds, L_A + 6 * b, S.al[b]); st3<T, LW>(lds, L_A + 6 * b + 3, S.aa[b]);
+      // the force warm start (warm_start == 2) reads last sub-step's constraint wrench: none before the first one
+      st3<T, LW>(lds, L_FC + 6 * b, mk(T(0), T(0), T(0))); st3<T, LW>(lds, L_FC + 6 * b + 3, mk(T(0), T(0), T(0)));
+    }
 }
 // ... and fetch it back for store_sim when the last sub-step is done
 template <typename T, int LW> TGR_DEV void warm_from_lds(Sim<T>& S, const T* lds) {
@@ -1249,6 +1253,12 @@ TGR_DEV void base_bar(const Params<T>& P, const Sim<T>& S, const Rot<T>* R, T* l
   if (!P.warm_start) {  // with mujoco's warm start the previous solution simply stays in L_A
     st3<T, LW>(lds, L_A + 6 * B, l0);
     st3<T, LW>(lds, L_A + 6 * B + 3, a0);
+  } else if (P.warm_start == 2) {
+    // force warm start: last sub-step's constraint wrench on top of THIS sub-step's unconstrained acceleration.  A contact's
+    // reference acceleration moves by ~B h a every sub-step, so last sub-step's acceleration is a poor guess -- but its contact
+    // forces are a good one (a cap at rest carries the same weight from one millisecond to the next).
+    st3<T, LW>(lds, L_A + 6 * B, l0 + im * ld3<T, LW>(lds, L_FC + 6 * B));
+    st3<T, LW>(lds, L_A + 6 * B + 3, a0 + inv_inertia(P, R[B].ez, ld3<T, LW>(lds, L_FC + 6 * B + 3)));
   }
   // floor contacts: caps 2B, 2B+1
 #pragma unroll

@@ -33,6 +33,7 @@ enum : int {
 };
 enum : int { I_STEPNUM = 0, I_ELAPSED, I_RINGLEN, I_RINGHEAD, I_EPISODE, I_PHASE, I_SRC, I_SRCEP, NI };
 constexpr int RING = 32;
+static_assert(RING == TGR_RING_CAPACITY && TGR_AUX_K == TGR_AUX_RING + RING, "aux layout of tgr_get_state / tgr_set_state");
 constexpr double PI = 3.14159265358979323846;
 
 template <typename T> struct EnvCfg {
@@ -42,7 +43,7 @@ template <typename T> struct EnvCfg {
   T direction, ctrl_cost_weight, contact_cost_weight, healthy_reward, contact_lo, contact_hi, dt;
   T ditch_max, ditch_std, waypt_amp, waypt_std, yaw_weight;
   double waypt_range[2], waypt_angle_range[2];
-  double min_heading, max_heading, ten_mean, ten_std, ten_max, ten_min;
+  double min_heading, max_heading, ten_mean, ten_std, ten_max, ten_min, reset_noise;
   unsigned long long seed, first_env_id;
 };
 
@@ -59,6 +60,7 @@ template <typename T> struct KArgs {
   unsigned long long* counters;
   int auto_reset;
   T* obs_reset;  // where the settle kernel writes reset observations ([N][D]) or null
+  T* obs_clean;  // info["real_observation"] of tr_env.py:507: the noise-free observation of the step ([N][D]) or null
 };
 
 __constant__ double c_qpos0[21] = {0.08369179, -0.28792231, 0.24830847, -0.49145555, 0.7539914, -0.27511722, -0.33805166,
@@ -428,13 +430,46 @@ template <typename T> TGR_DEV void init_episode(const EnvCfg<T>& E, unsigned lon
   Draws dr = reset_draws(E, key, episode);
   double c = cos(dr.theta), s = sin(dr.theta), ch = cos(0.5 * dr.theta), sh = sin(0.5 * dr.theta);
   const double* q0 = E.env_kind == TGR_ENV_TR ? c_rolling[dr.pose] : (E.model_kind ? c_qpos0_uneven : c_qpos0);
+  double qn[21], vn[18];
+#pragma unroll
+  for (int i = 0; i < 21; i++) qn[i] = q0[i];
+#pragma unroll
+  for (int i = 0; i < 18; i++) vn[i] = 0.0;
+  if (E.reset_noise != 0.0) {
+    // reset_noise_scale (tensegrity_env.py:436-445, tr_env.py:734-743): qpos += U(-s, s), qvel = s N(0,1), before the yaw transform;
+    // scipy's Rotation.from_quat re-normalises the perturbed quaternion (tensegrity_env.py:451-456)
+    const unsigned k0 = (unsigned)E.seed, k1 = (unsigned)(E.seed >> 32);
+    unsigned o[4];
+#pragma unroll 1
+    for (int j = 0; j < 11; j++) {
+      philox((unsigned)key, (unsigned)(key >> 32), (unsigned)episode, 16 + j, k0, k1, o);
+      qn[2 * j] += -E.reset_noise + u53(o[0], o[1]) * 2.0 * E.reset_noise;
+      if (2 * j + 1 < 21) qn[2 * j + 1] += -E.reset_noise + u53(o[2], o[3]) * 2.0 * E.reset_noise;
+    }
+#pragma unroll 1
+    for (int j = 0; j < 9; j++) {
+      philox((unsigned)key, (unsigned)(key >> 32), (unsigned)episode, 32 + j, k0, k1, o);
+      double u1 = 1.0 - u53(o[0], o[1]), u2 = u53(o[2], o[3]);
+      double r = sqrt(-2.0 * log(u1));
+      vn[2 * j] = E.reset_noise * r * cos(2 * PI * u2); vn[2 * j + 1] = E.reset_noise * r * sin(2 * PI * u2);
+    }
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      double* q = qn + 7 * b + 3;
+      double in = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      q[0] *= in; q[1] *= in; q[2] *= in; q[3] *= in;
+    }
+  }
 #pragma unroll
   for (int b = 0; b < 3; b++) {
-    const double* q = q0 + 7 * b;
+    const double* q = qn + 7 * b;
     S.x[b] = mk(T(c * q[0] - s * q[1]), T(s * q[0] + c * q[1]), T(q[2]));
     double w = q[3], x = q[4], y = q[5], z = q[6];
     S.q[b][0] = T(ch * w - sh * z); S.q[b][1] = T(ch * x - sh * y); S.q[b][2] = T(ch * y + sh * x); S.q[b][3] = T(ch * z + sh * w);
-    S.v[b] = mk(T(0), T(0), T(0)); S.w[b] = S.v[b]; S.al[b] = S.v[b]; S.aa[b] = S.v[b];
+    // qvel is (v_world, w_body) and is not rotated (tensegrity_env.py:484); Sim keeps w in the world frame
+    S.v[b] = mk(T(vn[6 * b]), T(vn[6 * b + 1]), T(vn[6 * b + 2]));
+    S.w[b] = rot_apply(quat_rot(S.q[b]), mk(T(vn[6 * b + 3]), T(vn[6 * b + 4]), T(vn[6 * b + 5])));
+    S.al[b] = mk(T(0), T(0), T(0)); S.aa[b] = S.al[b];
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) { S.ctrl[i] = T(dr.tendons[i]); S.act[i] = T(0); }  // mj_resetData zeroes the activations
@@ -608,6 +643,10 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
     atomicAdd(&k.counters[5], (unsigned long long)E.frame_skip);
   }
   if (active && w0 && lag.n_unconv) atomicAdd(&k.counters[6], (unsigned long long)lag.n_unconv);
+  if (w0) {  // lane-sub-steps run: what counters[6] is a fraction of
+    const int nact = __popcll(__ballot(active));
+    if (lane == 0) atomicAdd(&k.counters[7], (unsigned long long)(nact * E.frame_skip));
+  }
   V3<T> wb[3];
   if (active && w0) { warm_from_lds<T, LW>(S, lds); store_sim(k.st, m, e, S, lag, wb); }
   else if (active) {
@@ -658,6 +697,10 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
     done = out.terminated || truncated;
     if (valid && w0) {
       make_obs(P, E, S, lag, wb, ms, orow);
+      if (k.obs_clean) {
+        T* cp = k.obs_clean + (size_t)e * D;
+        for (int i = 0; i < D; i++) cp[i] = orow[i];
+      }
       if (E.use_obs_noise) apply_obs_noise(E, lane_key(E, n, k.ist[I_SRC * m + e]), (unsigned)k.ist[I_SRCEP * m + e], elapsed, orow);
       k.st[(F_XYLAG + 0) * m + e] = out.xy[0]; k.st[(F_XYLAG + 1) * m + e] = out.xy[1];
       k.st[F_PSILAG * m + e] = out.psi_straight;
@@ -868,6 +911,7 @@ struct tgr_handle {
   uint8_t* doneflag = nullptr;
   unsigned long long* counters = nullptr;
   float* hf = nullptr;  // heightfield elevations (model_kind 1)
+  void* obs_clean = nullptr;  // caller-owned [N][D] buffer bound with tgr_bind_real_observation, or null
   int hf_nrow = 0, hf_ncol = 0;
   std::string err;
 };
@@ -882,6 +926,13 @@ static thread_local std::string g_err;
       return TGR_ERR_HIP;                                                                        \
     }                                                                                            \
   } while (0)
+
+static void free_handle(tgr_handle* h) {
+  (void)hipFree(h->hf);
+  (void)hipFree(h->st); (void)hipFree(h->ist); (void)hipFree(h->ring); (void)hipFree(h->dobs); (void)hipFree(h->list_count);
+  (void)hipFree(h->list); (void)hipFree(h->rlist); (void)hipFree(h->doneflag); (void)hipFree(h->counters);
+  delete h;
+}
 
 #ifndef TGR_LW_F32
 #define TGR_LW_F32 64
@@ -954,6 +1005,7 @@ extern "C" int tgr_default_config(tgr_config* c, int env_kind, int desired_actio
   c->model_kind = 0; c->site_offset = 0.0675; c->act_tau = 1.0;
   c->hf_size[0] = 50; c->hf_size[1] = 50; c->hf_size[2] = 1; c->hf_size[3] = 0.1;
   c->hf_pos[0] = 0; c->hf_pos[1] = 0; c->hf_pos[2] = -1.0;
+  c->reset_noise_scale = 0.0;
   return TGR_OK;
 }
 
@@ -1034,38 +1086,18 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   P.cf_lo = T(c.contact_force_lo); P.cf_hi = T(c.contact_force_hi);
   E.min_heading = c.min_reset_heading; E.max_heading = c.max_reset_heading;
   E.ten_mean = c.tendon_reset_mean; E.ten_std = c.tendon_reset_stdev; E.ten_max = c.tendon_max_length; E.ten_min = c.tendon_min_length;
-  E.seed = c.seed; E.first_env_id = c.first_env_id;
+  E.seed = c.seed; E.first_env_id = c.first_env_id; E.reset_noise = c.reset_noise_scale;
   k.n = h->n; k.m = h->m;
   k.st = (T*)h->st; k.ist = h->ist; k.ring = (T*)h->ring; k.dobs = (T*)h->dobs;
   k.list_count = h->list_count; k.list = h->list; k.rlist = h->rlist; k.doneflag = h->doneflag; k.counters = h->counters;
   k.auto_reset = c.auto_reset;
   k.actions = nullptr; k.obs = nullptr; k.reward = nullptr; k.terminated = nullptr; k.truncated = nullptr;
-  k.terminal_obs = nullptr; k.info = nullptr; k.obs_reset = nullptr;
+  k.terminal_obs = nullptr; k.info = nullptr; k.obs_reset = nullptr; k.obs_clean = nullptr;
 }
 
-extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_handle** out) {
-  if (!cfg || !out || n_envs <= 0) { g_err = "tgr_create: bad arguments"; return TGR_ERR_INVALID; }
-  if (cfg->desired_action < TGR_ACT_STRAIGHT || cfg->desired_action > TGR_ACT_VEL_TRACK ||
-      (cfg->env_kind == TGR_ENV_TENSEGRITY && cfg->desired_action > TGR_ACT_TURN)) {
-    g_err = "tgr_create: desired_action not supported by this env class (tensegrity_env: straight|turn; tr_env: + aiming|tracking|vel_track)";
-    return TGR_ERR_UNSUPPORTED;
-  }
-  if (cfg->model_kind < 0 || cfg->model_kind > 1) { g_err = "tgr_create: model_kind must be 0 (flat) or 1 (uneven ground)"; return TGR_ERR_UNSUPPORTED; }
-  if (cfg->solimp[4] != 2.0 || cfg->solref[0] >= 0) { g_err = "tgr_create: only direct solref and power-2 solimp"; return TGR_ERR_UNSUPPORTED; }
-  if (cfg->n_donors > 8 * n_envs) { g_err = "tgr_create: n_donors must be <= 8 * n_envs"; return TGR_ERR_INVALID; }
-  if (cfg->reward_delay_steps >= RING - 1 || cfg->reward_delay_steps < 0) { g_err = "tgr_create: reward_delay_steps too large"; return TGR_ERR_INVALID; }
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "tgr_create: no HIP device (the HIP path is required; there is no CPU fallback)"; return TGR_ERR_HIP; }
-  if (device < 0 || device >= ndev) { g_err = "tgr_create: bad device index"; return TGR_ERR_INVALID; }
-  tgr_handle* h = new (std::nothrow) tgr_handle();
-  if (!h) return TGR_ERR_INVALID;
-  h->cfg = *cfg; h->n = n_envs; h->device = device; h->obs_dim = obs_dim_of(*cfg);
-  int donors = cfg->n_donors < 0 ? 2 * n_envs : cfg->n_donors;
-  if (!cfg->auto_reset) donors = 0;
-  h->m = n_envs + donors;
-  *out = h;
-  HIP_TRY(h, hipSetDevice(device));
-  size_t ts = cfg->precision == TGR_PRECISION_F64 ? 8 : 4;
+static int alloc_handle(tgr_handle* h, int n_envs, int donors) {
+  HIP_TRY(h, hipSetDevice(h->device));
+  size_t ts = h->cfg.precision == TGR_PRECISION_F64 ? 8 : 4;
   size_t m = (size_t)h->m;
   HIP_TRY(h, hipMalloc(&h->st, ts * NF * m));
   HIP_TRY(h, hipMemset(h->st, 0, ts * NF * m));
@@ -1089,6 +1121,37 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   return TGR_OK;
 }
 
+extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_handle** out) {
+  if (!cfg || !out || n_envs <= 0) { g_err = "tgr_create: bad arguments"; return TGR_ERR_INVALID; }
+  if (cfg->desired_action < TGR_ACT_STRAIGHT || cfg->desired_action > TGR_ACT_VEL_TRACK ||
+      (cfg->env_kind == TGR_ENV_TENSEGRITY && cfg->desired_action > TGR_ACT_TURN)) {
+    g_err = "tgr_create: desired_action not supported by this env class (tensegrity_env: straight|turn; tr_env: + aiming|tracking|vel_track)";
+    return TGR_ERR_UNSUPPORTED;
+  }
+  if (cfg->model_kind < 0 || cfg->model_kind > 1) { g_err = "tgr_create: model_kind must be 0 (flat) or 1 (uneven ground)"; return TGR_ERR_UNSUPPORTED; }
+  if (cfg->solimp[4] != 2.0 || cfg->solref[0] >= 0) { g_err = "tgr_create: only direct solref and power-2 solimp"; return TGR_ERR_UNSUPPORTED; }
+  if (cfg->n_donors > 8 * n_envs) { g_err = "tgr_create: n_donors must be <= 8 * n_envs"; return TGR_ERR_INVALID; }
+  if (cfg->reward_delay_steps >= RING - 1 || cfg->reward_delay_steps < 0) { g_err = "tgr_create: reward_delay_steps too large"; return TGR_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "tgr_create: no HIP device (the HIP path is required; there is no CPU fallback)"; return TGR_ERR_HIP; }
+  if (device < 0 || device >= ndev) { g_err = "tgr_create: bad device index"; return TGR_ERR_INVALID; }
+  tgr_handle* h = new (std::nothrow) tgr_handle();
+  if (!h) return TGR_ERR_INVALID;
+  h->cfg = *cfg; h->n = n_envs; h->device = device; h->obs_dim = obs_dim_of(*cfg);
+  int donors = cfg->n_donors < 0 ? 2 * n_envs : cfg->n_donors;
+  if (!cfg->auto_reset) donors = 0;
+  h->m = n_envs + donors;
+  *out = nullptr;
+  const int rc = alloc_handle(h, n_envs, donors);
+  if (rc != TGR_OK) {  // nothing half-built leaves this function: the message moves to the thread's slot, the handle is freed
+    g_err = "tgr_create: " + h->err;
+    free_handle(h);
+    return rc;
+  }
+  *out = h;
+  return TGR_OK;
+}
+
 extern "C" int tgr_set_hfield(tgr_handle* h, const float* heights, int nrow, int ncol) {
   if (!h) return TGR_ERR_INVALID;
   if (!heights || nrow < 2 || ncol < 2) { h->err = "tgr_set_hfield: need a [nrow >= 2][ncol >= 2] array"; return TGR_ERR_INVALID; }
@@ -1105,10 +1168,7 @@ extern "C" int tgr_destroy(tgr_handle* h) {
   if (!h) return TGR_OK;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
-  (void)hipFree(h->hf);
-  (void)hipFree(h->st); (void)hipFree(h->ist); (void)hipFree(h->ring); (void)hipFree(h->dobs); (void)hipFree(h->list_count);
-  (void)hipFree(h->list); (void)hipFree(h->rlist); (void)hipFree(h->doneflag); (void)hipFree(h->counters);
-  delete h;
+  free_handle(h);
   return TGR_OK;
 }
 extern "C" int tgr_num_envs(const tgr_handle* h) { return h ? h->n : 0; }
@@ -1128,6 +1188,15 @@ extern "C" uint64_t tgr_lane_key(const tgr_handle* h, int lane) {
 extern "C" int tgr_set_seed(tgr_handle* h, uint64_t seed) {
   if (!h) return TGR_ERR_INVALID;
   h->cfg.seed = seed;
+  // Env.reset(seed=s) twice must give the same episode twice: every lane's episode counter starts over
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemset(h->ist + (size_t)I_EPISODE * h->m, 0, sizeof(int) * (size_t)h->m));
+  return TGR_OK;
+}
+extern "C" int tgr_bind_real_observation(tgr_handle* h, void* real_obs_dev) {
+  if (!h) return TGR_ERR_INVALID;
+  h->obs_clean = real_obs_dev;
   return TGR_OK;
 }
 extern "C" int tgr_stats(tgr_handle* h, uint64_t out[8]) {
@@ -1187,6 +1256,7 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
   k.actions = actions; k.obs = obs; k.reward = reward; k.terminated = terminated; k.truncated = truncated;
   k.terminal_obs = terminal_obs; k.info = info;
   k.obs_reset = obs;
+  k.obs_clean = (T*)h->obs_clean;
   constexpr int LW = LaneW<T>::value;
   int blocks = (h->m + LW - 1) / LW;
   if (h->cfg.model_kind) hipLaunchKernelGGL((step_kernel<T, LW, 1>), dim3(blocks), dim3(256), 0, s, k);
@@ -1224,9 +1294,14 @@ template <typename T> static int get_state_impl(tgr_handle* h, double* qpos, dou
   size_t n = h->m, nlive = h->n;
   std::vector<T> st(NF * n);
   std::vector<int> ist(NI * n);
+  std::vector<T> ring;
   HIP_TRY(h, hipDeviceSynchronize());
   HIP_TRY(h, hipMemcpy(st.data(), h->st, sizeof(T) * NF * n, hipMemcpyDeviceToHost));
   HIP_TRY(h, hipMemcpy(ist.data(), h->ist, sizeof(int) * NI * n, hipMemcpyDeviceToHost));
+  if (aux) {
+    ring.resize(RING * n);
+    HIP_TRY(h, hipMemcpy(ring.data(), h->ring, sizeof(T) * RING * n, hipMemcpyDeviceToHost));
+  }
   for (size_t e = 0; e < nlive; e++) {
     if (qpos) for (int i = 0; i < 21; i++) qpos[e * 21 + i] = (double)st[(F_QPOS + i) * n + e];
     if (qvel) for (int i = 0; i < 18; i++) qvel[e * 18 + i] = (double)st[(F_QVEL + i) * n + e];
@@ -1244,6 +1319,8 @@ template <typename T> static int get_state_impl(tgr_handle* h, double* qpos, dou
       a[TGR_AUX_VCMD_X] = (double)st[(F_VCMD + 0) * n + e]; a[TGR_AUX_VCMD_Y] = (double)st[(F_VCMD + 1) * n + e];
       a[TGR_AUX_VCMD_W] = (double)st[(F_VCMD + 2) * n + e];
       for (int i = 0; i < 6; i++) a[TGR_AUX_ACT + i] = (double)st[(F_ACT + i) * n + e];
+      const int len = ist[I_RINGLEN * n + e], head = ist[I_RINGHEAD * n + e];
+      for (int i = 0; i < RING; i++) a[TGR_AUX_RING + i] = i < len ? (double)ring[(size_t)((head + i) % RING) * n + e] : 0.0;
     }
   }
   return TGR_OK;
@@ -1284,6 +1361,17 @@ static int set_state_impl(tgr_handle* h, const double* qpos, const double* qvel,
       st[(F_VCMD + 2) * n + e] = (T)a[TGR_AUX_VCMD_W];
       for (int i = 0; i < 6; i++) st[(F_ACT + i) * n + e] = (T)a[TGR_AUX_ACT + i];
     }
+    // the heading deque: replaced by the caller's (oldest first)
+    std::vector<T> ring(RING * n);
+    HIP_TRY(h, hipMemcpy(ring.data(), h->ring, sizeof(T) * RING * n, hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < nlive; e++) {
+      const double* a = aux + e * TGR_AUX_K;
+      int len = (int)a[TGR_AUX_RING_LEN];
+      if (len < 0 || len >= RING) { h->err = "tgr_set_state: aux ring length out of range"; return TGR_ERR_INVALID; }
+      ist[I_RINGLEN * n + e] = len; ist[I_RINGHEAD * n + e] = 0;
+      for (int i = 0; i < len; i++) ring[(size_t)i * n + e] = (T)a[TGR_AUX_RING + i];
+    }
+    HIP_TRY(h, hipMemcpy(h->ring, ring.data(), sizeof(T) * RING * n, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->st, st.data(), sizeof(T) * NF * n, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->ist, ist.data(), sizeof(int) * NI * n, hipMemcpyHostToDevice));
   }

@@ -50,6 +50,8 @@ class _GymEnvBase:
             d["waypt"] = ih[10:12].copy()
             d["oripoint"] = ih[12:14].copy()
             d["tendon_length"] = ih[N.INFO_TENDON_LENGTH:N.INFO_TENDON_LENGTH + 9].copy()
+            ro = self._venv.real_obs if self._venv.real_obs is not None else obs  # tr_env.py:507; equal to obs without observation noise
+            d["real_observation"] = ro.cpu().numpy().astype(np.float64)[0]
         d["total_bar_contact"] = float(ih[N.INFO_BAR_CONTACT])  # what run.py:149-155 computes from data.contact
         return (obs.cpu().numpy().astype(np.float64)[0], float(rew.cpu().numpy()[0]), bool(term.cpu().numpy()[0]),
                 bool(trunc.cpu().numpy()[0]), d)

@@ -136,6 +136,7 @@ def rollout(venv, actor, steps, deterministic=False, stop_after_done=500):
     logs = {k: [] for k in LOG_FILES}
     logs["done"] = []
     logs["oripoint"] = []
+    logs["observed_tendon_slice"] = []  # not a run.py file: the nine tendon entries of the observation
     extra = np.full(n, stop_after_done, dtype=np.int64)
     for _ in range(int(steps)):
         a = actor.act(obs, deterministic).contiguous()
@@ -144,15 +145,17 @@ def rollout(venv, actor, steps, deterministic=False, stop_after_done=500):
         oh = obs.cpu().numpy().astype(np.float64)
         logs["actions"].append(a.cpu().numpy())
         logs["tendon_length"].append(ih[:, N.INFO_TENDON_LENGTH:N.INFO_TENDON_LENGTH + 9])
+        # run.py:144-146 verbatim: obs[-9:] and obs[:18] whatever the layout (for the 48-dim tracking / aiming / vel_track observation
+        # obs[-9:] is NOT the nine tendon lengths -- the reference logs it that way; the tendon slice goes to its own key)
+        logs["observed_tendon_length"].append(oh[:, -9:])
+        logs["observed_cap_posi"].append(oh[:, :18])
+        real = venv.real_obs.cpu().numpy().astype(np.float64) if getattr(venv, "real_obs", None) is not None else oh
+        logs["cap_posi"].append(real[:, :18])  # info["real_observation"][:18] (run.py:145)
         if tr:  # tr_env observation: 18 cap positions first, tendons right after the (optional) 18 cap velocities
             nt = 36 if venv.cfg.use_cap_velocity else 18
-            logs["observed_tendon_length"].append(oh[:, nt:nt + 9] if D > nt + 9 else oh[:, -9:])
-            logs["observed_cap_posi"].append(oh[:, :18])
-            logs["cap_posi"].append(oh[:, :18])  # info["real_observation"][:18]: equal while use_obs_noise is off
+            logs["observed_tendon_slice"].append(oh[:, nt:nt + 9])
         else:
-            logs["observed_tendon_length"].append(oh[:, -9:])
-            logs["observed_cap_posi"].append(oh[:, :18])
-            logs["cap_posi"].append(oh[:, :18])
+            logs["observed_tendon_slice"].append(oh[:, -9:])
         logs["total_bar_contact"].append(ih[:, N.INFO_BAR_CONTACT])
         logs["reward_forward"].append(ih[:, 0])
         logs["reward_ctrl"].append(ih[:, 1])

@@ -6,7 +6,8 @@ import torch.distributed as dist
 
 
 def shard_range(rank, world_size, n_total):
-    """Contiguous block of global env ids owned by `rank` (sizes differ by at most one)."""
+    """Contiguous block of global env ids owned by `rank` (sizes differ by at most one; RolloutGatherer needs them equal, i.e.
+    n_total divisible by world_size -- BASELINE's configs are: 4096 per GPU)."""
     base, rem = divmod(n_total, world_size)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
@@ -30,6 +31,13 @@ class RolloutGatherer:
         self.cur = 0
         self.sets = []
         coll = self.world > 1 or self.always
+        if self.world > 1 and dist.is_initialized():
+            # all_gather_into_tensor needs the same shard on every rank; a ragged split would hang or corrupt the collective
+            lohi = torch.tensor([n_local, -n_local], dtype=torch.int64, device=device)
+            dist.all_reduce(lohi, op=dist.ReduceOp.MIN)
+            if int(lohi[0]) != -int(lohi[1]):
+                raise ValueError(f"RolloutGatherer: shards must have equal size on every rank (min {int(lohi[0])}, max {-int(lohi[1])}); "
+                                 "make n_total divisible by the world size")
         for _ in range(2 if self.overlap else 1):
             b = {"obs": torch.zeros((chunk, n_local, obs_dim), dtype=dtype, device=device),
                  "rew": torch.zeros((chunk, n_local), dtype=dtype, device=device),

@@ -21,9 +21,9 @@ _DIRECT = ["use_contact_forces", "use_cap_velocity", "terminate_when_unhealthy",
            "ctrl_cost_weight", "contact_cost_weight", "healthy_reward", "min_reset_heading", "max_reset_heading",
            "tendon_reset_mean", "tendon_reset_stdev", "tendon_max_length", "tendon_min_length", "ditch_reward_max",
            "ditch_reward_stdev", "waypt_reward_amplitude", "waypt_reward_stdev", "yaw_reward_weight", "use_obs_noise",
-           "obs_noise_tendon_stdev", "obs_noise_cap_pos_stdev"]
+           "obs_noise_tendon_stdev", "obs_noise_cap_pos_stdev", "reset_noise_scale"]
 # accepted for signature compatibility, no effect on the built path (reference defaults)
-_IGNORED = ["xml_file", "render_mode", "reset_noise_scale", "contact_with_self_penalty",
+_IGNORED = ["xml_file", "render_mode", "contact_with_self_penalty",
             "use_cap_size_noise", "cap_size_noise_range",
             "threshold_waypt", "width", "height", "camera_id", "camera_name"]
 
@@ -78,8 +78,6 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
             if k == "use_cap_size_noise" and v:
                 # tr_env.py:685-706 calls model.geom_names, which the mujoco bindings do not have: it raises in the reference too
                 raise NotImplementedError("use_cap_size_noise=True is dead code in the reference (AttributeError) and is not built")
-            if k == "reset_noise_scale" and v:
-                raise NotImplementedError("reset_noise_scale != 0 is not built")
     if "contact_force_range" in kwargs:
         lo, hi = kwargs.pop("contact_force_range")
         cfg.contact_force_lo, cfg.contact_force_hi = float(lo), float(hi)
@@ -146,6 +144,10 @@ class TensegrityVecEnv:
             self.terminated = torch.zeros(n, dtype=torch.uint8, device=self.device)
             self.truncated = torch.zeros(n, dtype=torch.uint8, device=self.device)
             self.info = torch.zeros((n, N.INFO_K), dtype=dt, device=self.device)
+            # info["real_observation"] (tr_env.py:507): the noise-free observation; only needed (and bound) with use_obs_noise
+            self.real_obs = torch.zeros((n, D), dtype=dt, device=self.device) if self.cfg.use_obs_noise and self.cfg.env_kind == N.ENV_TR else None
+        if self.real_obs is not None:
+            N.check(self.handle, self.lib.tgr_bind_real_observation(self.handle, self.real_obs.data_ptr()), "tgr_bind_real_observation")
         self.observation_space = Box(low=-np.inf, high=np.inf, shape=(D,), dtype=np.float64)
         self.action_space = Box(low=np.float32(self.cfg.ctrl_range[0]), high=np.float32(self.cfg.ctrl_range[1]), shape=(6,), dtype=np.float32)
         self.render_mode = None
@@ -203,14 +205,15 @@ class TensegrityVecEnv:
         term_h = term.cpu().numpy().astype(bool)
         trunc_h = trunc.cpu().numpy().astype(bool)
         dones = term_h | trunc_h
-        infos = self._infos(dones, term_h, trunc_h, tobs, info)
+        infos = self._infos(dones, term_h, trunc_h, tobs, info, obs_h)
         return obs_h, rew_h, dones, infos
 
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
 
-    def _infos(self, dones, term_h, trunc_h, tobs, info):
+    def _infos(self, dones, term_h, trunc_h, tobs, info, obs_h=None):
+        """info_mode="minimal": empty dicts except for finished envs (all SB3 itself reads); "full": the reference's info dict."""
         n = self.num_envs
         if self.info_mode == "full":
             ih = info.cpu().numpy().astype(np.float64)
@@ -221,6 +224,16 @@ class TensegrityVecEnv:
                     infos[i]["waypt"] = ih[i, 10:12].copy(); infos[i]["oripoint"] = ih[i, 12:14].copy()
                     infos[i]["tendon_length"] = ih[i, N.INFO_TENDON_LENGTH:N.INFO_TENDON_LENGTH + 9].copy()
                 infos[i]["total_bar_contact"] = float(ih[i, N.INFO_BAR_CONTACT])  # what run.py:149-155 computes from data.contact
+            if tr:  # tr_env.py:507: the noise-free observation of this step (of the last step for an env that just finished)
+                if self.real_obs is not None:
+                    rh = self.real_obs.cpu().numpy().astype(np.float64)
+                else:
+                    rh = obs_h.copy() if obs_h is not None else self.obs.cpu().numpy().astype(np.float64)
+                    fin = np.nonzero(dones)[0]
+                    if fin.size and self.cfg.auto_reset:
+                        rh[fin] = tobs.cpu().numpy().astype(np.float64)[fin]
+                for i in range(n):
+                    infos[i]["real_observation"] = rh[i]
         else:
             infos = [{} for _ in range(n)]
             ih = None
@@ -300,7 +313,8 @@ class TensegrityVecEnv:
         N.check(self.handle, self.lib.tgr_stats(self.handle, out), "tgr_stats")
         sub = max(int(out[5]), 1)
         return {"dropped_contacts": int(out[0]), "settle_kernel_resets": int(out[1]), "donor_resets": int(out[2]),
-                "newton_iters_per_substep": int(out[3]) / sub, "linesearch_evals_per_substep": int(out[4]) / sub, "unconverged_lane_substeps": int(out[6])}
+                "newton_iters_per_substep": int(out[3]) / sub, "linesearch_evals_per_substep": int(out[4]) / sub, "unconverged_lane_substeps": int(out[6]),
+                "lane_substeps": int(out[7])}
 
     def synchronize(self):
         self.lib.tgr_synchronize(self.handle)

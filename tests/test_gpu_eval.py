@@ -23,7 +23,10 @@ def test_tracking_policy_rollout_and_logs(golden_dir, tmp_path):
     assert logs["actions"].shape == (T, n, 6) and logs["tendon_length"].shape == (T, n, 9) and logs["waypt"].shape == (T, n, 2)
     assert logs["actions"].min() >= -0.45 - 1e-6 and logs["actions"].max() <= 0.15 + 1e-6
     # info["tendon_length"] is what the observation carries when use_obs_noise is off (tr_env.py:506,575)
-    assert np.abs(logs["tendon_length"] - logs["observed_tendon_length"]).max() < 1e-5
+    assert np.abs(logs["tendon_length"] - logs["observed_tendon_slice"]).max() < 1e-5
+    # run.py:144 logs obs[-9:] as "observed tendon length" whatever the layout: for the 48-dim observation that is tendons 3..8 and
+    # the tracking tail, reproduced verbatim
+    assert np.abs(logs["observed_tendon_length"][:, :, :6] - logs["tendon_length"][:, :, 3:]).max() < 1e-5
     assert (logs["total_bar_contact"] >= 0).all() and np.isfinite(logs["total_bar_contact"]).all()
     # behaviour: is_test puts the waypoint 3 m straight ahead (tr_env.py:833-838); the MuJoCo-trained policy closes in on it
     xy = np.stack([logs["x_pos"], logs["y_pos"]], axis=-1)
@@ -49,7 +52,8 @@ def test_gym_env_info_carries_reference_keys():
     obs, _ = env.reset()
     obs, r, term, trunc, info = env.step(np.full(6, -0.1, dtype=np.float32))
     for k in ("reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi", "distance_from_origin",
-              "x_velocity", "y_velocity", "tendon_length", "forward_reward", "waypt", "oripoint"):  # tr_env.py:496-511
+              "x_velocity", "y_velocity", "tendon_length", "forward_reward", "waypt", "oripoint", "real_observation"):  # tr_env.py:496-511
         assert k in info, k
+    assert np.array_equal(info["real_observation"], obs)  # no observation noise: the same vector (tr_env.py:484-507)
     assert info["tendon_length"].shape == (9,) and np.allclose(info["tendon_length"], obs[36:45], atol=1e-5)
     env.close()

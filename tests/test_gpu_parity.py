@@ -26,9 +26,7 @@ def _run(oracle, kind, action, prec, n, steps, seed=0, **kw):
     rng = np.random.default_rng(seed)
     rows = []
     for t in range(steps):
-        oracle_to_gpu_state(ob, env)
-        if action == "turn":  # heading ring is part of the state in turn mode: replay it through aux-free path = same pushes
-            pass
+        oracle_to_gpu_state(ob, env)  # includes the heading deque (turn / aiming rewards read it)
         a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
         if t % 3 == 1:
             a[: n // 4] *= 1.4  # outside ctrlrange: exercises the clamp
@@ -48,8 +46,6 @@ def _run(oracle, kind, action, prec, n, steps, seed=0, **kw):
 
 @pytest.mark.parametrize("kind,action", CASES)
 def test_fp64_matches_oracle(oracle, kind, action):
-    if action in ("turn", "aiming"):
-        pytest.skip("reward needs the heading ring, which set_state does not carry; covered by test_gpu_reset_vecenv")
     rows, stats = _run(oracle, kind, action, "f64", 64, 6)
     for r in rows:
         assert r["qpos"].max() < 1e-7, r["qpos"].max()
@@ -82,39 +78,70 @@ def test_fp32_within_stated_tolerance(oracle, kind, action):
         assert np.mean(r["term"]) < 0.02
 
 
-def test_reward_obs_epilogue_against_reference_fixture(oracle, golden_dir):
-    """fp64 HIP epilogue on the states recorded from the reference classes (tests/golden, oracle/gen_golden.py):
-    set_state(golden state k-1) ; step(golden action k) -> golden obs / reward / terminated / info of step k."""
+FIXTURES = ["tensegrity_env_straight_d1.npz", "tensegrity_env_straight_d-1_terminate_when_unhealthy-0.npz", "tensegrity_env_turn_d1.npz",
+            "tensegrity_env_straight_d1_use_contact_forces-1.npz", "tr_env_straight_d1.npz", "tr_env_turn_d-1.npz",
+            "tr_env_straight_d1_use_cap_velocity-0.npz", "tr_env_tracking_d1.npz", "tr_env_aiming_d1.npz", "tr_env_vel_track_d1.npz",
+            "uneven_tensegrity_env_straight_d1.npz", "uneven_tr_env_tracking_d1.npz",
+            "tensegrity_env_straight_d1_reset_noise_scale-0.05.npz", "tr_env_straight_d1_reset_noise_scale-0.05.npz"]
+
+
+def test_every_recorded_fixture_is_replayed(golden_dir):
+    import glob, os
+    have = sorted(os.path.basename(f) for f in glob.glob(os.path.join(golden_dir, "*_d*.npz")))
+    assert have == sorted(FIXTURES)
+
+
+@pytest.mark.parametrize("fname", FIXTURES)
+def test_reward_obs_epilogue_against_reference_fixture(oracle, golden_dir, fname):
+    """fp64 HIP epilogue on the states recorded from the reference classes (tests/golden, oracle/gen_golden.py), every fixture:
+    set_state(golden state k-1, incl. the heading deque and tr_env's _step_num) ; step(golden action k) -> golden obs / reward /
+    terminated / info of step k, and the deque the reference holds afterwards (tensegrity_env.py:326-345, tr_env.py:376-378,425-446)."""
     import os
+    from gpu_common import AUX, AUX_K
     from tensegrity_rl_amd import TensegrityVecEnv
-    for fname, kind in (("tensegrity_env_straight_d1.npz", "tensegrity_env"), ("tr_env_straight_d1.npz", "tr_env"),
-                        ("tr_env_straight_d1_use_cap_velocity-0.npz", "tr_env"), ("uneven_tensegrity_env_straight_d1.npz", "tensegrity_env"),
-                        ("uneven_tr_env_tracking_d1.npz", "tr_env")):
-        g = np.load(os.path.join(golden_dir, fname))
-        kw = {k: int(v) for k, v in zip(g["kwargs_keys"], g["kwargs_vals"])}
-        if int(g["model_kind"]) == 1:
-            kw.update(model="uneven", terrain=np.load(os.path.join(golden_dir, "terrain_100.npy")))
-        T = int(g["steps_per_episode"])
-        env = TensegrityVecEnv(1, kind + "-v0", desired_action=str(g["action"]), precision="f64", auto_reset=False, **kw)
-        k = 0
-        for ep in range(len(g["reset_theta"])):
-            qpos, qvel, ctrl = g["reset_qpos"][ep], g["reset_qvel"][ep], g["reset_ctrl"][ep]
-            xy = g["reset_xy_lag"][ep]
-            act = g["reset_act"][ep]
-            for t in range(T):
-                A = np.zeros((1, 23)); A[0, 0], A[0, 1], A[0, 3] = xy[0], xy[1], g["reset_reset_psi"][ep]
-                A[0, 9:11] = g["reset_waypt"][ep]; A[0, 11:13] = g["reset_oripoint"][ep]; A[0, 17:23] = act
-                env.set_state(qpos[None], qvel[None], ctrl[None], None, A)
-                obs, rew, term, trunc, _, info = [x.cpu().numpy() for x in env.step_tensors(g["actions"][k][None])]
-                np.testing.assert_allclose(obs[0], g["obs"][k], atol=2e-6, err_msg=f"{fname} step {k}")
-                assert abs(rew[0] - g["reward"][k]) < 1e-6 and bool(term[0]) == bool(g["terminated"][k])
-                for j, name in enumerate(["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
-                                          "distance_from_origin", "x_velocity", "y_velocity", "forward_reward"]):
-                    assert abs(info[0, j] - g[name][k]) < 2e-6, (fname, k, name)
-                qpos, qvel, ctrl, act = g["qpos"][k], g["qvel"][k], g["ctrl"][k], g["act"][k]
-                xy = np.array([g["x_position"][k], g["y_position"][k]])
-                k += 1
-        env.close()
+    g = np.load(os.path.join(golden_dir, fname))
+    kind = str(g["kind"])
+    kw = {k: (float(v) if k == "reset_noise_scale" else int(v)) for k, v in zip(g["kwargs_keys"], g["kwargs_vals"])}
+    if int(g["model_kind"]) == 1:
+        kw.update(model="uneven", terrain=np.load(os.path.join(golden_dir, "terrain_100.npy")))
+    T = int(g["steps_per_episode"])
+    action = str(g["action"])
+    env = TensegrityVecEnv(1, kind + "-v0", desired_action=action, desired_direction=float(g["direction"]), precision="f64",
+                           auto_reset=False, **kw)
+    k = 0
+    for ep in range(len(g["reset_theta"])):
+        qpos, qvel, ctrl = g["reset_qpos"][ep], g["reset_qvel"][ep], g["reset_ctrl"][ep]
+        xy = g["reset_xy_lag"][ep]
+        act = g["reset_act"][ep]
+        ring, ring_len, step_num = g["reset_ring"][ep], int(g["reset_ring_len"][ep]), int(g["reset_step_num"][ep])
+        rpsi = float(g["reset_reset_psi"][ep])
+        psi_lag = rpsi  # vel_track's psi_before of the first step: the heading reset_model() ended on
+        for t in range(T):
+            A = np.zeros((1, AUX_K)); A[0, AUX["xy_lag_x"]], A[0, AUX["xy_lag_y"]], A[0, AUX["reset_psi"]] = xy[0], xy[1], rpsi
+            A[0, AUX["psi_lag"]] = psi_lag; A[0, AUX["step_num"]] = step_num; A[0, AUX["elapsed"]] = t
+            A[0, AUX["waypt_x"]:AUX["waypt_x"] + 2] = g["reset_waypt"][ep]; A[0, AUX["ori_x"]:AUX["ori_x"] + 2] = g["reset_oripoint"][ep]
+            A[0, AUX["vcmd_x"]], A[0, AUX["vcmd_y"]] = 0.5 * np.cos(rpsi), 0.5 * np.sin(rpsi)  # tr_env.py:858-861
+            A[0, AUX["act"]:AUX["act"] + 6] = act
+            A[0, AUX["ring_len"]] = ring_len; A[0, AUX["ring"]:AUX["ring"] + 32] = ring
+            env.set_state(qpos[None], qvel[None], ctrl[None], None, A)
+            obs, rew, term, trunc, _, info = [x.cpu().numpy() for x in env.step_tensors(g["actions"][k][None])]
+            np.testing.assert_allclose(obs[0], g["obs"][k], atol=2e-6, err_msg=f"{fname} step {k}")
+            assert abs(rew[0] - g["reward"][k]) < 1e-6, (fname, k, rew[0], g["reward"][k])
+            assert bool(term[0]) == bool(g["terminated"][k]), (fname, k)
+            for j, name in enumerate(["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
+                                      "distance_from_origin", "x_velocity", "y_velocity", "forward_reward"]):
+                assert abs(info[0, j] - g[name][k]) < 2e-6, (fname, k, name)
+            aux = env.get_state()["aux"][0]
+            assert int(aux[AUX["ring_len"]]) == int(g["ring_len"][k]), (fname, k)
+            np.testing.assert_allclose(aux[AUX["ring"]:AUX["ring"] + int(g["ring_len"][k])], g["ring"][k][:int(g["ring_len"][k])], atol=2e-6)
+            if kind == "tr_env":
+                assert int(aux[AUX["step_num"]]) == int(g["step_num"][k])
+            qpos, qvel, ctrl, act = g["qpos"][k], g["qvel"][k], g["ctrl"][k], g["act"][k]
+            xy = np.array([g["x_position"][k], g["y_position"][k]])
+            ring, ring_len, step_num = g["ring"][k], int(g["ring_len"][k]), int(g["step_num"][k])
+            psi_lag = float(g["psi"][k]) if action != "turn" or kind == "tr_env" else psi_lag
+            k += 1
+    env.close()
 
 
 @pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f64", 1e-9)])

@@ -8,15 +8,20 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("kind,action", [("tensegrity_env", "straight"), ("tensegrity_env", "turn"), ("tr_env", "straight"), ("tr_env", "turn"),
-                                         ("tr_env", "tracking"), ("tr_env", "aiming"), ("tr_env", "vel_track")])
+                                         ("tr_env", "tracking"), ("tr_env", "aiming"), ("tr_env", "vel_track"),
+                                         ("tensegrity_env", "noise"), ("tr_env", "noise")])
 def test_reset_matches_oracle_fp64(oracle, kind, action):
-    """same philox draws -> same start pose -> 1000 sub-steps of settling agree (fp64)"""
+    """same philox draws -> same start pose -> 1000 sub-steps of settling agree (fp64).  "noise": reset_noise_scale = 0.05
+    (tensegrity_env.py:436-445; the oracle's handling of it is pinned by the *_reset_noise_scale-0.05 fixtures)"""
     from tensegrity_rl_amd import TensegrityVecEnv
     O = oracle
     n = 32
-    env = TensegrityVecEnv(n, kind + "-v0", desired_action=action, precision="f64", auto_reset=False, seed=77, first_env_id=5)
+    kw = {}
+    if action == "noise":
+        action, kw = "straight", dict(reset_noise_scale=0.05)
+    env = TensegrityVecEnv(n, kind + "-v0", desired_action=action, precision="f64", auto_reset=False, seed=77, first_env_id=5, **kw)
     obs = env.reset()
-    ob = O.OracleBatch(O.make_cfg(kind, action), n, seed=77, first_env_id=5)
+    ob = O.OracleBatch(O.make_cfg(kind, action, **kw), n, seed=77, first_env_id=5)
     oobs = ob.reset()
     st = env.get_state()
     q, v, c, w, aux = ob.get_state()
@@ -35,7 +40,22 @@ def test_reset_matches_oracle_fp64(oracle, kind, action):
         o_obs, o_rew, o_term, _, _, _ = ob.step(a, auto_reset=False)
         g_obs, g_rew, g_term, _ = env.step(a)
         assert np.abs(g_rew - o_rew).max() < 5e-3 and np.abs(g_obs - o_obs).max() < 5e-2
+    # the heading deque reset_model() leaves behind (tensegrity_env turn: 50 pushes capped at 25; tr_env turn / aiming: the prefill)
+    st = env.get_state(); aux2 = ob.get_state()[4]
+    assert (st["aux"][:, AUX["ring_len"]] == aux2["ring_len"]).all()
+    assert np.abs(st["aux"][:, AUX["ring"]:AUX["ring"] + 32] - aux2["ring"]).max() < 5e-3
     env.close(); ob.close()
+
+
+def test_reset_with_the_same_seed_reproduces_the_episode():
+    """Env.reset(seed=s) twice -> the same episode twice (tgr_set_seed restarts the lanes' episode counters)"""
+    from tensegrity_rl_amd.envs import make
+    env = make("tr_env-v0", desired_action="tracking", precision="f64")
+    o1, _ = env.reset(seed=11); q1 = env.get_state()["qpos"].copy()
+    o2, _ = env.reset(seed=12)
+    o3, _ = env.reset(seed=11); q3 = env.get_state()["qpos"].copy()
+    assert np.array_equal(o1, o3) and np.array_equal(q1, q3) and not np.array_equal(o1, o2)
+    env.close()
 
 
 def test_reset_fp32_close_to_oracle(oracle):
@@ -189,6 +209,8 @@ def test_obs_noise_matches_oracle(oracle, action, capv):
         g_obs = env.step(a)[0]
         c_obs = clean.step(a)[0]
         np.testing.assert_allclose(g_obs, o_obs, atol=2e-6)
+        # info["real_observation"] (tr_env.py:507, read by run.py:147): the noise-free observation of the same step
+        np.testing.assert_allclose(env.real_obs.cpu().numpy(), c_obs, atol=1e-12)
         diffs.append(g_obs - c_obs)
     d = np.concatenate(diffs)
     pos, ten = d[:, :18], d[:, 18 + nv:27 + nv]
@@ -196,6 +218,10 @@ def test_obs_noise_matches_oracle(oracle, action, capv):
     if nv:
         assert abs(d[:, 18:36].std() - 0.05) < 0.006
     assert not np.allclose(diffs[0], diffs[1])  # fresh draws every observation
+    env.info_mode = "full"
+    o, r, dn, infos = env.step(a)
+    assert np.abs(infos[3]["real_observation"] - o[3]).max() > 1e-3 and infos[3]["real_observation"].shape == o[3].shape
+    assert clean.real_obs is None  # nothing is bound (or written) without observation noise
     env.close(); clean.close(); ob.close()
 
 

@@ -24,6 +24,14 @@ def qpos_close(a, b, atol):
     np.testing.assert_allclose(a, b, rtol=0, atol=atol)
 
 
+def ring_close(O, env, ring, ring_len):
+    """self._heading_buffer of the reference (a deque that is never cleared: tensegrity_env.py:243) against the restatement's ring"""
+    e = env.e
+    assert e.ring_len == ring_len
+    mine = [O.arr(e.ring)[(e.ring_head + j) % O.RING] for j in range(e.ring_len)]
+    np.testing.assert_allclose(mine, ring[:ring_len], rtol=0, atol=1e-8)
+
+
 def load_cases(golden_dir):
     return sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "helpers" not in f and "obs_noise" not in f and not os.path.basename(f).startswith("policy_"))
 
@@ -39,10 +47,10 @@ def cfg_from_fixture(O, g):
 
 
 def test_fixtures_present(golden_dir):
-    assert len(load_cases(golden_dir)) == 12
+    assert len(load_cases(golden_dir)) == 14
 
 
-@pytest.mark.parametrize("idx", range(12))
+@pytest.mark.parametrize("idx", range(14))
 def test_oracle_env_matches_reference_classes(oracle, golden_dir, idx):
     O = oracle
     path = load_cases(golden_dir)[idx]
@@ -51,11 +59,18 @@ def test_oracle_env_matches_reference_classes(oracle, golden_dir, idx):
     T = int(g["steps_per_episode"])
     k = 0
     for ep in range(len(g["reset_theta"])):
-        obs0 = env.reset(int(g["reset_pose"][ep]), float(g["reset_theta"][ep]), g["reset_tendons"][ep], g["reset_u_way"][ep])
+        if "reset_noise_scale" in list(g["kwargs_keys"]):  # tensegrity_env.py:436-445: the reference's own np_random draws, replayed
+            assert np.abs(g["reset_dq"][ep]).max() > 1e-3 and np.abs(g["reset_dv"][ep]).max() > 1e-3
+            obs0 = env.reset_noise(int(g["reset_pose"][ep]), float(g["reset_theta"][ep]), g["reset_tendons"][ep], g["reset_dq"][ep],
+                                   g["reset_dv"][ep], g["reset_u_way"][ep])
+        else:
+            obs0 = env.reset(int(g["reset_pose"][ep]), float(g["reset_theta"][ep]), g["reset_tendons"][ep], g["reset_u_way"][ep])
         qpos_close(O.arr(env.data.qpos), g["reset_qpos"][ep], 1e-9)
         np.testing.assert_allclose(O.arr(env.data.qvel), g["reset_qvel"][ep], rtol=0, atol=1e-8)
         assert abs(env.e.reset_psi - g["reset_reset_psi"][ep]) < 1e-9
         np.testing.assert_allclose(obs0, g["reset_obs"][ep], rtol=0, atol=1e-8)
+        ring_close(O, env, g["reset_ring"][ep], int(g["reset_ring_len"][ep]))
+        assert env.e.step_num == int(g["reset_step_num"][ep])
         for t in range(T):
             obs, r, term, trunc, info = env.step(g["actions"][k])
             qpos_close(O.arr(env.data.qpos), g["qpos"][k], 1e-8)
@@ -64,6 +79,8 @@ def test_oracle_env_matches_reference_classes(oracle, golden_dir, idx):
             assert term == bool(g["terminated"][k])
             for name in INFO:
                 assert abs(info[name] - g[name][k]) < 1e-7, (path, k, name)
+            ring_close(O, env, g["ring"][k], int(g["ring_len"][k]))
+            assert env.e.step_num == int(g["step_num"][k])
             k += 1
 
 

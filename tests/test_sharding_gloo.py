@@ -94,3 +94,25 @@ def test_rollout_allgather_world2_matches_single_rank(tmp_path):
         assert torch.equal(got["rew"][t], ids + 0.5 * t)
         done = ((torch.arange(n_total) % 3 == t % 3) | (torch.arange(n_total) % 5 == 0)).to(torch.uint8)
         assert torch.equal(got["done"][t], done)
+
+
+def _worker_ragged(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(rank, world, 11)  # 6 + 5: not a valid layout for the all-gather
+    try:
+        RolloutGatherer(hi - lo, 3, 2, torch.device("cpu"))
+        msg = "no error"
+    except ValueError as e:
+        msg = str(e)
+    if rank == 0:
+        torch.save({"msg": msg}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_ragged_shards_are_refused_on_every_rank_instead_of_hanging(tmp_path):
+    out = str(tmp_path / "r.pt")
+    mp.spawn(_worker_ragged, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert "equal size" in torch.load(out, weights_only=True)["msg"]
