@@ -10,6 +10,7 @@ i32, f64, u64 = C.c_int32, C.c_double, C.c_uint64
 ENV_TENSEGRITY, ENV_TR = 0, 1
 ACTIONS = {"straight": 0, "turn": 1, "aiming": 2, "tracking": 3, "vel_track": 4}
 PRECISION = {"f32": 0, "f64": 1, "float32": 0, "float64": 1}
+KERNEL_LAYOUT = {"auto": 0, "block": 1, "row": 2}
 INFO_K, AUX_K, NQ, NV, NU = 26, 55, 21, 18, 6
 AUX_RING, RING_CAPACITY = 23, 32
 INFO_TENDON_LENGTH, INFO_BAR_CONTACT = 16, 25
@@ -36,7 +37,7 @@ class Config(C.Structure):
         ("waypt_reward_amplitude", f64), ("waypt_reward_stdev", f64), ("yaw_reward_weight", f64), ("solver_warm_start", i32),
         ("use_obs_noise", i32), ("obs_noise_tendon_stdev", f64), ("obs_noise_cap_pos_stdev", f64),
         ("model_kind", i32), ("site_offset", f64), ("act_tau", f64), ("hf_size", f64 * 4), ("hf_pos", f64 * 3),
-        ("reset_noise_scale", f64),
+        ("reset_noise_scale", f64), ("kernel_layout", i32),
     ]
 
 

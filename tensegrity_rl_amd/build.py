@@ -10,7 +10,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "tgr_sim.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "tgr_device.h"), os.path.join(os.path.dirname(HERE), "include", "tensegrity.h")]
+DEPS = [SRC, os.path.join(HERE, "csrc", "tgr_device.h"), os.path.join(HERE, "csrc", "tgr_row.h"), os.path.join(HERE, "csrc", "tgr_spmd.h"),
+        os.path.join(os.path.dirname(HERE), "include", "tensegrity.h")]
 LIB = os.path.join(HERE, "libtensegrity.so")
 STAMP = LIB + ".srchash"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]

@@ -1,0 +1,875 @@
+// tgr_row.h -- one physics sub-step of the 3-bar tensegrity robot in the "one environment = one DPP row" layout
+// (tgr_spmd.h): 16 lanes per environment, 4 environments per wavefront, no LDS and no barriers inside the sub-step.
+//
+// What it computes is what the reference gets from mujoco==2.3.7 mj_step for 3prism_jonathan_steady_side.xml (call sites
+// tensegrity_env.py:297, tr_env.py:346,812): tendon/actuator forces, soft contacts with elliptic cones solved by Newton's
+// method, implicitfast integration -- the same convex problem and the same formulation (world-frame twists, frame-free contact
+// rows, "isotropic + rank-1" cone Hessian) as the block kernels of tgr_device.h, which remain the cross-check.  What differs is
+// the mapping onto the machine:
+//   replicated in the row : rigid-body state, Newton iterate a (18), unconstrained acceleration a0, gradient, step p, all scalars
+//   tendon role  (lane t < 9)  : geometry, force and Jacobian of tendon t; row t of the 9x9 implicitfast (Woodbury) system
+//   slot role    (lane c < 12) : contact slot c -- cap c on the floor (c < 6) or sub-slot (c-6)&1 of bar pair (c-6)>>1:
+//                                 detection, cone evaluation, line-search coefficients
+//   dof role     (lane i < 6)  : row i of every 6x6 block of the 18x18 Newton Hessian; block Cholesky with row_newbcast
+// A wavefront iterates until its four environments have converged (the block kernels wait for 64).
+#pragma once
+#include "tgr_spmd.h"
+
+namespace tgr {
+namespace row {
+
+template <typename S> struct RParams {
+  S h, grav, mass, Ixx, Izz;
+  S cap_r, bar_half, rcyl_r, bcyl_r, bcyl_lo, bcyl_hi, site_off, site_z;
+  S ten_k[9], ten_b[9], ten_L0[9];
+  S gain, bias0, bias1, bias2, force_lo, force_hi, ctrl_lo, ctrl_hi;
+  S K, B;
+  S imp0, imp1, imp_width, imp_mid;
+  S f0, f1sq, f3sq, f4sq, impratio;
+  S invweight;
+  S tol, ls_tol;
+  S cf_lo, cf_hi;
+  int max_iter, ls_iter, skip_clamped;
+  S act_itau;
+  S hf_rx, hf_ry, hf_ez, hf_x0, hf_y0, hf_z0, hf_dx, hf_dy;
+  int hf_nrow, hf_ncol;
+  const float* hf;
+};
+
+// static model tables (3prism_jonathan_steady_side.xml:82-87,127-164; ..._uneven_ground.xml:76-81,122-158)
+struct RTab {
+  static constexpr int S0[6][3] = {{-1, 0, 1}, {0, 1, 1}, {1, 0, 1}, {0, 1, -1}, {1, 0, -1}, {0, -1, -1}};
+  static constexpr int S1[6][3] = {{-1, 0, 1}, {1, 0, 1}, {0, -1, 1}, {0, -1, -1}, {0, 1, -1}, {1, 0, -1}};
+  static constexpr int TEN0[9][4] = {{0, 1, 2, 0}, {0, 0, 1, 1}, {1, 0, 2, 1}, {0, 5, 2, 4}, {0, 4, 1, 5}, {1, 4, 2, 5}, {0, 3, 2, 2}, {0, 2, 1, 3}, {1, 2, 2, 3}};
+  static constexpr int TEN1[9][4] = {{0, 0, 2, 1}, {0, 2, 1, 1}, {1, 0, 2, 2}, {0, 5, 2, 3}, {0, 4, 1, 3}, {1, 5, 2, 4}, {0, 3, 2, 0}, {0, 1, 1, 4}, {1, 2, 2, 5}};
+};
+constexpr int ten_ba(int t) { return RTab::TEN0[t][0]; }  // the bars of a tendon are the same in both models
+constexpr int ten_bb(int t) { return RTab::TEN0[t][2]; }
+constexpr int pair_a(int p) { return p == 2 ? 1 : 0; }    // bar pairs (A,B): (0,1), (0,2), (1,2)
+constexpr int pair_b(int p) { return p == 0 ? 1 : 2; }
+// contact slot c of page 0: 0..5 cap c on the floor, 6..11 sub-slot (c-6)&1 of pair (c-6)>>1, MODEL 1: 12..14 rod of bar c-12 on the
+// terrain; page 1 (MODEL 1 only): 0..5 second terrain contact of cap c
+constexpr int slot_bar_a(int page, int c) { return (page == 0 && c >= 6 && c < 12) ? pair_a((c - 6) >> 1) : -1; }
+constexpr int slot_bar_b(int page, int c) { return c < 6 ? (c >> 1) : (c < 12 ? (page == 0 ? pair_b((c - 6) >> 1) : -1) : (page == 0 && c < 15 ? c - 12 : -1)); }
+template <int MODEL> constexpr int n_pages() { return MODEL ? 2 : 1; }
+template <int MODEL> constexpr int n_slots(int page) { return MODEL ? (page == 0 ? 15 : 6) : 12; }
+
+// ------------------------------------------------------------------ replicated state of one environment
+// K: the lane type of pose, kinematics, tendon geometry and smooth forces (double in the mixed-precision production kernels: a tendon
+// length must be good to ~1e-9 m for the stated 1e-4 relative bound on velocities of a few cm/s); F: everything else
+template <typename K, typename F> struct RSim {
+  V3<K> x[3];   // bar COM
+  K q[3][4];    // orientation (w,x,y,z)
+  V3<F> v[3];   // linear velocity (world)
+  V3<F> w[3];   // angular velocity (world frame; qvel stores the body frame)
+  V3<F> al[3];  // Newton iterate / warm start, linear
+  V3<F> aa[3];  // ... angular (world frame)
+  F ctrl[6];
+  F act[6];     // MODEL 1: actuator activations
+};
+// what the reference reads after mj_step: quantities of the forward pass of the LAST sub-step (one sub-step old)
+template <typename K, typename F> struct RLag {
+  V3<K> x[3], z[3];
+  K q[3][4];
+  F tenL[9];
+  F cfrc_absmax, cfrc_clip_sq, bar_contact;
+  F overflow;   // dropped bar-bar contacts in the last sub-step (a count, kept as a real)
+  F n_unconv;   // sub-steps this environment left the solver at the iteration cap
+  int n_it, n_ls;
+};
+template <typename F> struct Rot { V3<F> ex, ey, ez; };
+
+template <typename F> TGR_RDEV void normalize_quat(F* q) {
+  F s = rsqrt_(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] = q[0] * s; q[1] = q[1] * s; q[2] = q[2] * s; q[3] = q[3] * s;
+}
+template <typename F> TGR_RDEV Rot<F> quat_rot(const F* q) {
+  typedef typename LaneTraits<F>::S S;
+  F q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+  F q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
+  F q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+  Rot<F> R;
+  R.ex = mk<F>(q00 + q11 - q22 - q33, S(2) * (q12 + q03), S(2) * (q13 - q02));
+  R.ey = mk<F>(S(2) * (q12 - q03), q00 - q11 + q22 - q33, S(2) * (q23 + q01));
+  R.ez = mk<F>(S(2) * (q13 + q02), S(2) * (q23 - q01), q00 - q11 - q22 + q33);
+  return R;
+}
+template <typename F> TGR_RDEV V3<F> rot_apply(const Rot<F>& R, V3<F> l) { return l.x * R.ex + (l.y * R.ey + l.z * R.ez); }
+template <typename F> TGR_RDEV V3<F> rot_applyT(const Rot<F>& R, V3<F> g) { return mk<F>(dot(R.ex, g), dot(R.ey, g), dot(R.ez, g)); }
+template <typename F, typename S> TGR_RDEV V3<F> inv_inertia(const RParams<S>& P, V3<F> z, V3<F> t) {
+  const S iI = S(1) / P.Ixx, d = S(1) / P.Izz - iI;
+  return iI * t + (d * dot(z, t)) * z;
+}
+template <typename F, typename S> TGR_RDEV V3<F> inertia_mul(const RParams<S>& P, V3<F> z, V3<F> a) {
+  return P.Ixx * a + ((P.Izz - P.Ixx) * dot(z, a)) * z;
+}
+// lane-dependent choice among the three bars' replicated vectors
+template <typename F, typename I> TGR_RDEV V3<F> pick_bar(I b, const V3<F>* a) { return sel3(b == 0, a[0], sel3(b == 1, a[1], a[2])); }
+template <typename F, typename I> TGR_RDEV V3<F> pick_bar0(I b, const V3<F>* a) {  // b < 0: the world (zero)
+  typedef typename LaneTraits<F>::S S;
+  const V3<F> z = mk<F>(F(S(0)), F(S(0)), F(S(0)));
+  return sel3(b == 0, a[0], sel3(b == 1, a[1], sel3(b == 2, a[2], z)));
+}
+template <typename F, typename I> TGR_RDEV F pick_comp(I k, V3<F> a) { return sel(k == 0, a.x, sel(k == 1, a.y, a.z)); }
+
+// ------------------------------------------------------------------ per-lane role constants (set up once per kernel)
+template <typename K, typename F> struct Roles {
+  typedef typename LaneTraits<F>::I I;
+  typedef typename LaneTraits<F>::B B;
+  I r;
+  // tendon role
+  B is_ten; I ba, bb; V3<K> sa, sb; K tk, tb, tL0; B actuated;
+  // slot role (page 0)
+  B is_cap, is_pair, is_rod; I sub; I sA, sB; F cap_sign;
+  // dof role
+  B is_dof, is_ang; I k;
+};
+template <typename K, typename F, typename SK, int MODEL> TGR_RDEV Roles<K, F> make_roles(const RParams<SK>& P) {
+  typedef typename LaneTraits<F>::I I;
+  typedef typename LaneTraits<F>::S S;
+  typedef SK SKK;
+  Roles<K, F> R;
+  const I r = lane_id();
+  R.r = r;
+  R.is_ten = r < 9;
+  I ba = I(0), bb = I(0), sia = I(0), sib = I(0);
+  K tk = K(SKK(0)), tb = K(SKK(0)), tL0 = K(SKK(0));
+  static_for<9>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    const auto m = r == t;
+    ba = sel(m, I(RTab::TEN0[t][0]), ba); bb = sel(m, I(RTab::TEN0[t][2]), bb);
+    sia = sel(m, I(MODEL ? RTab::TEN1[t][1] : RTab::TEN0[t][1]), sia); sib = sel(m, I(MODEL ? RTab::TEN1[t][3] : RTab::TEN0[t][3]), sib);
+    tk = sel(m, K(P.ten_k[t]), tk); tb = sel(m, K(P.ten_b[t]), tb); tL0 = sel(m, K(P.ten_L0[t]), tL0);
+  });
+  R.ba = ba; R.bb = bb; R.tk = tk; R.tb = tb; R.tL0 = tL0;
+  R.actuated = r < 6;
+  V3<K> sa = mk<K>(K(SKK(0)), K(SKK(0)), K(SKK(0))), sb = sa;
+  static_for<6>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    const V3<K> loc = MODEL ? mk<K>(K(SKK(RTab::S1[s][0]) * P.site_off), K(SKK(RTab::S1[s][1]) * P.site_off), K(SKK(RTab::S1[s][2]) * P.site_z))
+                            : mk<K>(K(SKK(RTab::S0[s][0]) * P.site_off), K(SKK(RTab::S0[s][1]) * P.site_off), K(SKK(RTab::S0[s][2]) * P.site_z));
+    sa = sel3(sia == s, loc, sa); sb = sel3(sib == s, loc, sb);
+  });
+  R.sa = sa; R.sb = sb;
+  R.is_cap = r < 6;
+  R.is_pair = (r >= 6) & (r < 12);
+  R.is_rod = MODEL ? ((r >= 12) & (r < 15)) : (r < 0);
+  const I pr = (r - 6) >> 1;
+  R.sub = (r - 6) & 1;
+  R.sA = sel(R.is_pair, sel(pr == 2, I(1), I(0)), I(-1));
+  R.sB = sel(R.is_cap, r >> 1, sel(R.is_pair, sel(pr == 0, I(1), I(2)), sel(R.is_rod, r - 12, I(-1))));
+  R.cap_sign = sel((r & 1) == 0, F(S(1)), F(S(-1)));
+  R.is_dof = r < 6;
+  R.is_ang = (r >= 3) & (r < 6);
+  R.k = sel(r < 3, r, r - 3);
+  return R;
+}
+
+// ------------------------------------------------------------------ contacts
+template <typename F> struct RContact {
+  typedef typename LaneTraits<F>::B B;
+  V3<F> n, rA, rB;  // normal A -> B, contact point relative to the COMs
+  F c0, Dn;         // K imp dist (< 0 when penetrating), 1/R of the normal row
+  B active;
+};
+template <typename F, typename S> TGR_RDEV F impedance(const RParams<S>& P, F dist) {
+  F xx = abs_(dist) * (S(1) / P.imp_width);
+  F y = sel(xx >= S(1), F(S(1)), sel(xx <= P.imp_mid, xx * xx * (S(1) / P.imp_mid), S(1) - (S(1) - xx) * (S(1) - xx) * (S(1) / (S(1) - P.imp_mid))));
+  return P.imp0 + y * (P.imp1 - P.imp0);
+}
+template <typename F, typename S> TGR_RDEV void contact_params(const RParams<S>& P, F dist, S nbody, F& c0, F& Dn) {
+  F imp = impedance(P, dist);
+  F R0 = max_((S(1) - imp) * (P.invweight * nbody) * rcp_(imp), F(S(1e-15)));
+  Dn = rcp_(R0);
+  c0 = P.K * imp * dist;
+}
+
+template <typename F> struct RCone {
+  V3<F> fl, fa;
+  F a1, a2, b1, b2, cg, cw;
+  V3<F> gl, ga, wl, wa;
+};
+// cone force and Hessian ("isotropic + rank-1" form) of one contact at jar = (jl, ja); same algebra as tgr_device.h cone_eval
+template <typename F, typename S> TGR_RDEV RCone<F> cone_eval(const RParams<S>& P, const RContact<F>& c, V3<F> jl, V3<F> ja) {
+  RCone<F> o;
+  const S mu = P.f0 / std::sqrt(P.impratio);
+  const S rf0 = S(1) / (P.f0 * P.f0);
+  F Dt = c.Dn * P.impratio;
+  F Do = Dt * (P.f3sq * rf0), Dr = Dt * (P.f4sq * rf0);
+  F jn = dot(c.n, jl);
+  V3<F> jt = jl - jn * c.n;
+  F jo = dot(c.n, ja);
+  V3<F> jr = ja - jo * c.n;
+  F tt = P.f1sq * dot(jt, jt) + P.f3sq * jo * jo + P.f4sq * dot(jr, jr);
+  F Tn = sqrt_(tt);
+  F N = mu * jn;
+  auto top = (N >= mu * Tn) | !c.active;
+  auto bottom = !top & (mu * N + Tn <= S(0));
+  auto middle = !top & !bottom;
+  V3<F> flB = -((c.Dn * jn) * c.n + Dt * jt);
+  V3<F> faB = -((Do * jo) * c.n + Dr * jr);
+  F rT = rcp_(max_(Tn, F(S(1e-30))));
+  F Dm = c.Dn * (S(1) / (mu * mu * (S(1) + mu * mu)));
+  F NT = N - mu * Tn;
+  F fn = -Dm * NT * mu;
+  V3<F> wl = P.f1sq * jt;
+  V3<F> wa = (P.f3sq * jo) * c.n + P.f4sq * jr;
+  V3<F> flM = fn * c.n - (fn * rT) * wl;
+  V3<F> faM = -(fn * rT) * wa;
+  const F zero = F(S(0));
+  const V3<F> z3 = mk<F>(zero, zero, zero);
+  o.fl = sel3(bottom, flB, sel3(middle, flM, z3));
+  o.fa = sel3(bottom, faB, sel3(middle, faM, z3));
+  F kap = -Dm * mu * NT * rT;
+  o.a1 = sel(bottom, Dt, sel(middle, kap * P.f1sq, zero));
+  o.a2 = sel(bottom, c.Dn - Dt, sel(middle, -kap * P.f1sq, zero));
+  o.b1 = sel(bottom, Dr, sel(middle, kap * P.f4sq, zero));
+  o.b2 = sel(bottom, Do - Dr, sel(middle, kap * (P.f3sq - P.f4sq), zero));
+  o.cg = sel(middle, Dm, zero);
+  o.cw = sel(middle, -kap * rT * rT, zero);
+  o.gl = mu * c.n - (mu * rT) * wl;
+  o.ga = -(mu * rT) * wa;
+  o.wl = wl;
+  o.wa = wa;
+  return o;
+}
+
+// ---- contact geometry between two bars (slot role, pair lanes); same rules as tgr_device.h bar_pair_contacts
+template <typename F> struct RCand { F dist; V3<F> n, p; typename LaneTraits<F>::B ok; };
+template <typename F, typename B> TGR_RDEV void keep_deeper(RCand<F>& best, F& count, F dist, V3<F> n, V3<F> p, B valid) {
+  typedef typename LaneTraits<F>::S S;
+  auto hit = valid & (dist < S(0));
+  count = count + sel(hit, F(S(1)), F(S(0)));
+  auto take = hit & (!best.ok | (dist < best.dist));
+  best.dist = sel(take, dist, best.dist);
+  best.n = sel3(take, n, best.n);
+  best.p = sel3(take, p, best.p);
+  best.ok = best.ok | hit;
+}
+template <typename F, typename S, typename B>
+TGR_RDEV void sphere_vs_bar(const RParams<S>& P, V3<F> c, V3<F> xo, V3<F> zo, bool flip, B enable, RCand<F>& best, F& count) {
+  V3<F> wv = c - xo;
+  F t = dot(wv, zo);
+  V3<F> rad = wv - t * zo;
+  F rho = sqrt_(dot(rad, rad));
+  F irho = rcp_(max_(rho, F(S(1e-30))));
+  for (int k = 0; k < 3; k++) {
+    const S cen = k == 0 ? S(0) : (k == 1 ? S(0.5) * (P.bcyl_hi + P.bcyl_lo) : -S(0.5) * (P.bcyl_hi + P.bcyl_lo));
+    const S hh = k == 0 ? P.bar_half : S(0.5) * (P.bcyl_hi - P.bcyl_lo);
+    const S rc = k == 0 ? P.rcyl_r : P.bcyl_r;
+    F tl = t - cen;
+    F tc = clamp_(tl, F(-hh), F(hh));
+    F rr = min_(rho, F(rc));
+    auto inside = (abs_(tl) <= hh) & (rho <= rc);
+    V3<F> q = xo + (cen + tc) * zo + (rr * irho) * rad;
+    V3<F> dif = q - c;
+    F dd = sqrt_(dot(dif, dif));
+    F idd = rcp_(max_(dd, F(S(1e-30))));
+    F dist = sel(inside, rho - rc - P.cap_r, dd - P.cap_r);
+    V3<F> n = sel3(inside, -irho * rad, idd * dif);
+    V3<F> pos = c + (P.cap_r + S(0.5) * dist) * n;
+    auto valid = enable & sel(inside, rho > S(1e-12), dd > S(1e-12));
+    V3<F> nn = flip ? -n : n;
+    keep_deeper(best, count, dist, nn, pos, valid);
+  }
+}
+// c0: r-cylinder against r-cylinder (side-side); c1: the deepest of everything else; dropped: further hits that found no slot
+template <typename F, typename S>
+TGR_RDEV void bar_pair_contacts(const RParams<S>& P, V3<F> xA, V3<F> zA, V3<F> xB, V3<F> zB, typename LaneTraits<F>::B lanes,
+                                RContact<F>& c0, RContact<F>& c1, F& dropped) {
+  typedef typename LaneTraits<F>::B B;
+  const F zero = F(S(0));
+  c0.active = B(false); c1.active = B(false);
+  c0.n = mk<F>(zero, zero, F(S(1))); c1.n = c0.n;
+  c0.rA = mk<F>(zero, zero, zero); c0.rB = c0.rA; c1.rA = c0.rA; c1.rB = c0.rA;
+  c0.c0 = zero; c1.c0 = zero; c0.Dn = zero; c1.Dn = zero;
+  dropped = zero;
+  V3<F> wv = xA - xB;
+  F b = dot(zA, zB), dA = dot(zA, wv), dB = dot(zB, wv);
+  F den = S(1) - b * b;
+  auto skew = den > S(1e-6);
+  F iden = rcp_(sel(skew, den, F(S(1))));
+  F s = (b * dB - dA) * iden, t = (dB - b * dA) * iden;
+  V3<F> pa = xA + s * zA, pb = xB + t * zB;
+  V3<F> dif = pb - pa;
+  F dd = sqrt_(dot(dif, dif));
+  F idd = rcp_(max_(dd, F(S(1e-30))));
+  V3<F> n = idd * dif;
+  auto okdir = skew & (dd > S(1e-9));
+  B near_;
+  {
+    F sc = clamp_(sel(skew, s, zero), F(-P.bar_half), F(P.bar_half));
+    F tc = clamp_(dB + b * sc, F(-P.bar_half), F(P.bar_half));
+    sc = clamp_(b * tc - dA, F(-P.bar_half), F(P.bar_half));
+    V3<F> dv = (xB + tc * zB) - (xA + sc * zA);
+    const S reach = S(2) * P.cap_r + S(1e-6);
+    near_ = lanes & (dot(dv, dv) <= reach * reach);
+  }
+  if (!any_lane(near_)) return;
+  {
+    auto interior = near_ & okdir & (abs_(s) < P.bar_half) & (abs_(t) < P.bar_half);
+    F dist = dd - S(2) * P.rcyl_r;
+    auto hit = interior & (dist < S(0));
+    c0.active = hit;
+    c0.n = sel3(hit, n, c0.n);
+    V3<F> pos = pa + (P.rcyl_r + S(0.5) * dist) * n;
+    c0.rA = sel3(hit, pos - xA, c0.rA); c0.rB = sel3(hit, pos - xB, c0.rB);
+    F cc, dn;
+    contact_params(P, sel(hit, dist, zero), S(2), cc, dn);
+    c0.c0 = sel(hit, cc, zero); c0.Dn = sel(hit, dn, zero);
+  }
+  auto deep = near_ & okdir & (dd - S(2) * P.rcyl_r < -(P.rcyl_r - P.bcyl_r));
+  B ends = B(false);
+  {
+    const S reach2 = (S(2) * P.cap_r + S(1e-6)) * (S(2) * P.cap_r + S(1e-6));
+    for (int e = 0; e < 2; e++) {
+      const S sg = e == 0 ? P.bar_half : -P.bar_half;
+      V3<F> ea = (xA + sg * zA) - xB;
+      F ta = clamp_(dot(ea, zB), F(-P.bar_half), F(P.bar_half));
+      V3<F> da = ea - ta * zB;
+      V3<F> eb = (xB + sg * zB) - xA;
+      F tb = clamp_(dot(eb, zA), F(-P.bar_half), F(P.bar_half));
+      V3<F> db = eb - tb * zA;
+      ends = ends | (dot(da, da) <= reach2) | (dot(db, db) <= reach2);
+    }
+    ends = ends & near_;
+  }
+  if (!any_lane(deep | ends)) return;
+  RCand<F> best; best.ok = B(false); best.dist = zero; best.n = c0.n; best.p = xA;
+  F count = zero;
+  const S bc = S(0.5) * (P.bcyl_hi + P.bcyl_lo), bh = S(0.5) * (P.bcyl_hi - P.bcyl_lo);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      if (i == 0 && j == 0) continue;
+      const S ci = i == 0 ? S(0) : (i == 1 ? bc : -bc), hi_ = i == 0 ? P.bar_half : bh, ri = i == 0 ? P.rcyl_r : P.bcyl_r;
+      const S cj = j == 0 ? S(0) : (j == 1 ? bc : -bc), hj_ = j == 0 ? P.bar_half : bh, rj = j == 0 ? P.rcyl_r : P.bcyl_r;
+      auto interior = near_ & okdir & (abs_(s - ci) < hi_) & (abs_(t - cj) < hj_);
+      F dist = dd - (ri + rj);
+      V3<F> pos = pa + (ri + S(0.5) * dist) * n;
+      keep_deeper(best, count, dist, n, pos, interior);
+    }
+  for (int ea = 0; ea < 2; ea++) {
+    V3<F> ca = xA + (ea == 0 ? P.bar_half : -P.bar_half) * zA;
+    sphere_vs_bar(P, ca, xB, zB, false, near_, best, count);
+    for (int eb = 0; eb < 2; eb++) {
+      V3<F> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
+      V3<F> dv = cb - ca;
+      F cd = sqrt_(dot(dv, dv));
+      F dist = cd - S(2) * P.cap_r;
+      V3<F> nn = rcp_(max_(cd, F(S(1e-30)))) * dv;
+      V3<F> pos = ca + (P.cap_r + S(0.5) * dist) * nn;
+      keep_deeper(best, count, dist, nn, pos, near_ & (cd > S(1e-12)));
+    }
+  }
+  for (int eb = 0; eb < 2; eb++) {
+    V3<F> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
+    sphere_vs_bar(P, cb, xA, zA, true, near_, best, count);
+  }
+  {
+    auto hit = best.ok;
+    c1.active = hit;
+    c1.n = sel3(hit, best.n, c1.n);
+    c1.rA = sel3(hit, best.p - xA, c1.rA); c1.rB = sel3(hit, best.p - xB, c1.rB);
+    F cc, dn;
+    contact_params(P, sel(hit, best.dist, zero), S(2), cc, dn);
+    c1.c0 = sel(hit, cc, zero); c1.Dn = sel(hit, dn, zero);
+  }
+  dropped = sel(count > S(1), count - S(1), zero);
+}
+
+// ------------------------------------------------------------------ row-distributed dense algebra (lane i holds row i)
+// In-place Cholesky of an N x N SPD matrix whose row i lives in A[0..N) of lane i (full rows, both triangles).  Afterwards the
+// lower part of the rows holds L (A[j], j < i) and il[j] = 1 / L_jj is replicated.  Pivots are floored relative to the original
+// diagonal: a Schur complement that loses positivity to rounding must cost accuracy of one Newton direction, never produce inf.
+template <int N, typename F> TGR_RDEV void rchol(F* A, F* il) {
+  typedef typename LaneTraits<F>::S S;
+  const S rel = sizeof(S) == 4 ? S(1e-6) : S(1e-13);
+  F ref[N];
+  static_for<N>([&](auto jc) { constexpr int j = decltype(jc)::value; ref[j] = bcast<j>(A[j]); });
+  static_for<N>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    F d = bcast<j>(A[j]);
+    d = max_(d, max_(rel * abs_(ref[j]), F(S(1e-30))));
+    const F ilj = rsqrt_(d);
+    il[j] = ilj;
+    const F t = A[j] * (ilj * ilj);  // L_ij / L_jj
+    static_for<N - 1 - j>([&](auto kc) {
+      constexpr int k = j + 1 + decltype(kc)::value;
+      A[k] = A[k] - t * bcast<j>(A[k]);
+    });
+    A[j] = A[j] * ilj;  // L_ij (lane j: L_jj)
+  });
+}
+// X <- X L^-T for the row X of every lane (L: row-distributed factor of rchol, N x N): solves X_new L^T = X
+template <int N, typename F> TGR_RDEV void rtrsm(const F* Lr, const F* il, F* X) {
+  static_for<N>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    F s = X[j];
+    static_for<j>([&](auto kc) { constexpr int k = decltype(kc)::value; s = s - X[k] * bcast<j>(Lr[k]); });
+    X[j] = s * il[j];
+  });
+}
+// C <- C - X Y^T  (row i of C: C[k] -= sum_m X_i[m] Y_k[m]); rows of X, Y, C distributed, N columns
+template <int N, typename F> TGR_RDEV void rsyrk(F* C, const F* X, const F* Y) {
+  static_for<N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    F s = C[k];
+    static_for<N>([&](auto mc) { constexpr int m = decltype(mc)::value; s = s - X[m] * bcast<k>(Y[m]); });
+    C[k] = s;
+  });
+}
+// forward substitution y <- L^-1 y, y distributed (lane i holds y_i)
+template <int N, typename F> TGR_RDEV void rfwd(const F* Lr, const F* il, F& y) {
+  static_for<N>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const F yj = bcast<j>(y) * il[j];
+    const auto r = lane_id();
+    y = sel(r == j, yj, sel(r > j, y - Lr[j] * yj, y));
+  });
+}
+// y <- y - X z  with z distributed over the N lanes (row i: y_i -= sum_m X_i[m] z_m)
+template <int N, typename F> TGR_RDEV void rgemv(const F* X, F z, F& y) {
+  static_for<N>([&](auto mc) { constexpr int m = decltype(mc)::value; y = y - X[m] * bcast<m>(z); });
+}
+// backward substitution: solves L^T x = y for y given REPLICATED (yr[N]); returns x distributed (xd, lane i holds x_i, other
+// lanes zero) and replicated (xr[N])
+template <int N, typename F> TGR_RDEV void rbwd(const F* Lr, const F* il, const F* yr, F& xd, F* xr) {
+  typedef typename LaneTraits<F>::S S;
+  const auto r = lane_id();
+  xd = F(S(0));
+  static_for<N>([&](auto ic) {
+    constexpr int i = N - 1 - decltype(ic)::value;
+    const F s = rowsum(Lr[i] * xd);  // lanes k > i hold their final x_k, the others zero
+    const F xi = (yr[i] - s) * il[i];
+    xr[i] = xi;
+    xd = sel(r == i, xi, xd);
+  });
+}
+template <int N, typename F> TGR_RDEV void rgather(F yd, F* yr) {
+  static_for<N>([&](auto ic) { constexpr int i = decltype(ic)::value; yr[i] = bcast<i>(yd); });
+}
+// t_i = sum_k X_k[i] z_k  (X^T z) for i < N, replicated results
+template <int N, typename F> TGR_RDEV void rgemvT(const F* X, F zd, F* out) {
+  static_for<N>([&](auto ic) { constexpr int i = decltype(ic)::value; out[i] = rowsum(X[i] * zd); });
+}
+
+// ------------------------------------------------------------------ line search pieces (slot role)
+template <typename F> struct RLSlot { F A0, A1, A2, B0, B1, B2, jn0, qn, jo0, qo, Dn; typename LaneTraits<F>::B act; };
+template <typename F> TGR_RDEV RLSlot<F> ls_make(const RContact<F>& c, V3<F> jl, V3<F> ja, V3<F> ql, V3<F> qa) {
+  RLSlot<F> s;
+  s.A0 = dot(jl, jl); s.A1 = dot(jl, ql); s.A2 = dot(ql, ql);
+  s.B0 = dot(ja, ja); s.B1 = dot(ja, qa); s.B2 = dot(qa, qa);
+  s.jn0 = dot(c.n, jl); s.qn = dot(c.n, ql); s.jo0 = dot(c.n, ja); s.qo = dot(c.n, qa);
+  s.Dn = c.Dn; s.act = c.active;
+  return s;
+}
+template <typename F, typename S> TGR_RDEV void ls_slot(const RParams<S>& P, const RLSlot<F>& s, F alpha, F& d1, F& d2) {
+  const S mu = P.f0 / std::sqrt(P.impratio);
+  F Dtf = s.Dn * (P.impratio / (P.f0 * P.f0));
+  F jn = s.jn0 + alpha * s.qn, jo = s.jo0 + alpha * s.qo;
+  F jl2 = s.A0 + alpha * (S(2) * s.A1 + alpha * s.A2), ja2 = s.B0 + alpha * (S(2) * s.B1 + alpha * s.B2);
+  F jlq = s.A1 + alpha * s.A2, jaq = s.B1 + alpha * s.B2;
+  F tt = P.f1sq * (jl2 - jn * jn) + P.f3sq * jo * jo + P.f4sq * (ja2 - jo * jo);
+  F Tn = sqrt_(max_(tt, F(S(0))));
+  F wq = P.f1sq * (jlq - jn * s.qn) + P.f3sq * jo * s.qo + P.f4sq * (jaq - jo * s.qo);
+  F qtt = P.f1sq * (s.A2 - s.qn * s.qn) + P.f3sq * s.qo * s.qo + P.f4sq * (s.B2 - s.qo * s.qo);
+  F N = mu * jn;
+  auto top = (N >= mu * Tn) | !s.act;
+  auto bottom = !top & (mu * N + Tn <= S(0));
+  F b1 = s.Dn * jn * s.qn + Dtf * wq;
+  F b2 = s.Dn * s.qn * s.qn + Dtf * qtt;
+  F rT = rcp_(max_(Tn, F(S(1e-30))));
+  F Dm = s.Dn * (S(1) / (mu * mu * (S(1) + mu * mu)));
+  F NT = N - mu * Tn;
+  F gq = mu * (s.qn - wq * rT);
+  F kap = -Dm * mu * NT * rT;
+  F m1 = Dm * NT * gq;
+  F m2 = Dm * gq * gq + kap * (qtt - wq * wq * rT * rT);
+  const F zero = F(S(0));
+  d1 = sel(top, zero, sel(bottom, b1, m1));
+  d2 = sel(top, zero, sel(bottom, b2, m2));
+}
+
+// ------------------------------------------------------------------ Newton Hessian, dof role
+// per-lane dof constants: e = unit vector of my component, ang = am I an angular row
+template <typename F> struct DofC { V3<F> e; typename LaneTraits<F>::B ang, dof; };
+// column r of J = [[I, -[arm]x], [0, I]] for my dof r:  (u_lin, u_ang)
+template <typename F> TGR_RDEV void dof_col(const DofC<F>& d, V3<F> arm, V3<F>& ul, V3<F>& ua) {
+  typedef typename LaneTraits<F>::S S;
+  const V3<F> z = mk<F>(F(S(0)), F(S(0)), F(S(0)));
+  ul = sel3(d.ang, cross(d.e, arm), d.e);
+  ua = sel3(d.ang, d.e, z);
+}
+// slot data after the broadcast from its slot lane (replicated in the row)
+template <typename F> struct SlotB { V3<F> n, rA, rB; F a1, a2, b1, b2, cg, cw; V3<F> gl, ga, wl, wa; };
+// w = C u  for the cone Hessian C of the broadcast slot
+template <typename F> TGR_RDEV void cone_mul(const SlotB<F>& s, bool cone, V3<F> ul, V3<F> ua, V3<F>& wl, V3<F>& wa) {
+  wl = s.a1 * ul + (s.a2 * dot(s.n, ul)) * s.n;
+  wa = s.b1 * ua + (s.b2 * dot(s.n, ua)) * s.n;
+  if (cone) {
+    F gu = s.cg * (dot(s.gl, ul) + dot(s.ga, ua)), wu = s.cw * (dot(s.wl, ul) + dot(s.wa, ua));
+    wl = wl + gu * s.gl + wu * s.wl;
+    wa = wa + gu * s.ga + wu * s.wa;
+  }
+}
+// row += sign * (wl, arm x wl + wa)   (my row of J_row^T C J_col, J_col built on `arm`)
+template <typename F> TGR_RDEV void row_acc(F* R, V3<F> wl, V3<F> wa, V3<F> arm, bool neg) {
+  V3<F> t = cross(arm, wl) + wa;
+  if (neg) { R[0] = R[0] - wl.x; R[1] = R[1] - wl.y; R[2] = R[2] - wl.z; R[3] = R[3] - t.x; R[4] = R[4] - t.y; R[5] = R[5] - t.z; }
+  else { R[0] = R[0] + wl.x; R[1] = R[1] + wl.y; R[2] = R[2] + wl.z; R[3] = R[3] + t.x; R[4] = R[4] + t.y; R[5] = R[5] + t.z; }
+}
+// the 18x18 Hessian as 6 blocks, row r of each in lane r:  [D0 ; O10 D1 ; O20 O21 D2]
+template <typename F> struct RHess { F D[3][6]; F O10[6], O20[6], O21[6]; };
+template <typename F> TGR_RDEV F* hess_off(RHess<F>& H, int a, int b) { return (a == 0 && b == 1) ? H.O10 : ((a == 0 && b == 2) ? H.O20 : H.O21); }
+
+template <int PAGE, int C, typename F>
+TGR_RDEV void hess_add_slot(RHess<F>& H, const DofC<F>& d, const RContact<F>& c, const RCone<F>& o) {
+  typedef typename LaneTraits<F>::S S;
+  if (!any_slot<C>(c.active)) return;
+  SlotB<F> s;
+  s.n = bcast3<C>(c.n); s.rA = bcast3<C>(c.rA); s.rB = bcast3<C>(c.rB);
+  s.a1 = bcast<C>(o.a1); s.a2 = bcast<C>(o.a2); s.b1 = bcast<C>(o.b1); s.b2 = bcast<C>(o.b2);
+  const bool cone = any_slot<C>(o.cg != S(0));
+  if (cone) { s.cg = bcast<C>(o.cg); s.cw = bcast<C>(o.cw); s.gl = bcast3<C>(o.gl); s.ga = bcast3<C>(o.ga); s.wl = bcast3<C>(o.wl); s.wa = bcast3<C>(o.wa); }
+  constexpr int A = slot_bar_a(PAGE, C), Bb = slot_bar_b(PAGE, C);
+  static_assert(Bb >= 0, "slot without a body");
+  V3<F> ul, ua, wl, wa;
+  dof_col(d, s.rB, ul, ua);
+  cone_mul(s, cone, ul, ua, wl, wa);
+  row_acc(H.D[Bb], wl, wa, s.rB, false);
+  if (A >= 0) {
+    row_acc(hess_off(H, A < 0 ? 0 : A, Bb), wl, wa, s.rA, true);  // rows: B dofs, columns: A dofs
+    dof_col(d, s.rA, ul, ua);
+    cone_mul(s, cone, ul, ua, wl, wa);
+    row_acc(H.D[A < 0 ? 0 : A], wl, wa, s.rA, false);
+  }
+}
+
+// p = -H^-1 g.  g: per bar distributed (lane r: component r of the bar's 6-vector); returns p replicated, pr[b][0..6)
+template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F pr[3][6]) {
+  typedef typename LaneTraits<F>::S S;
+  F il0[6], il1[6], il2[6];
+  rchol<6>(H.D[0], il0);
+  rtrsm<6>(H.D[0], il0, H.O10);
+  rtrsm<6>(H.D[0], il0, H.O20);
+  rsyrk<6>(H.D[1], H.O10, H.O10);
+  rsyrk<6>(H.O21, H.O20, H.O10);
+  rchol<6>(H.D[1], il1);
+  rtrsm<6>(H.D[1], il1, H.O21);
+  rsyrk<6>(H.D[2], H.O20, H.O20);
+  rsyrk<6>(H.D[2], H.O21, H.O21);
+  rchol<6>(H.D[2], il2);
+  // forward: L y = g
+  F y0 = gd[0], y1 = gd[1], y2 = gd[2];
+  rfwd<6>(H.D[0], il0, y0);
+  rgemv<6>(H.O10, y0, y1);
+  rgemv<6>(H.O20, y0, y2);
+  rfwd<6>(H.D[1], il1, y1);
+  rgemv<6>(H.O21, y1, y2);
+  rfwd<6>(H.D[2], il2, y2);
+  // backward: L^T x = y
+  F x0, x1, x2, t[6], yr[6];
+  rgather<6>(y2, yr);
+  rbwd<6>(H.D[2], il2, yr, x2, pr[2]);
+  rgather<6>(y1, yr);
+  rgemvT<6>(H.O21, x2, t);
+  for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
+  rbwd<6>(H.D[1], il1, yr, x1, pr[1]);
+  rgather<6>(y0, yr);
+  rgemvT<6>(H.O10, x1, t);
+  for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
+  rgemvT<6>(H.O20, x2, t);
+  for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
+  rbwd<6>(H.D[0], il0, yr, x0, pr[0]);
+  for (int b = 0; b < 3; b++)
+    for (int i = 0; i < 6; i++) pr[b][i] = -pr[b][i];
+}
+
+// ------------------------------------------------------------------ the sub-step
+// `LAST`: what only the last sub-step of a control period records (lagged kinematics, tendon lengths, contact wrench).
+// K / PK: lane and scalar type of the pose, the kinematics, the tendon geometry and the smooth forces; F / P: of the rest.
+template <typename K, typename F, typename SK, typename S, int MODEL, bool LAST>
+TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<K, F>& Ro, RSim<K, F>& Sm, RLag<K, F>& lag) {
+  typedef typename LaneTraits<F>::I I;
+  typedef typename LaneTraits<F>::B B;
+  const F zero = F(S(0));
+  const K kzero = K(SK(0));
+  const V3<F> z3 = mk<F>(zero, zero, zero);
+  const S im = S(1) / P.mass;
+  // ---- kinematics (replicated)
+  V3<K> kex[3], key[3], kez[3];
+  V3<F> ez[3], xf[3];
+  for (int b = 0; b < 3; b++) {
+    normalize_quat(Sm.q[b]);
+    Rot<K> R = quat_rot(Sm.q[b]);
+    kex[b] = R.ex; key[b] = R.ey; kez[b] = R.ez;
+    ez[b] = cvt3<F>(R.ez); xf[b] = cvt3<F>(Sm.x[b]);
+  }
+  if (LAST) {
+    for (int b = 0; b < 3; b++) {
+      lag.x[b] = Sm.x[b]; lag.z[b] = kez[b];
+      for (int i = 0; i < 4; i++) lag.q[b][i] = Sm.q[b][i];
+    }
+  }
+  // ---- tendons (tendon role): geometry, force, Jacobian pieces
+  V3<F> tu, tma, tmb;  // unit vector a -> b, moment arms ra x u, rb x u
+  F tdamp;
+  V3<K> l0k[3], a0k[3];  // unconstrained acceleration (replicated)
+  {
+    const V3<K> xa = pick_bar(Ro.ba, Sm.x), xb = pick_bar(Ro.bb, Sm.x);
+    const V3<K> ra = Ro.sa.x * pick_bar(Ro.ba, kex) + (Ro.sa.y * pick_bar(Ro.ba, key) + Ro.sa.z * pick_bar(Ro.ba, kez));
+    const V3<K> rb = Ro.sb.x * pick_bar(Ro.bb, kex) + (Ro.sb.y * pick_bar(Ro.bb, key) + Ro.sb.z * pick_bar(Ro.bb, kez));
+    const V3<K> dif = (xb + rb) - (xa + ra);
+    const K L2 = dot(dif, dif);
+    const K iL = rsqrt_(max_(L2, K(SK(1e-30))));
+    const K L = L2 * iL;
+    if (LAST) static_for<9>([&](auto tc) { constexpr int t = decltype(tc)::value; lag.tenL[t] = cvt<F>(bcast<t>(L)); });
+    const V3<K> u = iL * dif;
+    const V3<K> va = cvt3<K>(pick_bar(Ro.ba, Sm.v)) + cross(cvt3<K>(pick_bar(Ro.ba, Sm.w)), ra);
+    const V3<K> vb = cvt3<K>(pick_bar(Ro.bb, Sm.v)) + cross(cvt3<K>(pick_bar(Ro.bb, Sm.w)), rb);
+    const K Ld = dot(u, vb - va);
+    F cin = Sm.ctrl[5], ain = Sm.act[5];  // my actuator's control / activation (lanes >= 6: unused)
+    for (int t = 4; t >= 0; t--) { cin = sel(Ro.r == t, Sm.ctrl[t], cin); ain = sel(Ro.r == t, Sm.act[t], ain); }
+    const K passive = -Ro.tk * (L - Ro.tL0) - Ro.tb * Ld;
+    K f, damp;
+    if (MODEL) {  // dyntype filter, no bias, no force limit (uneven xml:39)
+      f = sel(Ro.actuated, PK.gain * cvt<K>(ain), kzero) + passive;
+      damp = Ro.tb;
+    } else {
+      const K cc = clamp_(cvt<K>(cin), K(PK.ctrl_lo), K(PK.ctrl_hi));
+      const K fr = PK.gain * cc + PK.bias0 + PK.bias1 * L + PK.bias2 * Ld;
+      const K fa = clamp_(fr, K(PK.force_lo), K(PK.force_hi));
+      const auto clamped = (fa <= PK.force_lo) | (fa >= PK.force_hi);
+      K dact = K(-PK.bias2);
+      if (PK.skip_clamped) dact = sel(clamped, kzero, dact);
+      f = sel(Ro.actuated, fa, kzero) + passive;
+      damp = sel(Ro.actuated, dact, kzero) + Ro.tb;
+    }
+    f = sel(Ro.is_ten, f, kzero);
+    tdamp = cvt<F>(sel(Ro.is_ten, damp, kzero));
+    const V3<K> ma = cross(ra, u), mb = cross(rb, u);
+    tu = cvt3<F>(u); tma = cvt3<F>(ma); tmb = cvt3<F>(mb);
+    const SK imk = SK(1) / PK.mass;
+    for (int b = 0; b < 3; b++) {
+      const auto onb = Ro.bb == b, ona = Ro.ba == b;
+      const K fb = sel(onb, f, kzero), fa_ = sel(ona, f, kzero);
+      V3<K> Fb = rowsum3((fb - fa_) * u);
+      const V3<K> Tb = rowsum3(fb * mb - fa_ * ma);
+      Fb.z = Fb.z - PK.mass * PK.grav;
+      const V3<K> wk = cvt3<K>(Sm.w[b]);
+      const V3<K> Tq = Tb + (-(PK.Izz - PK.Ixx) * dot(kez[b], wk)) * cross(wk, kez[b]);  // gyroscopic
+      l0k[b] = imk * Fb;
+      a0k[b] = inv_inertia(PK, kez[b], Tq);
+    }
+  }
+  V3<F> l0[3], a0[3];
+  for (int b = 0; b < 3; b++) { l0[b] = cvt3<F>(l0k[b]); a0[b] = cvt3<F>(a0k[b]); }
+  // ---- contacts (slot role)
+  RContact<F> c;
+  F dropped;
+  {
+    // caps on the floor: the distance is a small difference of pose quantities -> K
+    const V3<K> kzc = pick_bar(Ro.sB, kez), kxc = pick_bar(Ro.sB, Sm.x);
+    const K ksign = cvt<K>(Ro.cap_sign);
+    const K kdist = kxc.z + (ksign * PK.bar_half) * kzc.z - PK.cap_r;
+    const F dist = cvt<F>(kdist);
+    const V3<F> arm = (Ro.cap_sign * P.bar_half) * cvt3<F>(kzc);
+    F cc, dn;
+    contact_params(P, dist, S(1), cc, dn);
+    // bar pairs (every lane runs the routine; only pair lanes keep the outcome)
+    const V3<F> pxA = pick_bar0(Ro.sA, xf), pzA = pick_bar0(Ro.sA, ez), pxB = pick_bar0(Ro.sB, xf), pzB = pick_bar0(Ro.sB, ez);
+    RContact<F> p0, p1;
+    bar_pair_contacts(P, pxA, pzA, pxB, pzB, Ro.is_pair, p0, p1, dropped);
+    const auto s0 = Ro.sub == 0;
+    c.n = sel3(Ro.is_cap, mk<F>(zero, zero, F(S(1))), sel3(s0, p0.n, p1.n));
+    c.rA = sel3(Ro.is_cap, z3, sel3(s0, p0.rA, p1.rA));
+    c.rB = sel3(Ro.is_cap, mk<F>(arm.x, arm.y, arm.z - (P.cap_r + S(0.5) * dist)), sel3(s0, p0.rB, p1.rB));
+    c.c0 = sel(Ro.is_cap, cc, sel(s0, p0.c0, p1.c0));
+    c.Dn = sel(Ro.is_cap, dn, sel(s0, p0.Dn, p1.Dn));
+    c.active = sel(Ro.is_cap, dist < S(0), sel(Ro.is_pair, sel(s0, p0.active, p1.active), false));
+    dropped = sel(Ro.is_pair & s0, dropped, zero);
+  }
+  if (LAST) lag.overflow = rowsum(dropped);
+  const auto any_contact = rowsum(sel(c.active, F(S(1)), zero)) > S(0);
+  // ---- Newton
+  // Stopping rule: sqrt(g^T M^-1 g) < tol, in sqrt(kg) m/s^2.  mujoco's rule -- the plain norm of g over (mean inertia x nv) -- lets a
+  // torque residual about a bar's own axis (inertia 0.0038 kg m^2) pass that still spins the bar up by 1e-2 rad/s^2; weighting by
+  // M^-1 bounds the acceleration error itself (H >= M), which is what the stated tolerance on qvel is about.
+  DofC<F> dc;
+  dc.dof = Ro.is_dof; dc.ang = Ro.is_ang;
+  dc.e = mk<F>(sel(Ro.is_dof & (Ro.k == 0), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 1), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 2), F(S(1)), zero));
+  for (int b = 0; b < 3; b++) { Sm.al[b] = l0[b]; Sm.aa[b] = a0[b]; }  // the iteration starts from the unconstrained acceleration
+  auto conv = !any_contact;
+  V3<K> fclk[3], fcak[3];  // constraint wrench per bar.  The wrench sum and the gradient are formed in K: the torque about a bar's own
+                           // axis is a 1e-6 N m question inside 10 N m cross products (and I d cancels to Izz d along the axis)
+  V3<F> fcl[3], fca[3];
+  F cfrc_max = zero, bar_force = zero;
+  int n_it = 0, n_ls = 0;
+  for (int it = 0;; it++) {
+    // my slot's residual jar at the current iterate
+    V3<F> yl[3], ya[3];
+    for (int b = 0; b < 3; b++) { yl[b] = Sm.al[b] + P.B * Sm.v[b]; ya[b] = Sm.aa[b] + P.B * Sm.w[b]; }
+    const V3<F> ylA = pick_bar0(Ro.sA, yl), yaA = pick_bar0(Ro.sA, ya), ylB = pick_bar0(Ro.sB, yl), yaB = pick_bar0(Ro.sB, ya);
+    const V3<F> jl = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
+    const V3<F> ja = yaB - yaA;
+    const RCone<F> o = cone_eval(P, c, jl, ja);
+    // constraint wrench per bar, gradient
+    const V3<K> kfl = cvt3<K>(o.fl), kfa = cvt3<K>(o.fa);
+    const V3<K> tB = cross(cvt3<K>(c.rB), kfl) + kfa, tA = cross(cvt3<K>(c.rA), kfl) + kfa;
+    const V3<K> kz3 = mk<K>(kzero, kzero, kzero);
+    K gn = kzero;  // g^T M^-1 g: the M-norm of the acceleration error this residual can still hide (H >= M)
+    cfrc_max = zero;
+    V3<F> gl[3], ga[3];
+    for (int b = 0; b < 3; b++) {
+      const auto onb = Ro.sB == b, ona = Ro.sA == b;
+      fclk[b] = rowsum3(sel3(onb, kfl, kz3) - sel3(ona, kfl, kz3));
+      fcak[b] = rowsum3(sel3(onb, tB, kz3) - sel3(ona, tA, kz3));
+      fcl[b] = cvt3<F>(fclk[b]); fca[b] = cvt3<F>(fcak[b]);
+      const V3<K> glk = PK.mass * (cvt3<K>(Sm.al[b]) - l0k[b]) - fclk[b];
+      const V3<K> gak = inertia_mul(PK, kez[b], cvt3<K>(Sm.aa[b]) - a0k[b]) - fcak[b];
+      gn = gn + (SK(1) / PK.mass) * dot(glk, glk) + dot(gak, inv_inertia(PK, kez[b], gak));
+      gl[b] = cvt3<F>(glk); ga[b] = cvt3<F>(gak);
+      cfrc_max = max_(cfrc_max, max_(max_(max_(abs_(fcl[b].x), abs_(fcl[b].y)), abs_(fcl[b].z)), max_(max_(abs_(fca[b].x), abs_(fca[b].y)), abs_(fca[b].z))));
+    }
+    if (LAST) bar_force = rowsum(sel(Ro.is_pair, sqrt_(dot(o.fl, o.fl)), zero));
+    conv = conv | !(gn >= PK.tol * PK.tol);
+    if (!any_lane(!conv) || it >= P.max_iter) break;
+    n_it++;
+    // Hessian rows (dof role)
+    RHess<F> H;
+    for (int b = 0; b < 3; b++) {
+      const S dI = P.Izz - P.Ixx;
+      const F ze = dot(dc.e, ez[b]);
+      const V3<F> lin = sel3(dc.ang, z3, P.mass * dc.e);
+      const V3<F> ang = sel3(dc.ang, P.Ixx * dc.e + (dI * ze) * ez[b], z3);
+      H.D[b][0] = lin.x; H.D[b][1] = lin.y; H.D[b][2] = lin.z; H.D[b][3] = ang.x; H.D[b][4] = ang.y; H.D[b][5] = ang.z;
+    }
+    for (int i = 0; i < 6; i++) { H.O10[i] = zero; H.O20[i] = zero; H.O21[i] = zero; }
+    static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<0, decltype(cc)::value>(H, dc, c, o); });
+    // direction
+    F gd[3], pr[3][6];
+    for (int b = 0; b < 3; b++) gd[b] = sel(Ro.is_dof, sel(Ro.is_ang, pick_comp(Ro.k, ga[b]), pick_comp(Ro.k, gl[b])), zero);
+    newton_direction(H, gd, pr);
+    V3<F> pl[3], pa[3];
+    for (int b = 0; b < 3; b++) {
+      pl[b] = sel3(conv, z3, mk<F>(pr[b][0], pr[b][1], pr[b][2]));
+      pa[b] = sel3(conv, z3, mk<F>(pr[b][3], pr[b][4], pr[b][5]));
+    }
+    // line search: Gauss part (replicated), cone part (slot role)
+    F g1 = zero, g2 = zero, d0 = zero;
+    for (int b = 0; b < 3; b++) {
+      const V3<F> Ipa = inertia_mul(P, ez[b], pa[b]);
+      g1 = g1 + P.mass * dot(pl[b], Sm.al[b] - l0[b]) + dot(Ipa, Sm.aa[b] - a0[b]);
+      g2 = g2 + P.mass * dot(pl[b], pl[b]) + dot(Ipa, pa[b]);
+      d0 = d0 + dot(pl[b], gl[b]) + dot(pa[b], ga[b]);
+    }
+    const V3<F> plA = pick_bar0(Ro.sA, pl), paA = pick_bar0(Ro.sA, pa), plB = pick_bar0(Ro.sB, pl), paB = pick_bar0(Ro.sB, pa);
+    const V3<F> ql = (plB + cross(paB, c.rB)) - (plA + cross(paA, c.rA));
+    const V3<F> qa = paB - paA;
+    const RLSlot<F> ls = ls_make(c, jl, ja, ql, qa);
+    conv = conv | !(abs_(d0) >= P.tol * P.tol);  // Newton decrement g^T H^-1 g (<= g^T M^-1 g) below tolerance
+    conv = conv | !(d0 < S(0));                  // no descent left at working precision
+    F alpha = sel(conv, zero, F(S(1))), lo = zero, hi = F(S(-1));
+    auto ls_done = conv;
+    const F gtol = P.ls_tol * abs_(d0);
+    for (int k = 0;; k++) {
+      F s1, s2;
+      ls_slot(P, ls, alpha, s1, s2);
+      n_ls++;
+      const F d1 = g1 + alpha * g2 + rowsum(s1), d2 = g2 + rowsum(s2);
+      const auto small = abs_(d1) <= gtol;
+      const auto go = !ls_done & !small;
+      ls_done = ls_done | small;
+      lo = sel(go & (d1 < S(0)), alpha, lo);
+      hi = sel(go & !(d1 < S(0)), alpha, hi);
+      F na = sel(d2 > S(0), alpha - d1 * rcp_(d2), F(S(-1)));
+      const auto nohi = hi < S(0);
+      na = sel(nohi & (!(na > lo) | (na > S(10) * (lo + S(1)))), S(2) * alpha + S(1e-3), na);
+      na = sel(!nohi & (!(na > lo) | !(na < hi)), S(0.5) * (lo + hi), na);
+      ls_done = ls_done | (go & (hi > S(0)) & ((hi - lo) <= S(1e-6) * hi));
+      alpha = sel(go, na, alpha);
+      if (!any_lane(!ls_done) || k + 1 >= P.ls_iter) break;
+    }
+    for (int b = 0; b < 3; b++) { Sm.al[b] = Sm.al[b] + alpha * pl[b]; Sm.aa[b] = Sm.aa[b] + alpha * pa[b]; }
+  }
+  lag.n_it += n_it; lag.n_ls += n_ls;
+  lag.n_unconv = lag.n_unconv + sel(conv, zero, F(S(1)));
+  if (LAST) {
+    lag.cfrc_absmax = cfrc_max;
+    F sq = zero;
+    for (int b = 0; b < 3; b++) {
+      const V3<F> a = mk<F>(clamp_(fcl[b].x, F(P.cf_lo), F(P.cf_hi)), clamp_(fcl[b].y, F(P.cf_lo), F(P.cf_hi)), clamp_(fcl[b].z, F(P.cf_lo), F(P.cf_hi)));
+      const V3<F> t = mk<F>(clamp_(fca[b].x, F(P.cf_lo), F(P.cf_hi)), clamp_(fca[b].y, F(P.cf_lo), F(P.cf_hi)), clamp_(fca[b].z, F(P.cf_lo), F(P.cf_hi)));
+      sq = sq + dot(a, a) + dot(t, t);
+    }
+    lag.cfrc_clip_sq = sq;
+    lag.bar_contact = bar_force;
+  }
+  // ---- implicitfast: (M + h sum_t b_t J_t J_t^T) a_new = F_smooth + F_constraint  (Woodbury over the nine tendons, tendon role).
+  // yl/ya: the correction to the unconstrained acceleration (constraint part + damping part); a0 itself stays in K
+  V3<F> yl[3], ya[3];
+  V3<K> ylk[3], yak[3];  // acceleration by the constraint wrench (K)
+  for (int b = 0; b < 3; b++) {
+    ylk[b] = (SK(1) / PK.mass) * fclk[b]; yak[b] = inv_inertia(PK, kez[b], fcak[b]);
+    yl[b] = cvt3<F>(ylk[b]); ya[b] = cvt3<F>(yak[b]);
+  }
+  {
+    const F sc = sqrt_(P.h * tdamp);
+    const V3<F> us = sc * tu, mas = sc * tma, mbs = sc * tmb;
+    const V3<F> was = inv_inertia(P, pick_bar(Ro.ba, ez), mas), wbs = inv_inertia(P, pick_bar(Ro.bb, ez), mbs);
+    V3<F> fl_[3], fa_[3];
+    for (int b = 0; b < 3; b++) { fl_[b] = l0[b] + yl[b]; fa_[b] = a0[b] + ya[b]; }
+    F zt = dot(us, pick_bar(Ro.bb, fl_) - pick_bar(Ro.ba, fl_)) + dot(mbs, pick_bar(Ro.bb, fa_)) - dot(mas, pick_bar(Ro.ba, fa_));
+    F Sr[9], il9[9];
+    static_for<9>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int as = ten_ba(s), bs = ten_bb(s);
+      const V3<F> u2 = bcast3<s>(us), wa2 = bcast3<s>(was), wb2 = bcast3<s>(wbs);
+      const F uu = im * dot(us, u2);
+      F v = sel(Ro.r == s, F(S(1)), zero);
+      v = v + sel(Ro.ba == as, uu + dot(mas, wa2), zero);
+      v = v + sel(Ro.bb == bs, uu + dot(mbs, wb2), zero);
+      v = v - sel(Ro.ba == bs, uu + dot(mas, wb2), zero);
+      v = v - sel(Ro.bb == as, uu + dot(mbs, wa2), zero);
+      Sr[s] = sel(Ro.is_ten, v, zero);
+    });
+    rchol<9>(Sr, il9);
+    rfwd<9>(Sr, il9, zt);
+    F zr[9], zd, zrep[9];
+    rgather<9>(zt, zr);
+    rbwd<9>(Sr, il9, zr, zd, zrep);
+    for (int b = 0; b < 3; b++) {  // from here on yl / ya hold only the damping correction
+      const auto ona = Ro.ba == b, onb = Ro.bb == b;
+      const F ca = sel(ona, zd, zero) - sel(onb, zd, zero);
+      yl[b] = rowsum3((ca * im) * us);
+      ya[b] = rowsum3(sel(ona, zd, zero) * was - sel(onb, zd, zero) * wbs);
+    }
+  }
+  // ---- advance: v += h a ; x += h v ; q <- exp(h w / 2) * q   (world-frame w: left multiplication)
+  for (int b = 0; b < 3; b++) {
+    const V3<K> vk = cvt3<K>(Sm.v[b]) + PK.h * ((l0k[b] + ylk[b]) + cvt3<K>(yl[b]));
+    const V3<K> wk = cvt3<K>(Sm.w[b]) + PK.h * ((a0k[b] + yak[b]) + cvt3<K>(ya[b]));
+    Sm.v[b] = cvt3<F>(vk);
+    Sm.w[b] = cvt3<F>(wk);
+    Sm.x[b] = Sm.x[b] + PK.h * vk;
+    const V3<K> w = wk;
+    const SK hh = SK(0.5) * PK.h;
+    const K x2 = (hh * hh) * dot(w, w);
+    // half angle ~1e-3: series for sin(x)/x and cos(x) (exact to rounding for x < 1; spins beyond that end the episode anyway)
+    const K sinc = SK(1) + x2 * (SK(-1.0 / 6) + x2 * (SK(1.0 / 120) + x2 * (SK(-1.0 / 5040) + x2 * (SK(1.0 / 362880) + x2 * SK(-1.0 / 39916800)))));
+    const K cs = SK(1) + x2 * (SK(-0.5) + x2 * (SK(1.0 / 24) + x2 * (SK(-1.0 / 720) + x2 * (SK(1.0 / 40320) + x2 * (SK(-1.0 / 3628800) + x2 * SK(1.0 / 479001600))))));
+    const K k = hh * sinc;
+    const K rw = cs, rx = k * w.x, ry = k * w.y, rz = k * w.z;
+    K* q = Sm.q[b];
+    const K nw = rw * q[0] - rx * q[1] - ry * q[2] - rz * q[3];
+    const K nx = rw * q[1] + rx * q[0] + ry * q[3] - rz * q[2];
+    const K ny = rw * q[2] - rx * q[3] + ry * q[0] + rz * q[1];
+    const K nz = rw * q[3] + rx * q[2] - ry * q[1] + rz * q[0];
+    q[0] = nw; q[1] = nx; q[2] = ny; q[3] = nz;
+  }
+  if (MODEL) {
+    for (int a = 0; a < 6; a++) Sm.act[a] = Sm.act[a] + P.h * (clamp_(Sm.ctrl[a], F(P.ctrl_lo), F(P.ctrl_hi)) - Sm.act[a]) * P.act_itau;
+  }
+}
+}  // namespace row
+}  // namespace tgr

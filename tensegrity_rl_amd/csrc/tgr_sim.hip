@@ -20,6 +20,7 @@
 
 #include "../../include/tensegrity.h"
 #include "tgr_device.h"
+#include "tgr_row.h"
 
 #ifndef TGR_STAMP_BLOCKS
 #define TGR_STAMP_BLOCKS (blockIdx.x < 64)  // diagnostic build: which blocks report their phase cycles
@@ -563,62 +564,15 @@ TGR_DEV void store_reset_aux(const Params<T>& P, T* st, int* ist, int m, int e, 
   ist[I_RINGLEN * m + e] = ring.len; ist[I_RINGHEAD * m + e] = ring.head;
 }
 
-// ------------------------------------------------------------------ step kernel
-template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void step_kernel(KArgs<T> k) {
-  __shared__ T lds_all[lds_slots<MODEL>() * LW];
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 4 waves share the block's LW envs
-  if (lane >= LW) return;
-  const int gid = blockIdx.x * LW + lane;
-  const int n = k.n, m = k.m;
-  const bool valid = gid < m;
-  const int e = valid ? gid : m - 1;
+// ------------------------------------------------------------------ after the twenty sub-steps: bookkeeping of one env (shared by the
+// block kernels and the row kernels).  `w0`: this lane owns the env's global stores; orow: the env's row of the observation tile
+template <typename T>
+TGR_DEV void finish_lane(const KArgs<T>& k, Sim<T>& S, const Lag<T>& lag, int e, bool valid, bool live, bool active, bool w0, int phase,
+                         int total, T* orow) {
   const Params<T>& P = k.P;
   const EnvCfg<T>& E = k.E;
-  T* lds = lds_all + lane;
-
-  const bool live = e < n;
-  int phase = k.ist[I_PHASE * m + e];
-  const bool donor_run = !live && (phase > 0 || phase == PH_INIT);
-  const bool active = valid && (live || donor_run);
-  if (!__any(active)) return;  // a wave of idle donors
-
-  Sim<T> S;
-  int episode = k.ist[I_EPISODE * m + e];
-  const int total = settle_total(E);
-  if (!live && phase == PH_INIT) {
-    init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
-    phase = total;
-    if (valid) { k.ist[I_SRC * m + e] = e; k.ist[I_SRCEP * m + e] = episode; k.ist[I_EPISODE * m + e] = episode + 1; }
-  } else {
-    load_sim(k.st, m, e, S);
-  }
-  if (live) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const T a = T(k.actions[e * 6 + i]);
-      S.ctrl[i] = E.env_kind == TGR_ENV_TR ? S.ctrl[i] + (a - S.ctrl[i]) * E.dt : a;  // tr_env: _action_filter, k_FILTER = 1
-    }
-  }
-
-  Lag<T> lag;
-  lag.cfrc_absmax = T(0); lag.cfrc_clip_sq = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
-  lag.bar_contact = T(0);
-#pragma unroll
-  for (int i = 0; i < 9; i++) lag.tenL[i] = T(0);  // wave 3 never evaluates tendons
-#ifdef TGR_STAMPS
-  for (int i = 0; i < 32; i++) lag.stamp[i] = 0;
-  lag.t_last = clock64();
-#endif
-  warm_to_lds<T, LW>(S, lds, wid);
-#pragma unroll 1
-  for (int s = 0; s + 1 < E.frame_skip; s++) substep<T, LW, false, MODEL>(P, S, lds, wid, lag);
-  substep<T, LW, true, MODEL>(P, S, lds, wid, lag);
-
-#ifdef TGR_STAMPS
-  { long long _t = clock64(); lag.stamp[5] += _t - lag.t_last; lag.t_last = _t; }
-  if (lane == 0 && TGR_STAMP_BLOCKS) for (int i = 0; i < 32; i++) atomicAdd(&k.counters[8 + wid * 32 + i], (unsigned long long)lag.stamp[i]);
-#endif
+  const int n = k.n, m = k.m;
+  const int D = E.obs_dim;
   // everything the epilogue needs and the physics did not is (re)read only now: a value held across the twenty sub-steps
   // costs a register there, or a scratch round trip
   T action[6];
@@ -636,19 +590,8 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
   RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
   ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
   ModeState<T> ms = load_modes(k.st, k.ist, m, e);
-  const bool w0 = wid == 0;  // one wave owns every global store
-  if (lane == 0 && w0) {
-    atomicAdd(&k.counters[3], (unsigned long long)lag.n_it);
-    atomicAdd(&k.counters[4], (unsigned long long)lag.n_ls);
-    atomicAdd(&k.counters[5], (unsigned long long)E.frame_skip);
-  }
-  if (active && w0 && lag.n_unconv) atomicAdd(&k.counters[6], (unsigned long long)lag.n_unconv);
-  if (w0) {  // lane-sub-steps run: what counters[6] is a fraction of
-    const int nact = __popcll(__ballot(active));
-    if (lane == 0) atomicAdd(&k.counters[7], (unsigned long long)(nact * E.frame_skip));
-  }
   V3<T> wb[3];
-  if (active && w0) { warm_from_lds<T, LW>(S, lds); store_sim(k.st, m, e, S, lag, wb); }
+  if (active && w0) store_sim(k.st, m, e, S, lag, wb);
   else if (active) {
 #pragma unroll
     for (int b = 0; b < 3; b++) { normalize_quat(S.q[b]); wb[b] = rot_applyT(quat_rot(S.q[b]), S.w[b]); }
@@ -656,10 +599,6 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
 #pragma unroll
     for (int b = 0; b < 3; b++) wb[b] = mk(T(0), T(0), T(0));
   }
-  const int D = E.obs_dim;
-  const int Dp = (D & 1) ? D : D + 1;  // odd row pitch of the observation tile: conflict-free
-  T* orow = lds_all + lane * Dp;       // this lane's row (the physics columns are dead after the barrier below)
-  __syncthreads();
   if (!live) {
     // ---- donor lane: one more settle period done
     if (active && w0) {
@@ -729,6 +668,81 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
       }
     }
   }
+}
+
+// ------------------------------------------------------------------ step kernel
+template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void step_kernel(KArgs<T> k) {
+  __shared__ T lds_all[lds_slots<MODEL>() * LW];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 4 waves share the block's LW envs
+  if (lane >= LW) return;
+  const int gid = blockIdx.x * LW + lane;
+  const int n = k.n, m = k.m;
+  const bool valid = gid < m;
+  const int e = valid ? gid : m - 1;
+  const Params<T>& P = k.P;
+  const EnvCfg<T>& E = k.E;
+  T* lds = lds_all + lane;
+
+  const bool live = e < n;
+  int phase = k.ist[I_PHASE * m + e];
+  const bool donor_run = !live && (phase > 0 || phase == PH_INIT);
+  const bool active = valid && (live || donor_run);
+  if (!__any(active)) return;  // a wave of idle donors
+
+  Sim<T> S;
+  int episode = k.ist[I_EPISODE * m + e];
+  const int total = settle_total(E);
+  if (!live && phase == PH_INIT) {
+    init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
+    phase = total;
+    if (valid) { k.ist[I_SRC * m + e] = e; k.ist[I_SRCEP * m + e] = episode; k.ist[I_EPISODE * m + e] = episode + 1; }
+  } else {
+    load_sim(k.st, m, e, S);
+  }
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const T a = T(k.actions[e * 6 + i]);
+      S.ctrl[i] = E.env_kind == TGR_ENV_TR ? S.ctrl[i] + (a - S.ctrl[i]) * E.dt : a;  // tr_env: _action_filter, k_FILTER = 1
+    }
+  }
+
+  Lag<T> lag;
+  lag.cfrc_absmax = T(0); lag.cfrc_clip_sq = T(0); lag.overflow = 0; lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = 0;
+  lag.bar_contact = T(0);
+#pragma unroll
+  for (int i = 0; i < 9; i++) lag.tenL[i] = T(0);  // wave 3 never evaluates tendons
+#ifdef TGR_STAMPS
+  for (int i = 0; i < 32; i++) lag.stamp[i] = 0;
+  lag.t_last = clock64();
+#endif
+  warm_to_lds<T, LW>(S, lds, wid);
+#pragma unroll 1
+  for (int s = 0; s + 1 < E.frame_skip; s++) substep<T, LW, false, MODEL>(P, S, lds, wid, lag);
+  substep<T, LW, true, MODEL>(P, S, lds, wid, lag);
+
+#ifdef TGR_STAMPS
+  { long long _t = clock64(); lag.stamp[5] += _t - lag.t_last; lag.t_last = _t; }
+  if (lane == 0 && TGR_STAMP_BLOCKS) for (int i = 0; i < 32; i++) atomicAdd(&k.counters[8 + wid * 32 + i], (unsigned long long)lag.stamp[i]);
+#endif
+  const bool w0 = wid == 0;  // one wave owns every global store
+  if (lane == 0 && w0) {
+    atomicAdd(&k.counters[3], (unsigned long long)lag.n_it);
+    atomicAdd(&k.counters[4], (unsigned long long)lag.n_ls);
+    atomicAdd(&k.counters[5], (unsigned long long)E.frame_skip);
+  }
+  if (active && w0 && lag.n_unconv) atomicAdd(&k.counters[6], (unsigned long long)lag.n_unconv);
+  if (w0) {  // lane-sub-steps run: what counters[6] is a fraction of
+    const int nact = __popcll(__ballot(active));
+    if (lane == 0) atomicAdd(&k.counters[7], (unsigned long long)(nact * E.frame_skip));
+  }
+  if (active && w0) warm_from_lds<T, LW>(S, lds);
+  const int D = E.obs_dim;
+  const int Dp = (D & 1) ? D : D + 1;  // odd row pitch of the observation tile: conflict-free
+  T* orow = lds_all + lane * Dp;       // this lane's row (the physics columns are dead after the barrier below)
+  __syncthreads();
+  finish_lane(k, S, lag, e, valid, live, active, w0, phase, total, orow);
   // observations of the live lanes of this block leave through the LDS tile: coalesced stores into the [N][D] buffer
   const int base = blockIdx.x * LW;
   const int rows = min(LW, n - base);
@@ -739,6 +753,204 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
       k.obs[(size_t)base * D + f] = lds_all[r * Dp + c];
     }
   }
+}
+
+// ------------------------------------------------------------------ row kernels: one environment = one DPP row (tgr_row.h)
+// 256-thread blocks = 4 independent wavefronts x 4 environments; the 16 lanes of a row hold the environment's state replicated and
+// split the work by role.  No LDS in the physics (the observation tile is the only shared memory), no barrier inside a sub-step.
+// T: type of the state arrays / outputs; TK: type of pose, kinematics and tendon geometry inside the kernel (double in production).
+constexpr int ROW_ENVS = 16;  // environments per 256-thread block
+
+template <typename T, typename TK> struct RowArgs { row::RParams<T> P; row::RParams<TK> PK; };
+
+template <typename T, typename TK>
+TGR_DEV void row_load(const T* st, int m, int e, row::RSim<TK, T>& S) {
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    S.x[b] = row::mk<TK>(TK(st[(F_QPOS + 7 * b + 0) * m + e]), TK(st[(F_QPOS + 7 * b + 1) * m + e]), TK(st[(F_QPOS + 7 * b + 2) * m + e]));
+#pragma unroll
+    for (int i = 0; i < 4; i++) S.q[b][i] = TK(st[(F_QPOS + 7 * b + 3 + i) * m + e]);
+    row::normalize_quat(S.q[b]);
+    const row::Rot<TK> R = row::quat_rot(S.q[b]);
+    S.v[b] = row::mk<T>(st[(F_QVEL + 6 * b + 0) * m + e], st[(F_QVEL + 6 * b + 1) * m + e], st[(F_QVEL + 6 * b + 2) * m + e]);
+    const row::V3<TK> wb = row::mk<TK>(TK(st[(F_QVEL + 6 * b + 3) * m + e]), TK(st[(F_QVEL + 6 * b + 4) * m + e]), TK(st[(F_QVEL + 6 * b + 5) * m + e]));
+    S.w[b] = row::cvt3<T>(row::rot_apply(R, wb));
+    S.al[b] = row::mk<T>(T(0), T(0), T(0)); S.aa[b] = S.al[b];  // every solve starts from the unconstrained acceleration
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) { S.ctrl[i] = st[(F_CTRL + i) * m + e]; S.act[i] = st[(F_ACT + i) * m + e]; }
+}
+// the env layer (finish_lane, settle_period_done, make_obs ...) works on the block kernels' structs
+template <typename T, typename TK>
+TGR_DEV void row_export(const row::RSim<TK, T>& R, const row::RLag<TK, T>& rl, Sim<T>& S, Lag<T>& lag) {
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    S.x[b] = mk(T(R.x[b].x), T(R.x[b].y), T(R.x[b].z));
+    S.v[b] = mk(R.v[b].x, R.v[b].y, R.v[b].z); S.w[b] = mk(R.w[b].x, R.w[b].y, R.w[b].z);
+    S.al[b] = mk(R.al[b].x, R.al[b].y, R.al[b].z); S.aa[b] = mk(R.aa[b].x, R.aa[b].y, R.aa[b].z);
+    lag.x[b] = mk(T(rl.x[b].x), T(rl.x[b].y), T(rl.x[b].z)); lag.z[b] = mk(T(rl.z[b].x), T(rl.z[b].y), T(rl.z[b].z));
+#pragma unroll
+    for (int i = 0; i < 4; i++) { S.q[b][i] = T(R.q[b][i]); lag.q[b][i] = T(rl.q[b][i]); }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) { S.ctrl[i] = R.ctrl[i]; S.act[i] = R.act[i]; }
+#pragma unroll
+  for (int i = 0; i < 9; i++) lag.tenL[i] = rl.tenL[i];
+  lag.cfrc_absmax = rl.cfrc_absmax; lag.cfrc_clip_sq = rl.cfrc_clip_sq; lag.bar_contact = rl.bar_contact;
+  lag.overflow = (int)rl.overflow; lag.n_it = rl.n_it; lag.n_ls = rl.n_ls; lag.n_unconv = (int)rl.n_unconv;
+}
+template <typename T, typename TK> TGR_DEV void row_lag_init(row::RLag<TK, T>& rl) {
+  rl.cfrc_absmax = T(0); rl.cfrc_clip_sq = T(0); rl.bar_contact = T(0); rl.overflow = T(0); rl.n_unconv = T(0); rl.n_it = 0; rl.n_ls = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) rl.tenL[i] = T(0);
+}
+
+template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256) void step_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
+  __shared__ T tile[ROW_ENVS * 49];
+  const int r = (int)(threadIdx.x & 15u);
+  const int slot = (int)(threadIdx.x >> 4);  // environment of this row within the block
+  const int gid = blockIdx.x * ROW_ENVS + slot;
+  const int n = k.n, m = k.m;
+  const bool valid = gid < m;
+  const int e = valid ? gid : m - 1;
+  const EnvCfg<T>& E = k.E;
+  const bool live = valid && e < n;  // (rows past the end do nothing at all)
+  int phase = k.ist[I_PHASE * m + e];
+  const bool donor_run = valid && e >= n && (phase > 0 || phase == PH_INIT);
+  const bool active = live || donor_run;
+  const int total = settle_total(E);
+  const int D = E.obs_dim;
+  const int Dp = (D & 1) ? D : D + 1;
+  if (__any(active)) {  // (a wavefront of idle donor rows has nothing to do; the block still meets at the tile barrier below)
+    row::RSim<TK, T> R;
+    int episode = k.ist[I_EPISODE * m + e];
+    if (donor_run && phase == PH_INIT) {
+      Sim<T> S0;
+      init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S0);
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        R.x[b] = row::mk<TK>(TK(S0.x[b].x), TK(S0.x[b].y), TK(S0.x[b].z));
+#pragma unroll
+        for (int i = 0; i < 4; i++) R.q[b][i] = TK(S0.q[b][i]);
+        R.v[b] = row::mk<T>(S0.v[b].x, S0.v[b].y, S0.v[b].z); R.w[b] = row::mk<T>(S0.w[b].x, S0.w[b].y, S0.w[b].z);
+        R.al[b] = row::mk<T>(T(0), T(0), T(0)); R.aa[b] = R.al[b];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; i++) { R.ctrl[i] = S0.ctrl[i]; R.act[i] = S0.act[i]; }
+      phase = total;
+      if (valid && r == 0) { k.ist[I_SRC * m + e] = e; k.ist[I_SRCEP * m + e] = episode; k.ist[I_EPISODE * m + e] = episode + 1; }
+    } else {
+      row_load<T, TK>(k.st, m, e, R);
+    }
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const T a = T(k.actions[e * 6 + i]);
+        R.ctrl[i] = E.env_kind == TGR_ENV_TR ? R.ctrl[i] + (a - R.ctrl[i]) * E.dt : a;  // tr_env: _action_filter, k_FILTER = 1
+      }
+    }
+    const row::Roles<TK, T> Ro = row::make_roles<TK, T, TK, MODEL>(ra.PK);
+    row::RLag<TK, T> rl;
+    row_lag_init<T, TK>(rl);
+#pragma unroll 1
+    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, Ro, R, rl);
+    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, Ro, R, rl);
+    Sim<T> S;
+    Lag<T> lag;
+    row_export<T, TK>(R, rl, S, lag);
+    const bool w0 = r == 0;  // one lane of the row owns the env's global stores
+    if ((threadIdx.x & 63u) == 0) {
+      atomicAdd(&k.counters[3], (unsigned long long)lag.n_it);
+      atomicAdd(&k.counters[4], (unsigned long long)lag.n_ls);
+      atomicAdd(&k.counters[5], (unsigned long long)E.frame_skip);
+    }
+    if (active && w0 && lag.n_unconv) atomicAdd(&k.counters[6], (unsigned long long)lag.n_unconv);
+    {
+      const int nact = __popcll(__ballot(active && w0));
+      if ((threadIdx.x & 63u) == 0) atomicAdd(&k.counters[7], (unsigned long long)(nact * E.frame_skip));
+    }
+    finish_lane(k, S, lag, e, valid, live, active, w0, phase, total, tile + slot * Dp);
+  }
+  // observations of the live envs of this block leave through the tile: coalesced stores into the [N][D] buffer
+  const int base = blockIdx.x * ROW_ENVS;
+  const int rows = min(ROW_ENVS, n - base);
+  if (rows > 0) {
+    __syncthreads();
+    for (int f = (int)threadIdx.x; f < rows * D; f += 256) {
+      int rr = f / D, c = f - rr * D;
+      k.obs[(size_t)base * D + f] = tile[rr * Dp + c];
+    }
+  }
+}
+
+// reset_model() in one go, row layout: one row per entry of list[] (tgr_reset, and live envs that found no ready donor)
+template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256) void settle_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
+  __shared__ T tile[ROW_ENVS * 49];
+  const int r = (int)(threadIdx.x & 15u);
+  const int slot = (int)(threadIdx.x >> 4);
+  const int count = *k.list_count;
+  if (blockIdx.x * ROW_ENVS >= count) return;
+  const int li = blockIdx.x * ROW_ENVS + slot;
+  const bool valid = li < count;
+  if (!__any(valid)) return;  // (no barrier follows in this kernel)
+  const int e = k.list[valid ? li : count - 1];
+  const int n = k.n, m = k.m;
+  const EnvCfg<T>& E = k.E;
+  const Params<T>& P = k.P;
+  const int episode = k.ist[I_EPISODE * m + e];
+  Sim<T> S;
+  init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
+  row::RSim<TK, T> R;
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    R.x[b] = row::mk<TK>(TK(S.x[b].x), TK(S.x[b].y), TK(S.x[b].z));
+#pragma unroll
+    for (int i = 0; i < 4; i++) R.q[b][i] = TK(S.q[b][i]);
+    R.v[b] = row::mk<T>(S.v[b].x, S.v[b].y, S.v[b].z); R.w[b] = row::mk<T>(S.w[b].x, S.w[b].y, S.w[b].z);
+    R.al[b] = row::mk<T>(T(0), T(0), T(0)); R.aa[b] = R.al[b];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) { R.ctrl[i] = S.ctrl[i]; R.act[i] = S.act[i]; }
+  RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
+  ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
+  int step_num = 0;
+  const int total = settle_total(E);
+  const row::Roles<TK, T> Ro = row::make_roles<TK, T, TK, MODEL>(ra.PK);
+  row::RLag<TK, T> rl;
+  row_lag_init<T, TK>(rl);
+  Lag<T> lag;
+  T reset_psi = T(0);
+  ModeState<T> ms = load_modes(k.st, k.ist, m, e);
+  T xy_prev[2] = {T(0), T(0)};
+  const bool w0 = valid && r == 0;
+#pragma unroll 1
+  for (int st = 0; st < total; st++) {
+#pragma unroll 1
+    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, Ro, R, rl);
+    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, Ro, R, rl);
+    row_export<T, TK>(R, rl, S, lag);
+    // the heading deque lives in global memory: one lane of the row pushes (the others would push the same value again)
+    if (w0) settle_period_done(P, E, lag, st, ring, step_num, reset_psi, ms, xy_prev, lane_key(E, n, e), (unsigned long long)(unsigned)episode);
+  }
+  if (!w0) return;
+  V3<T> wb[3];
+  store_sim(k.st, m, e, S, lag, wb);
+  store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
+  store_modes(k.st, m, e, ms);
+  ms.step_num = step_num;
+  k.ist[I_SRC * m + e] = e;
+  k.ist[I_SRCEP * m + e] = episode;
+  k.ist[I_EPISODE * m + e] = episode + 1;
+  k.ist[I_PHASE * m + e] = e < n ? PH_LIVE : PH_READY;
+  atomicAdd(&k.counters[1], 1ull);
+  if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
+  const int D = E.obs_dim;
+  T* orow = tile + slot * ((D & 1) ? D : D + 1);
+  make_obs(P, E, S, lag, wb, ms, orow);
+  if (E.use_obs_noise) apply_obs_noise(E, lane_key(E, n, e), (unsigned)episode, 0, orow);
+  T* op = e < n ? (k.obs_reset ? k.obs_reset + (size_t)e * D : nullptr) : k.dobs + (size_t)(e - n) * D;
+  if (op)
+    for (int i = 0; i < D; i++) op[i] = orow[i];
 }
 
 // ------------------------------------------------------------------ settle kernel: reset_model() in one go
@@ -1006,6 +1218,7 @@ extern "C" int tgr_default_config(tgr_config* c, int env_kind, int desired_actio
   c->hf_size[0] = 50; c->hf_size[1] = 50; c->hf_size[2] = 1; c->hf_size[3] = 0.1;
   c->hf_pos[0] = 0; c->hf_pos[1] = 0; c->hf_pos[2] = -1.0;
   c->reset_noise_scale = 0.0;
+  c->kernel_layout = TGR_KERNEL_AUTO;
   return TGR_OK;
 }
 
@@ -1121,6 +1334,38 @@ static int alloc_handle(tgr_handle* h, int n_envs, int donors) {
   return TGR_OK;
 }
 
+// parameters of the row kernels in both precisions (tgr_row.h).  The row kernels' stopping rule is sqrt(g^T M^-1 g) < tol
+// [sqrt(kg) m/s^2], not mujoco's scaled plain norm: solver_tolerance of the config means that for them.
+template <typename T> static void params_to_row(const Params<T>& P, const tgr_config& c, row::RParams<T>& R) {
+  R.h = P.h; R.grav = P.grav; R.mass = P.mass; R.Ixx = P.Ixx; R.Izz = P.Izz;
+  R.cap_r = P.cap_r; R.bar_half = P.bar_half; R.rcyl_r = P.rcyl_r; R.bcyl_r = P.bcyl_r; R.bcyl_lo = P.bcyl_lo; R.bcyl_hi = P.bcyl_hi;
+  R.site_off = P.site_off; R.site_z = P.site_z;
+  for (int t = 0; t < 9; t++) { R.ten_k[t] = P.ten_k[t]; R.ten_b[t] = P.ten_b[t]; R.ten_L0[t] = P.ten_L0[t]; }
+  R.gain = P.gain; R.bias0 = P.bias0; R.bias1 = P.bias1; R.bias2 = P.bias2; R.force_lo = P.force_lo; R.force_hi = P.force_hi;
+  R.ctrl_lo = P.ctrl_lo; R.ctrl_hi = P.ctrl_hi; R.K = P.K; R.B = P.B;
+  R.imp0 = P.imp0; R.imp1 = P.imp1; R.imp_width = P.imp_width; R.imp_mid = P.imp_mid;
+  R.f0 = P.f0; R.f1sq = P.f1sq; R.f3sq = P.f3sq; R.f4sq = P.f4sq; R.impratio = P.impratio; R.invweight = P.invweight;
+  R.ls_tol = P.ls_tol; R.cf_lo = P.cf_lo; R.cf_hi = P.cf_hi;
+  R.skip_clamped = P.skip_clamped; R.act_itau = P.act_itau;
+  R.hf_rx = P.hf_rx; R.hf_ry = P.hf_ry; R.hf_ez = P.hf_ez; R.hf_x0 = P.hf_x0; R.hf_y0 = P.hf_y0; R.hf_z0 = P.hf_z0; R.hf_dx = P.hf_dx; R.hf_dy = P.hf_dy;
+  R.hf_nrow = P.hf_nrow; R.hf_ncol = P.hf_ncol; R.hf = P.hf;
+  const bool f32 = c.precision != TGR_PRECISION_F64;
+  R.tol = T(c.solver_tolerance > 0 ? c.solver_tolerance : (f32 ? 1e-3 : 1e-8));
+  R.max_iter = c.solver_iterations > 0 ? c.solver_iterations : (f32 ? 8 : 40);
+  R.ls_iter = f32 ? 6 : 50;
+}
+template <typename T> static void fill_row_args(const tgr_handle* h, const KArgs<T>& k, RowArgs<T, double>& ra) {
+  params_to_row<T>(k.P, h->cfg, ra.P);
+  KArgs<double> kd;
+  fill_args<double>(h, kd);
+  params_to_row<double>(kd.P, h->cfg, ra.PK);
+}
+// which kernels step this handle: the row kernels wherever they exist (flat-floor model), the block kernels otherwise
+static bool use_row_kernels(const tgr_handle* h) {
+  if (h->cfg.kernel_layout == TGR_KERNEL_BLOCK) return false;
+  return h->cfg.model_kind == 0;
+}
+
 extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_handle** out) {
   if (!cfg || !out || n_envs <= 0) { g_err = "tgr_create: bad arguments"; return TGR_ERR_INVALID; }
   if (cfg->desired_action < TGR_ACT_STRAIGHT || cfg->desired_action > TGR_ACT_VEL_TRACK ||
@@ -1231,9 +1476,15 @@ template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, 
   fill_args<T>(h, k);
   k.obs_reset = (T*)obs;
   constexpr int LW = LaneW<T>::value;
-  int blocks = (cnt + LW - 1) / LW;
-  if (h->cfg.model_kind) hipLaunchKernelGGL((settle_kernel<T, LW, 1>), dim3(blocks), dim3(256), 0, s, k);
-  else hipLaunchKernelGGL((settle_kernel<T, LW, 0>), dim3(blocks), dim3(256), 0, s, k);
+  if (use_row_kernels(h)) {
+    RowArgs<T, double> ra;
+    fill_row_args<T>(h, k, ra);
+    hipLaunchKernelGGL((settle_kernel_row<T, double, 0>), dim3((cnt + ROW_ENVS - 1) / ROW_ENVS), dim3(256), 0, s, k, ra);
+  } else {
+    int blocks = (cnt + LW - 1) / LW;
+    if (h->cfg.model_kind) hipLaunchKernelGGL((settle_kernel<T, LW, 1>), dim3(blocks), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((settle_kernel<T, LW, 0>), dim3(blocks), dim3(256), 0, s, k);
+  }
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->list_count, 0, sizeof(int), s));
   return TGR_OK;
@@ -1258,17 +1509,28 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
   k.obs_reset = obs;
   k.obs_clean = (T*)h->obs_clean;
   constexpr int LW = LaneW<T>::value;
-  int blocks = (h->m + LW - 1) / LW;
-  if (h->cfg.model_kind) hipLaunchKernelGGL((step_kernel<T, LW, 1>), dim3(blocks), dim3(256), 0, s, k);
-  else hipLaunchKernelGGL((step_kernel<T, LW, 0>), dim3(blocks), dim3(256), 0, s, k);
+  const bool rowk = use_row_kernels(h);
+  RowArgs<T, double> ra;
+  if (rowk) {
+    fill_row_args<T>(h, k, ra);
+    hipLaunchKernelGGL((step_kernel_row<T, double, 0>), dim3((h->m + ROW_ENVS - 1) / ROW_ENVS), dim3(256), 0, s, k, ra);
+  } else {
+    int blocks = (h->m + LW - 1) / LW;
+    if (h->cfg.model_kind) hipLaunchKernelGGL((step_kernel<T, LW, 1>), dim3(blocks), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((step_kernel<T, LW, 0>), dim3(blocks), dim3(256), 0, s, k);
+  }
   HIP_TRY(h, hipGetLastError());
   if (h->cfg.auto_reset) {
     hipLaunchKernelGGL((match_kernel<T>), dim3(1), dim3(1024), 0, s, k);
     HIP_TRY(h, hipGetLastError());
     // envs that found no ready donor are settled here and now (grid sized for the worst case, exits on an empty list)
-    int sblocks = (h->n + LW - 1) / LW;
-    if (h->cfg.model_kind) hipLaunchKernelGGL((settle_kernel<T, LW, 1>), dim3(sblocks), dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((settle_kernel<T, LW, 0>), dim3(sblocks), dim3(256), 0, s, k);
+    if (rowk) {
+      hipLaunchKernelGGL((settle_kernel_row<T, double, 0>), dim3((h->n + ROW_ENVS - 1) / ROW_ENVS), dim3(256), 0, s, k, ra);
+    } else {
+      int sblocks = (h->n + LW - 1) / LW;
+      if (h->cfg.model_kind) hipLaunchKernelGGL((settle_kernel<T, LW, 1>), dim3(sblocks), dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((settle_kernel<T, LW, 0>), dim3(sblocks), dim3(256), 0, s, k);
+    }
     HIP_TRY(h, hipGetLastError());
   }
   return TGR_OK;

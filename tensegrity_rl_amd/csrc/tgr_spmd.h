@@ -1,0 +1,171 @@
+// tgr_spmd.h -- the "one environment = one DPP row" execution model of the row kernels (gfx950 / CDNA4).
+//
+// An environment is worked on by the 16 lanes of one DPP row (a wavefront carries 4 environments).  Values are either
+// REPLICATED (every lane of the row holds the same bits -- the rigid-body state, the Newton iterate, every scalar that steers
+// control flow) or ROLE values (lane r holds item r of some set: contact slot r, tendon r, row r of a 6x6 block).  Lanes
+// exchange data only through the row collectives below, which on the GPU are single DPP instructions (row_newbcast, row_ror):
+// no LDS, no barriers.  Replicated values stay bit-identical across a row because every lane computes them with the same
+// instruction sequence from bit-identical inputs (rowsum() adds in an order that is the same set-wise for every lane).
+//
+// The same source compiles for the host with TGR_ROW_EMUL: a "lane value" is then an array of 16 scalars and every operator
+// works element-wise, so the physics in tgr_row.h can be checked against the CPU checker in the build container (tests/emul/
+// row_emul.cpp) before it ever runs on a GPU.  The emulation is test infrastructure; the product only ever compiles the
+// device branch.
+#pragma once
+
+#include <type_traits>
+#include <utility>
+#ifndef TGR_ROW_EMUL
+#include <hip/hip_runtime.h>
+#define TGR_RDEV __device__ __forceinline__
+#else
+#include <cmath>
+#include <cstring>
+#define TGR_RDEV inline
+#endif
+
+namespace tgr {
+namespace row {
+
+constexpr int ROW = 16;
+
+#ifndef TGR_ROW_EMUL
+// ------------------------------------------------------------------ device: a lane value is a plain scalar
+template <typename T> using Ln = T;
+template <typename F> struct LaneTraits;
+template <> struct LaneTraits<float> { typedef float S; typedef int I; typedef bool B; };
+template <> struct LaneTraits<double> { typedef double S; typedef int I; typedef bool B; };
+
+TGR_RDEV int lane_id() { return (int)(threadIdx.x & 15u); }
+template <typename T> TGR_RDEV T sel(bool c, T a, T b) { return c ? a : b; }
+TGR_RDEV bool any_lane(bool c) { return __any(c) != 0; }  // over the wavefront: a superset of the row, only ever used to skip work
+TGR_RDEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+TGR_RDEV double rcp_(double x) { return 1.0 / x; }
+TGR_RDEV float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+TGR_RDEV double sqrt_(double x) { return sqrt(x); }
+TGR_RDEV float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
+TGR_RDEV double rsqrt_(double x) { return 1.0 / sqrt(x); }
+TGR_RDEV float floor_(float x) { return floorf(x); }
+TGR_RDEV double floor_(double x) { return floor(x); }
+template <typename T> TGR_RDEV int to_int(T x) { return (int)x; }
+template <typename T> TGR_RDEV T from_int(int x, T) { return (T)x; }
+
+template <int CTRL> TGR_RDEV int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+template <int CTRL> TGR_RDEV float dpp_(float x) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, x))); }
+template <int CTRL> TGR_RDEV int dpp_(int x) { return dpp_i<CTRL>(x); }
+template <int CTRL> TGR_RDEV double dpp_(double x) {
+  long long b = __builtin_bit_cast(long long, x);
+  int lo = dpp_i<CTRL>((int)(b & 0xffffffffll)), hi = dpp_i<CTRL>((int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+// value of lane K of the row, in every lane of the row (row_newbcast:K)
+template <int K, typename T> TGR_RDEV T bcast(T x) { return dpp_<0x150 + K>(x); }
+// sum over the 16 lanes of the row, in every lane (row_ror butterfly)
+template <typename T> TGR_RDEV T rowsum(T x) {
+  x = x + dpp_<0x128>(x); x = x + dpp_<0x124>(x); x = x + dpp_<0x122>(x); x = x + dpp_<0x121>(x);
+  return x;
+}
+template <typename T> TGR_RDEV T rowmax(T x) {
+  T y = dpp_<0x128>(x); x = x > y ? x : y; y = dpp_<0x124>(x); x = x > y ? x : y;
+  y = dpp_<0x122>(x); x = x > y ? x : y; y = dpp_<0x121>(x); x = x > y ? x : y;
+  return x;
+}
+// is slot K's flag set in ANY row of the wavefront?  (uniform; used to skip the work of slots nobody has)
+template <int K> TGR_RDEV bool any_slot(bool flag) {
+  return (__ballot(flag) & (0x0001000100010001ull << K)) != 0ull;
+}
+template <typename To, typename From> TGR_RDEV To cvt(From x) { return (To)x; }
+#else
+// ------------------------------------------------------------------ host emulation: a lane value is the 16 scalars of a row
+template <typename T> struct Ln {
+  T v[ROW];
+  Ln() {}
+  Ln(T s) { for (int i = 0; i < ROW; i++) v[i] = s; }
+};
+template <typename F> struct LaneTraits;
+template <> struct LaneTraits<Ln<float>> { typedef float S; typedef Ln<int> I; typedef Ln<bool> B; };
+template <> struct LaneTraits<Ln<double>> { typedef double S; typedef Ln<int> I; typedef Ln<bool> B; };
+
+#define TGR_EMUL_BIN(OP)                                                                                                   \
+  template <typename T> inline Ln<T> operator OP(const Ln<T>& a, const Ln<T>& b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] OP b.v[i]; return r; } \
+  template <typename T> inline Ln<T> operator OP(const Ln<T>& a, T b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] OP b; return r; }               \
+  template <typename T> inline Ln<T> operator OP(T a, const Ln<T>& b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = a OP b.v[i]; return r; }
+TGR_EMUL_BIN(+) TGR_EMUL_BIN(-) TGR_EMUL_BIN(*) TGR_EMUL_BIN(/)
+#undef TGR_EMUL_BIN
+#define TGR_EMUL_CMP(OP)                                                                                                   \
+  template <typename T> inline Ln<bool> operator OP(const Ln<T>& a, const Ln<T>& b) { Ln<bool> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] OP b.v[i]; return r; } \
+  template <typename T> inline Ln<bool> operator OP(const Ln<T>& a, T b) { Ln<bool> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] OP b; return r; }               \
+  template <typename T> inline Ln<bool> operator OP(T a, const Ln<T>& b) { Ln<bool> r; for (int i = 0; i < ROW; i++) r.v[i] = a OP b.v[i]; return r; }
+TGR_EMUL_CMP(<) TGR_EMUL_CMP(>) TGR_EMUL_CMP(<=) TGR_EMUL_CMP(>=) TGR_EMUL_CMP(==) TGR_EMUL_CMP(!=)
+#undef TGR_EMUL_CMP
+template <typename T> inline Ln<T> operator-(const Ln<T>& a) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = -a.v[i]; return r; }
+template <typename T> inline Ln<T>& operator+=(Ln<T>& a, const Ln<T>& b) { for (int i = 0; i < ROW; i++) a.v[i] += b.v[i]; return a; }
+template <typename T> inline Ln<T>& operator-=(Ln<T>& a, const Ln<T>& b) { for (int i = 0; i < ROW; i++) a.v[i] -= b.v[i]; return a; }
+template <typename T> inline Ln<T>& operator*=(Ln<T>& a, const Ln<T>& b) { for (int i = 0; i < ROW; i++) a.v[i] *= b.v[i]; return a; }
+template <typename T> inline Ln<T>& operator+=(Ln<T>& a, T b) { for (int i = 0; i < ROW; i++) a.v[i] += b; return a; }
+template <typename T> inline Ln<T>& operator-=(Ln<T>& a, T b) { for (int i = 0; i < ROW; i++) a.v[i] -= b; return a; }
+template <typename T> inline Ln<T>& operator*=(Ln<T>& a, T b) { for (int i = 0; i < ROW; i++) a.v[i] *= b; return a; }
+inline Ln<bool> operator&(const Ln<bool>& a, const Ln<bool>& b) { Ln<bool> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] && b.v[i]; return r; }
+inline Ln<bool> operator|(const Ln<bool>& a, const Ln<bool>& b) { Ln<bool> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] || b.v[i]; return r; }
+inline Ln<bool> operator&(const Ln<bool>& a, bool b) { Ln<bool> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] && b; return r; }
+inline Ln<bool> operator|(const Ln<bool>& a, bool b) { Ln<bool> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] || b; return r; }
+inline Ln<bool> operator&(bool a, const Ln<bool>& b) { return b & a; }
+inline Ln<bool> operator|(bool a, const Ln<bool>& b) { return b | a; }
+inline Ln<bool> operator!(const Ln<bool>& a) { Ln<bool> r; for (int i = 0; i < ROW; i++) r.v[i] = !a.v[i]; return r; }
+inline Ln<int> operator>>(const Ln<int>& a, int s) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] >> s; return r; }
+inline Ln<int> operator&(const Ln<int>& a, int m) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] & m; return r; }
+
+inline Ln<int> lane_id() { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = i; return r; }
+template <typename T> inline Ln<T> sel(const Ln<bool>& c, const Ln<T>& a, const Ln<T>& b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+template <typename T> inline Ln<T> sel(const Ln<bool>& c, const Ln<T>& a, T b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a.v[i] : b; return r; }
+template <typename T> inline Ln<T> sel(const Ln<bool>& c, T a, const Ln<T>& b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a : b.v[i]; return r; }
+template <typename T> inline Ln<T> sel(const Ln<bool>& c, T a, T b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a : b; return r; }
+inline Ln<bool> sel(const Ln<bool>& c, const Ln<bool>& a, bool b) { Ln<bool> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a.v[i] : b; return r; }
+template <typename T> inline T sel(bool c, T a, T b) { return c ? a : b; }
+inline bool any_lane(const Ln<bool>& c) { for (int i = 0; i < ROW; i++) if (c.v[i]) return true; return false; }
+inline bool any_lane(bool c) { return c; }
+#define TGR_EMUL_FN(NAME, EXPR)                                                                                            \
+  template <typename T> inline T NAME##_scalar(T x) { return EXPR; }                                                       \
+  template <typename T> inline Ln<T> NAME(const Ln<T>& a) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = NAME##_scalar<T>(a.v[i]); return r; } \
+  inline float NAME(float x) { return NAME##_scalar<float>(x); }                                                           \
+  inline double NAME(double x) { return NAME##_scalar<double>(x); }
+TGR_EMUL_FN(rcp_, T(1) / x) TGR_EMUL_FN(sqrt_, std::sqrt(x)) TGR_EMUL_FN(rsqrt_, T(1) / std::sqrt(x)) TGR_EMUL_FN(floor_, std::floor(x))
+#undef TGR_EMUL_FN
+template <typename T> inline Ln<int> to_int(const Ln<T>& a) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = (int)a.v[i]; return r; }
+template <typename T> inline Ln<T> from_int(const Ln<int>& a, Ln<T>) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = (T)a.v[i]; return r; }
+template <int K, typename T> inline Ln<T> bcast(const Ln<T>& x) { return Ln<T>(x.v[K]); }
+template <typename T> inline Ln<T> rowsum(const Ln<T>& x) {  // same butterfly as the device's row_ror:8,4,2,1
+  Ln<T> a = x, b;
+  for (int s = 8; s >= 1; s >>= 1) { for (int i = 0; i < ROW; i++) b.v[i] = a.v[i] + a.v[(i + s) & 15]; a = b; }
+  return a;
+}
+template <typename T> inline Ln<T> rowmax(const Ln<T>& x) { T m = x.v[0]; for (int i = 1; i < ROW; i++) m = x.v[i] > m ? x.v[i] : m; return Ln<T>(m); }
+template <int K> inline bool any_slot(const Ln<bool>& flag) { return flag.v[K]; }
+template <typename To, typename T> inline To cvt(const Ln<T>& x) { To r; for (int i = 0; i < ROW; i++) r.v[i] = (decltype(r.v[0] + 0))x.v[i]; return r; }
+#endif
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1 (bcast<K> needs K as a constant)
+template <typename Fn, int... Is> TGR_RDEV void static_for_impl(Fn&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename Fn> TGR_RDEV void static_for(Fn&& f) { static_for_impl(static_cast<Fn&&>(f), std::make_integer_sequence<int, N>{}); }
+
+// ------------------------------------------------------------------ shared helpers (F = lane real: float/double or their Ln<>)
+template <typename F> TGR_RDEV F abs_(F x) { return sel(x < typename LaneTraits<F>::S(0), -x, x); }
+template <typename F> TGR_RDEV F max_(F a, F b) { return sel(a > b, a, b); }
+template <typename F> TGR_RDEV F min_(F a, F b) { return sel(a < b, a, b); }
+template <typename F> TGR_RDEV F clamp_(F x, F lo, F hi) { return sel(x < lo, lo, sel(x > hi, hi, x)); }
+
+template <typename F> struct V3 { F x, y, z; };
+template <typename F> TGR_RDEV V3<F> mk(F x, F y, F z) { V3<F> r; r.x = x; r.y = y; r.z = z; return r; }
+template <typename F> TGR_RDEV V3<F> operator+(V3<F> a, V3<F> b) { return mk<F>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename F> TGR_RDEV V3<F> operator-(V3<F> a, V3<F> b) { return mk<F>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename F> TGR_RDEV V3<F> operator-(V3<F> a) { return mk<F>(-a.x, -a.y, -a.z); }
+template <typename G, typename F> TGR_RDEV V3<F> operator*(G s, V3<F> a) { return mk<F>(s * a.x, s * a.y, s * a.z); }  // G: lane value or scalar
+template <typename F> TGR_RDEV F dot(V3<F> a, V3<F> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename F> TGR_RDEV V3<F> cross(V3<F> a, V3<F> b) { return mk<F>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+template <typename F, typename B> TGR_RDEV V3<F> sel3(B c, V3<F> a, V3<F> b) { return mk<F>(sel(c, a.x, b.x), sel(c, a.y, b.y), sel(c, a.z, b.z)); }
+template <int K, typename F> TGR_RDEV V3<F> bcast3(V3<F> a) { return mk<F>(bcast<K>(a.x), bcast<K>(a.y), bcast<K>(a.z)); }
+template <typename F> TGR_RDEV V3<F> rowsum3(V3<F> a) { return mk<F>(rowsum(a.x), rowsum(a.y), rowsum(a.z)); }
+template <typename To, typename From> TGR_RDEV V3<To> cvt3(V3<From> a) { return mk<To>(cvt<To>(a.x), cvt<To>(a.y), cvt<To>(a.z)); }
+
+}  // namespace row
+}  // namespace tgr

@@ -89,6 +89,8 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
             getattr(cfg, dst)[0], getattr(cfg, dst)[1] = float(lo), float(hi)
     if "reward_delay_seconds" in kwargs:
         cfg.reward_delay_steps = int(kwargs.pop("reward_delay_seconds") / (cfg.timestep * cfg.frame_skip))
+    if "kernel_layout" in kwargs:
+        cfg.kernel_layout = N.KERNEL_LAYOUT[kwargs.pop("kernel_layout")]
     for k in ("actuator_deriv_skip_clamped", "solver_tolerance", "solver_iterations", "n_donors", "solver_warm_start"):
         if k in kwargs:
             setattr(cfg, k, type(getattr(cfg, k))(kwargs.pop(k)))

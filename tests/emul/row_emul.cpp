@@ -1,0 +1,101 @@
+// row_emul.cpp -- HOST EMULATION of the row kernels' physics (tensegrity_rl_amd/csrc/tgr_row.h compiled with TGR_ROW_EMUL: one
+// "lane value" = the 16 lanes of a DPP row as an array).  TEST INFRASTRUCTURE: lets tests/test_row_emulation.py check the
+// sub-step against the CPU oracle in the build container, where there is no GPU.  Nothing in the product links this.
+#define TGR_ROW_EMUL 1
+#include "../../tensegrity_rl_amd/csrc/tgr_row.h"
+
+#include <cstdio>
+
+using namespace tgr::row;
+
+template <typename T> static void fill_params(const double* p, RParams<T>& P, const float* hf, int nrow, int ncol) {
+  int i = 0;
+  P.h = T(p[i++]); P.grav = T(p[i++]); P.mass = T(p[i++]); P.Ixx = T(p[i++]); P.Izz = T(p[i++]);
+  P.cap_r = T(p[i++]); P.bar_half = T(p[i++]); P.rcyl_r = T(p[i++]); P.bcyl_r = T(p[i++]); P.bcyl_lo = T(p[i++]); P.bcyl_hi = T(p[i++]);
+  P.site_off = T(p[i++]); P.site_z = T(p[i++]);
+  for (int t = 0; t < 9; t++) P.ten_k[t] = T(p[i++]);
+  for (int t = 0; t < 9; t++) P.ten_b[t] = T(p[i++]);
+  for (int t = 0; t < 9; t++) P.ten_L0[t] = T(p[i++]);
+  P.gain = T(p[i++]); P.bias0 = T(p[i++]); P.bias1 = T(p[i++]); P.bias2 = T(p[i++]); P.force_lo = T(p[i++]); P.force_hi = T(p[i++]);
+  P.ctrl_lo = T(p[i++]); P.ctrl_hi = T(p[i++]); P.K = T(p[i++]); P.B = T(p[i++]);
+  P.imp0 = T(p[i++]); P.imp1 = T(p[i++]); P.imp_width = T(p[i++]); P.imp_mid = T(p[i++]);
+  P.f0 = T(p[i++]); P.f1sq = T(p[i++]); P.f3sq = T(p[i++]); P.f4sq = T(p[i++]); P.impratio = T(p[i++]); P.invweight = T(p[i++]);
+  P.tol = T(p[i++]); P.ls_tol = T(p[i++]); P.cf_lo = T(p[i++]); P.cf_hi = T(p[i++]);
+  P.max_iter = (int)p[i++]; P.ls_iter = (int)p[i++]; P.skip_clamped = (int)p[i++]; P.act_itau = T(p[i++]);
+  P.hf_rx = T(p[i++]); P.hf_ry = T(p[i++]); P.hf_ez = T(p[i++]); P.hf_x0 = T(p[i++]); P.hf_y0 = T(p[i++]); P.hf_z0 = T(p[i++]);
+  P.hf = hf; P.hf_nrow = nrow; P.hf_ncol = ncol;
+  P.hf_dx = T(ncol > 1 ? 2 * p[i - 6] / (ncol - 1) : 1.0); P.hf_dy = T(nrow > 1 ? 2 * p[i - 5] / (nrow - 1) : 1.0);
+}
+
+// every lane of the row must hold the same bits of a replicated value
+template <typename T> static int check_rep(const Ln<T>& x, const char* what, int env) {
+  for (int i = 1; i < ROW; i++)
+    if (std::memcmp(&x.v[i], &x.v[0], sizeof(T)) != 0 && !(x.v[i] != x.v[i] && x.v[0] != x.v[0])) {
+      std::fprintf(stderr, "row_emul: replicated value %s differs across lanes (env %d lane %d: %.17g vs %.17g)\n", what, env, i, (double)x.v[i], (double)x.v[0]);
+      return 1;
+    }
+  return 0;
+}
+
+template <typename TK, typename T, int MODEL>
+static int run(const double* params, const float* hf, int nrow, int ncol, int n, int nsub, double* qpos, double* qvel, const double* ctrl, double* act,
+               double* out /* [n][32] */) {
+  typedef Ln<T> F;
+  typedef Ln<TK> K;
+  RParams<T> P;
+  RParams<TK> PK;
+  fill_params<T>(params, P, hf, nrow, ncol);
+  fill_params<TK>(params, PK, hf, nrow, ncol);
+  const Roles<K, F> Ro = make_roles<K, F, TK, MODEL>(PK);
+  int bad = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : bad)
+  for (int e = 0; e < n; e++) {
+    RSim<K, F> S;
+    RLag<K, F> lag;
+    for (int b = 0; b < 3; b++) {
+      const double* q = qpos + 21 * e + 7 * b;
+      S.x[b] = mk<K>(K(TK(q[0])), K(TK(q[1])), K(TK(q[2])));
+      for (int i = 0; i < 4; i++) S.q[b][i] = K(TK(q[3 + i]));
+      normalize_quat(S.q[b]);
+      const Rot<K> R = quat_rot(S.q[b]);
+      const double* v = qvel + 18 * e + 6 * b;
+      S.v[b] = mk<F>(F(T(v[0])), F(T(v[1])), F(T(v[2])));
+      S.w[b] = cvt3<F>(rot_apply(R, mk<K>(K(TK(v[3])), K(TK(v[4])), K(TK(v[5])))));
+      S.al[b] = mk<F>(F(T(0)), F(T(0)), F(T(0))); S.aa[b] = S.al[b];
+    }
+    for (int i = 0; i < 6; i++) { S.ctrl[i] = F(T(ctrl[6 * e + i])); S.act[i] = F(T(act[6 * e + i])); }
+    lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = F(T(0)); lag.cfrc_absmax = F(T(0)); lag.cfrc_clip_sq = F(T(0)); lag.bar_contact = F(T(0)); lag.overflow = F(T(0));
+    for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, Ro, S, lag);
+    substep<K, F, TK, T, MODEL, true>(PK, P, Ro, S, lag);
+    for (int b = 0; b < 3; b++) {
+      normalize_quat(S.q[b]);
+      const Rot<K> R = quat_rot(S.q[b]);
+      const V3<K> wb = rot_applyT(R, cvt3<K>(S.w[b]));
+      double* q = qpos + 21 * e + 7 * b;
+      double* v = qvel + 18 * e + 6 * b;
+      bad += check_rep(S.x[b].x, "x", e) + check_rep(S.q[b][0], "q", e) + check_rep(S.v[b].z, "v", e) + check_rep(wb.x, "w", e) + check_rep(S.al[b].x, "a", e);
+      q[0] = S.x[b].x.v[0]; q[1] = S.x[b].y.v[0]; q[2] = S.x[b].z.v[0];
+      for (int i = 0; i < 4; i++) q[3 + i] = S.q[b][i].v[0];
+      v[0] = S.v[b].x.v[0]; v[1] = S.v[b].y.v[0]; v[2] = S.v[b].z.v[0]; v[3] = wb.x.v[0]; v[4] = wb.y.v[0]; v[5] = wb.z.v[0];
+    }
+    for (int i = 0; i < 6; i++) act[6 * e + i] = S.act[i].v[0];
+    double* o = out + 32 * e;
+    for (int t = 0; t < 9; t++) { o[t] = lag.tenL[t].v[0]; bad += check_rep(lag.tenL[t], "tenL", e); }
+    for (int b = 0; b < 3; b++) { o[9 + 3 * b] = lag.x[b].x.v[0]; o[10 + 3 * b] = lag.x[b].y.v[0]; o[11 + 3 * b] = lag.x[b].z.v[0]; }
+    o[18] = lag.cfrc_absmax.v[0]; o[19] = lag.cfrc_clip_sq.v[0]; o[20] = lag.bar_contact.v[0]; o[21] = lag.overflow.v[0];
+    o[22] = lag.n_unconv.v[0]; o[23] = lag.n_it; o[24] = lag.n_ls;
+    bad += check_rep(lag.cfrc_absmax, "cfrc", e) + check_rep(lag.bar_contact, "bar_contact", e) + check_rep(lag.n_unconv, "n_unconv", e);
+  }
+  return bad;
+}
+
+// precision: 0 = fp32 throughout, 1 = fp64 throughout, 2 = mixed (pose / kinematics / tendons fp64, the rest fp32)
+extern "C" int tgr_row_emul(int precision, int model, const double* params, const float* hf, int nrow, int ncol, int n, int nsub, double* qpos,
+                            double* qvel, const double* ctrl, double* act, double* out) {
+  if (model == 0) {
+    if (precision == 1) return run<double, double, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
+    if (precision == 2) return run<double, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
+    return run<float, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
+  }
+  return -1;
+}

@@ -8,7 +8,14 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 auto = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 kw = {}
 for a in sys.argv[5:]:
-    k_, v_ = a.split('='); kw[k_] = float(v_) if '.' in v_ or 'e' in v_ else int(v_)
+    k_, v_ = a.split('=')
+    try:
+        kw[k_] = int(v_)
+    except ValueError:
+        try:
+            kw[k_] = float(v_)
+        except ValueError:
+            kw[k_] = v_
 env = TensegrityVecEnv(n, kind, auto_reset=bool(auto), **kw)
 t0 = time.time(); env.reset_tensors(); torch.cuda.synchronize(); t_reset = time.time() - t0
 g = torch.Generator(device="cuda"); g.manual_seed(0)

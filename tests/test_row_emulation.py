@@ -1,0 +1,71 @@
+"""The row kernels' physics (tensegrity_rl_amd/csrc/tgr_row.h: one environment = the 16 lanes of a DPP row) checked on the CPU.
+
+tests/emul/row_emul.cpp compiles the SAME header with TGR_ROW_EMUL -- a "lane value" becomes an array of 16 scalars, the row
+collectives (row_newbcast / row_ror butterflies) become loops -- so the sub-step can be compared with the CPU checker in the build
+container, where there is no GPU.  The emulation also verifies that every replicated value stays bit-identical across the 16 lanes.
+-m gpu tests (tests/test_gpu_parity.py) then check the same code on the device through the C-ABI."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gpu_common import qfix, rel_env  # noqa: E402
+
+
+def _ctrl(kind, c, a):
+    return c + (a.astype(np.float64) - c) * 0.02 if kind == "tr_env" else a.astype(np.float64)  # tr_env.py:345,680-683
+
+
+@pytest.mark.parametrize("kind", ["tensegrity_env", "tr_env"])
+def test_fp64_row_substeps_match_the_oracle(oracle, kind):
+    import row_emul as RE
+    O = oracle
+    n = 64
+    ob = O.OracleBatch(O.make_cfg(kind, "straight"), n, seed=1234)
+    ob.reset()
+    P = RE.params_from_oracle_model(ob.env(0).model, 1e-9, 40)
+    rng = np.random.default_rng(0)
+    bar = 0.0
+    for t in range(3):
+        q, v, c, w, aux = ob.get_state()
+        a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+        q2, v2, _, out = RE.step(P, q, v, _ctrl(kind, c, a), nsub=20, precision="f64")
+        info = ob.step(a, auto_reset=False)[5]
+        qo, vo = ob.get_state()[:2]
+        assert rel_env(qfix(q2, qo) - qo, qo, 1e-3).max() < 1e-8 and rel_env(v2 - vo, vo, 1e-2).max() < 1e-6
+        assert np.abs(out[:, :9] - info[:, 16:25]).max() < 1e-8                                       # lagged tendon lengths
+        assert (np.abs(out[:, 20] - info[:, 25]) / np.maximum(1.0, info[:, 25])).max() < 1e-4         # bar-bar contact force
+        bar = max(bar, info[:, 25].max())
+    if kind == "tensegrity_env":
+        assert bar > 1.0  # random actions do produce bar-bar contacts to compare
+    ob.close()
+
+
+@pytest.mark.parametrize("kind", ["tensegrity_env", "tr_env"])
+def test_mixed_precision_meets_the_stated_tolerance(oracle, kind):
+    """BASELINE.json: qpos / qvel within 1e-4 relative per env-step.  The production precision of the row kernels: fp32 with pose,
+    kinematics, tendon geometry and the Newton gradient in fp64, stopping rule sqrt(g^T M^-1 g) < 1e-3, state stored as fp32 between
+    steps.  >= 99 % of env-steps must be inside the bound; plain fp32 (and mujoco's stopping rule) is not -- see DESIGN.md."""
+    import row_emul as RE
+    O = oracle
+    n = 256
+    ob = O.OracleBatch(O.make_cfg(kind, "straight"), n, seed=1234)
+    ob.reset()
+    P = RE.params_from_oracle_model(ob.env(0).model, 1e-3, 8, 6)
+    rng = np.random.default_rng(0)
+    eq, ev, it = [], [], []
+    for t in range(4):
+        q, v, c, w, aux = ob.get_state()
+        a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+        q32, v32 = q.astype(np.float32).astype(np.float64), v.astype(np.float32).astype(np.float64)
+        q2, v2, _, out = RE.step(P, q32, v32, _ctrl(kind, c, a), nsub=20, precision="mixed")
+        ob.step(a, auto_reset=False)
+        qo, vo = ob.get_state()[:2]
+        eq.append(rel_env(qfix(q2, qo) - qo, qo, 1e-3)); ev.append(rel_env(v2 - vo, vo, 1e-2)); it.append(out[:, 23] / 20)
+    eq, ev = np.concatenate(eq), np.concatenate(ev)
+    assert (eq < 1e-4).mean() >= 0.99 and (ev < 1e-4).mean() >= 0.99, ((eq < 1e-4).mean(), (ev < 1e-4).mean())
+    assert np.median(ev) < 2e-5 and np.concatenate(it).mean() < 5.0
+    ob.close()
