@@ -57,22 +57,13 @@ template <int MODEL> constexpr int n_slots(int page) { return MODEL ? (page == 0
 // ------------------------------------------------------------------ replicated state of one environment
 // K: the lane type of pose, kinematics, tendon geometry and smooth forces (double in the mixed-precision production kernels: a tendon
 // length must be good to ~1e-9 m for the stated 1e-4 relative bound on velocities of a few cm/s); F: everything else
-template <typename K, typename F> struct RSim {
-  V3<K> x[3];   // bar COM
-  K q[3][4];    // orientation (w,x,y,z)
-  V3<F> v[3];   // linear velocity (world)
-  V3<F> w[3];   // angular velocity (world frame; qvel stores the body frame)
-  V3<F> al[3];  // Newton iterate / warm start, linear
-  V3<F> aa[3];  // ... angular (world frame)
-  F ctrl[6];
-  F act[6];     // MODEL 1: actuator activations
-};
 // what the reference reads after mj_step: quantities of the forward pass of the LAST sub-step (one sub-step old)
 template <typename K, typename F> struct RLag {
   V3<K> x[3], z[3];
   K q[3][4];
   F tenL[9];
   F cfrc_absmax, cfrc_clip_sq, bar_contact;
+  V3<F> al[3], aa[3];  // qacc of the last forward pass (angular part in the world frame)
   F overflow;   // dropped bar-bar contacts in the last sub-step (a count, kept as a real)
   F n_unconv;   // sub-steps this environment left the solver at the iteration cap
   int n_it, n_ls;
@@ -113,22 +104,22 @@ template <typename F, typename I> TGR_RDEV V3<F> pick_bar0(I b, const V3<F>* a) 
 template <typename F, typename I> TGR_RDEV F pick_comp(I k, V3<F> a) { return sel(k == 0, a.x, sel(k == 1, a.y, a.z)); }
 
 // ------------------------------------------------------------------ per-lane role constants (set up once per kernel)
-template <typename K, typename F> struct Roles {
+template <typename F> struct Roles {
   typedef typename LaneTraits<F>::I I;
   typedef typename LaneTraits<F>::B B;
   I r;
-  // tendon role
-  B is_ten; I ba, bb; V3<K> sa, sb; K tk, tb, tL0; B actuated;
+  // tendon role (its K constants -- site coordinates, stiffness, damping, spring length -- live in the role slab)
+  B is_ten; I ba, bb; B actuated;
   // slot role (page 0)
   B is_cap, is_pair, is_rod; I sub; I sA, sB; F cap_sign;
   // dof role
   B is_dof, is_ang; I k;
 };
-template <typename K, typename F, typename SK, int MODEL> TGR_RDEV Roles<K, F> make_roles(const RParams<SK>& P) {
+template <typename K, typename F, typename SK, int MODEL> TGR_RDEV Roles<F> make_roles(const RParams<SK>& P, const Slab<K>& rd) {
   typedef typename LaneTraits<F>::I I;
   typedef typename LaneTraits<F>::S S;
   typedef SK SKK;
-  Roles<K, F> R;
+  Roles<F> R;
   const I r = lane_id();
   R.r = r;
   R.is_ten = r < 9;
@@ -141,7 +132,8 @@ template <typename K, typename F, typename SK, int MODEL> TGR_RDEV Roles<K, F> m
     sia = sel(m, I(MODEL ? RTab::TEN1[t][1] : RTab::TEN0[t][1]), sia); sib = sel(m, I(MODEL ? RTab::TEN1[t][3] : RTab::TEN0[t][3]), sib);
     tk = sel(m, K(P.ten_k[t]), tk); tb = sel(m, K(P.ten_b[t]), tb); tL0 = sel(m, K(P.ten_L0[t]), tL0);
   });
-  R.ba = ba; R.bb = bb; R.tk = tk; R.tb = tb; R.tL0 = tL0;
+  R.ba = ba; R.bb = bb;
+  rd.st(6, tk); rd.st(7, tb); rd.st(8, tL0);  // RTK, RTB, RTL0
   R.actuated = r < 6;
   V3<K> sa = mk<K>(K(SKK(0)), K(SKK(0)), K(SKK(0))), sb = sa;
   static_for<6>([&](auto sc) {
@@ -150,7 +142,7 @@ template <typename K, typename F, typename SK, int MODEL> TGR_RDEV Roles<K, F> m
                             : mk<K>(K(SKK(RTab::S0[s][0]) * P.site_off), K(SKK(RTab::S0[s][1]) * P.site_off), K(SKK(RTab::S0[s][2]) * P.site_z));
     sa = sel3(sia == s, loc, sa); sb = sel3(sib == s, loc, sb);
   });
-  R.sa = sa; R.sb = sb;
+  st3(rd, 0, sa); st3(rd, 3, sb);  // RSA, RSB
   R.is_cap = r < 6;
   R.is_pair = (r >= 6) & (r < 12);
   R.is_rod = MODEL ? ((r >= 12) & (r < 15)) : (r < 0);
@@ -546,190 +538,222 @@ TGR_RDEV void hess_add_slot(RHess<F>& H, const DofC<F>& d, const RContact<F>& c,
 }
 
 // p = -H^-1 g.  g: per bar distributed (lane r: component r of the bar's 6-vector); returns p replicated, pr[b][0..6)
-template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F pr[3][6]) {
+// c01 / c02 / c12: does ANY environment of the wavefront couple bars (0,1) / (0,2) / (1,2)?  (uniform flags; an off-diagonal block
+// nobody fills is zero and its part of the factorisation is skipped.  O21 also fills in through O20 O10^T.)
+template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F pr[3][6], bool c01, bool c02, bool c12) {
   typedef typename LaneTraits<F>::S S;
+  const bool n21 = c12 || (c01 && c02);
   F il0[6], il1[6], il2[6];
   rchol<6>(H.D[0], il0);
-  rtrsm<6>(H.D[0], il0, H.O10);
-  rtrsm<6>(H.D[0], il0, H.O20);
-  rsyrk<6>(H.D[1], H.O10, H.O10);
-  rsyrk<6>(H.O21, H.O20, H.O10);
+  if (c01) rtrsm<6>(H.D[0], il0, H.O10);
+  if (c02) rtrsm<6>(H.D[0], il0, H.O20);
+  if (c01) rsyrk<6>(H.D[1], H.O10, H.O10);
+  if (c01 && c02) rsyrk<6>(H.O21, H.O20, H.O10);
   rchol<6>(H.D[1], il1);
-  rtrsm<6>(H.D[1], il1, H.O21);
-  rsyrk<6>(H.D[2], H.O20, H.O20);
-  rsyrk<6>(H.D[2], H.O21, H.O21);
+  if (n21) rtrsm<6>(H.D[1], il1, H.O21);
+  if (c02) rsyrk<6>(H.D[2], H.O20, H.O20);
+  if (n21) rsyrk<6>(H.D[2], H.O21, H.O21);
   rchol<6>(H.D[2], il2);
   // forward: L y = g
   F y0 = gd[0], y1 = gd[1], y2 = gd[2];
   rfwd<6>(H.D[0], il0, y0);
-  rgemv<6>(H.O10, y0, y1);
-  rgemv<6>(H.O20, y0, y2);
+  if (c01) rgemv<6>(H.O10, y0, y1);
+  if (c02) rgemv<6>(H.O20, y0, y2);
   rfwd<6>(H.D[1], il1, y1);
-  rgemv<6>(H.O21, y1, y2);
+  if (n21) rgemv<6>(H.O21, y1, y2);
   rfwd<6>(H.D[2], il2, y2);
   // backward: L^T x = y
   F x0, x1, x2, t[6], yr[6];
   rgather<6>(y2, yr);
   rbwd<6>(H.D[2], il2, yr, x2, pr[2]);
   rgather<6>(y1, yr);
-  rgemvT<6>(H.O21, x2, t);
-  for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
+  if (n21) {
+    rgemvT<6>(H.O21, x2, t);
+    for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
+  }
   rbwd<6>(H.D[1], il1, yr, x1, pr[1]);
   rgather<6>(y0, yr);
-  rgemvT<6>(H.O10, x1, t);
-  for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
-  rgemvT<6>(H.O20, x2, t);
-  for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
+  if (c01) {
+    rgemvT<6>(H.O10, x1, t);
+    for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
+  }
+  if (c02) {
+    rgemvT<6>(H.O20, x2, t);
+    for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
+  }
   rbwd<6>(H.D[0], il0, yr, x0, pr[0]);
   for (int b = 0; b < 3; b++)
     for (int i = 0; i < 6; i++) pr[b][i] = -pr[b][i];
 }
 
 // ------------------------------------------------------------------ the sub-step
+// Between its uses the environment's state lives in slabs (LDS on the GPU), not in registers:
+//   kd (K, replicated): pose x, q; unconstrained acceleration l0, a0; bar axes ez       fd (F, replicated): v, w, ctrl, act
+//   td (F, per lane):   tendon-role results u, ra x u, rb x u, damping                  rd (K, per lane, per block): tendon-role constants
+enum : int { KX = 0, KQ = 9, KL0 = 21, KA0 = 30, KEZ = 39, K_SLAB = 48 };
+enum : int { FV = 0, FW = 9, FCTRL = 18, FACT = 24, F_SLAB = 30 };
+enum : int { TU = 0, TMA = 3, TMB = 6, TDAMP = 9, T_SLAB = 10 };
+enum : int { RSA = 0, RSB = 3, RTK = 6, RTB = 7, RTL0 = 8, R_SLAB = 9 };
+template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; };
+
 // `LAST`: what only the last sub-step of a control period records (lagged kinematics, tendon lengths, contact wrench).
 // K / PK: lane and scalar type of the pose, the kinematics, the tendon geometry and the smooth forces; F / P: of the rest.
 template <typename K, typename F, typename SK, typename S, int MODEL, bool LAST>
-TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<K, F>& Ro, RSim<K, F>& Sm, RLag<K, F>& lag) {
+TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>& Ro, const RMem<K, F>& M, RLag<K, F>& lag) {
   typedef typename LaneTraits<F>::I I;
   typedef typename LaneTraits<F>::B B;
   const F zero = F(S(0));
   const K kzero = K(SK(0));
   const V3<F> z3 = mk<F>(zero, zero, zero);
+  const V3<K> kz3 = mk<K>(kzero, kzero, kzero);
   const S im = S(1) / P.mass;
-  // ---- kinematics (replicated)
-  V3<K> kex[3], key[3], kez[3];
-  V3<F> ez[3], xf[3];
-  for (int b = 0; b < 3; b++) {
-    normalize_quat(Sm.q[b]);
-    Rot<K> R = quat_rot(Sm.q[b]);
-    kex[b] = R.ex; key[b] = R.ey; kez[b] = R.ez;
-    ez[b] = cvt3<F>(R.ez); xf[b] = cvt3<F>(Sm.x[b]);
-  }
-  if (LAST) {
-    for (int b = 0; b < 3; b++) {
-      lag.x[b] = Sm.x[b]; lag.z[b] = kez[b];
-      for (int i = 0; i < 4; i++) lag.q[b][i] = Sm.q[b][i];
-    }
-  }
-  // ---- tendons (tendon role): geometry, force, Jacobian pieces
-  V3<F> tu, tma, tmb;  // unit vector a -> b, moment arms ra x u, rb x u
-  F tdamp;
-  V3<K> l0k[3], a0k[3];  // unconstrained acceleration (replicated)
-  {
-    const V3<K> xa = pick_bar(Ro.ba, Sm.x), xb = pick_bar(Ro.bb, Sm.x);
-    const V3<K> ra = Ro.sa.x * pick_bar(Ro.ba, kex) + (Ro.sa.y * pick_bar(Ro.ba, key) + Ro.sa.z * pick_bar(Ro.ba, kez));
-    const V3<K> rb = Ro.sb.x * pick_bar(Ro.bb, kex) + (Ro.sb.y * pick_bar(Ro.bb, key) + Ro.sb.z * pick_bar(Ro.bb, kez));
-    const V3<K> dif = (xb + rb) - (xa + ra);
-    const K L2 = dot(dif, dif);
-    const K iL = rsqrt_(max_(L2, K(SK(1e-30))));
-    const K L = L2 * iL;
-    if (LAST) static_for<9>([&](auto tc) { constexpr int t = decltype(tc)::value; lag.tenL[t] = cvt<F>(bcast<t>(L)); });
-    const V3<K> u = iL * dif;
-    const V3<K> va = cvt3<K>(pick_bar(Ro.ba, Sm.v)) + cross(cvt3<K>(pick_bar(Ro.ba, Sm.w)), ra);
-    const V3<K> vb = cvt3<K>(pick_bar(Ro.bb, Sm.v)) + cross(cvt3<K>(pick_bar(Ro.bb, Sm.w)), rb);
-    const K Ld = dot(u, vb - va);
-    F cin = Sm.ctrl[5], ain = Sm.act[5];  // my actuator's control / activation (lanes >= 6: unused)
-    for (int t = 4; t >= 0; t--) { cin = sel(Ro.r == t, Sm.ctrl[t], cin); ain = sel(Ro.r == t, Sm.act[t], ain); }
-    const K passive = -Ro.tk * (L - Ro.tL0) - Ro.tb * Ld;
-    K f, damp;
-    if (MODEL) {  // dyntype filter, no bias, no force limit (uneven xml:39)
-      f = sel(Ro.actuated, PK.gain * cvt<K>(ain), kzero) + passive;
-      damp = Ro.tb;
-    } else {
-      const K cc = clamp_(cvt<K>(cin), K(PK.ctrl_lo), K(PK.ctrl_hi));
-      const K fr = PK.gain * cc + PK.bias0 + PK.bias1 * L + PK.bias2 * Ld;
-      const K fa = clamp_(fr, K(PK.force_lo), K(PK.force_hi));
-      const auto clamped = (fa <= PK.force_lo) | (fa >= PK.force_hi);
-      K dact = K(-PK.bias2);
-      if (PK.skip_clamped) dact = sel(clamped, kzero, dact);
-      f = sel(Ro.actuated, fa, kzero) + passive;
-      damp = sel(Ro.actuated, dact, kzero) + Ro.tb;
-    }
-    f = sel(Ro.is_ten, f, kzero);
-    tdamp = cvt<F>(sel(Ro.is_ten, damp, kzero));
-    const V3<K> ma = cross(ra, u), mb = cross(rb, u);
-    tu = cvt3<F>(u); tma = cvt3<F>(ma); tmb = cvt3<F>(mb);
-    const SK imk = SK(1) / PK.mass;
-    for (int b = 0; b < 3; b++) {
-      const auto onb = Ro.bb == b, ona = Ro.ba == b;
-      const K fb = sel(onb, f, kzero), fa_ = sel(ona, f, kzero);
-      V3<K> Fb = rowsum3((fb - fa_) * u);
-      const V3<K> Tb = rowsum3(fb * mb - fa_ * ma);
-      Fb.z = Fb.z - PK.mass * PK.grav;
-      const V3<K> wk = cvt3<K>(Sm.w[b]);
-      const V3<K> Tq = Tb + (-(PK.Izz - PK.Ixx) * dot(kez[b], wk)) * cross(wk, kez[b]);  // gyroscopic
-      l0k[b] = imk * Fb;
-      a0k[b] = inv_inertia(PK, kez[b], Tq);
-    }
-  }
-  V3<F> l0[3], a0[3];
-  for (int b = 0; b < 3; b++) { l0[b] = cvt3<F>(l0k[b]); a0[b] = cvt3<F>(a0k[b]); }
-  // ---- contacts (slot role)
+  const SK imk = SK(1) / PK.mass;
+  V3<F> ez[3];
   RContact<F> c;
+  V3<F> jl0, ja0;  // my slot's residual at the unconstrained acceleration: J (a0 + B v) + c0 n
   F dropped;
   {
-    // caps on the floor: the distance is a small difference of pose quantities -> K
-    const V3<K> kzc = pick_bar(Ro.sB, kez), kxc = pick_bar(Ro.sB, Sm.x);
-    const K ksign = cvt<K>(Ro.cap_sign);
-    const K kdist = kxc.z + (ksign * PK.bar_half) * kzc.z - PK.cap_r;
-    const F dist = cvt<F>(kdist);
-    const V3<F> arm = (Ro.cap_sign * P.bar_half) * cvt3<F>(kzc);
-    F cc, dn;
-    contact_params(P, dist, S(1), cc, dn);
-    // bar pairs (every lane runs the routine; only pair lanes keep the outcome)
-    const V3<F> pxA = pick_bar0(Ro.sA, xf), pzA = pick_bar0(Ro.sA, ez), pxB = pick_bar0(Ro.sB, xf), pzB = pick_bar0(Ro.sB, ez);
-    RContact<F> p0, p1;
-    bar_pair_contacts(P, pxA, pzA, pxB, pzB, Ro.is_pair, p0, p1, dropped);
-    const auto s0 = Ro.sub == 0;
-    c.n = sel3(Ro.is_cap, mk<F>(zero, zero, F(S(1))), sel3(s0, p0.n, p1.n));
-    c.rA = sel3(Ro.is_cap, z3, sel3(s0, p0.rA, p1.rA));
-    c.rB = sel3(Ro.is_cap, mk<F>(arm.x, arm.y, arm.z - (P.cap_r + S(0.5) * dist)), sel3(s0, p0.rB, p1.rB));
-    c.c0 = sel(Ro.is_cap, cc, sel(s0, p0.c0, p1.c0));
-    c.Dn = sel(Ro.is_cap, dn, sel(s0, p0.Dn, p1.Dn));
-    c.active = sel(Ro.is_cap, dist < S(0), sel(Ro.is_pair, sel(s0, p0.active, p1.active), false));
-    dropped = sel(Ro.is_pair & s0, dropped, zero);
+    // ---- kinematics (replicated)
+    V3<K> kx[3], kex[3], key[3], kez[3];
+    for (int b = 0; b < 3; b++) {
+      kx[b] = ld3(M.kd, KX + 3 * b);
+      K q[4] = {M.kd.ld(KQ + 4 * b), M.kd.ld(KQ + 4 * b + 1), M.kd.ld(KQ + 4 * b + 2), M.kd.ld(KQ + 4 * b + 3)};
+      normalize_quat(q);
+      const Rot<K> R = quat_rot(q);
+      kex[b] = R.ex; key[b] = R.ey; kez[b] = R.ez;
+      ez[b] = cvt3<F>(R.ez);
+      st3(M.kd, KEZ + 3 * b, R.ez);
+      if (LAST) {
+        lag.x[b] = kx[b]; lag.z[b] = R.ez;
+        for (int i = 0; i < 4; i++) lag.q[b][i] = q[i];
+      }
+    }
+    V3<F> v[3], w[3];
+    for (int b = 0; b < 3; b++) { v[b] = ld3(M.fd, FV + 3 * b); w[b] = ld3(M.fd, FW + 3 * b); }
+    // ---- tendons (tendon role): geometry, force, Jacobian pieces; smooth wrench per bar (replicated)
+    V3<F> l0[3], a0[3];
+    {
+      const V3<K> sa = ld3(M.rd, RSA), sb = ld3(M.rd, RSB);
+      const K tk = M.rd.ld(RTK), tb = M.rd.ld(RTB), tL0 = M.rd.ld(RTL0);
+      const V3<K> xa = pick_bar(Ro.ba, kx), xb = pick_bar(Ro.bb, kx);
+      const V3<K> ra = sa.x * pick_bar(Ro.ba, kex) + (sa.y * pick_bar(Ro.ba, key) + sa.z * pick_bar(Ro.ba, kez));
+      const V3<K> rb = sb.x * pick_bar(Ro.bb, kex) + (sb.y * pick_bar(Ro.bb, key) + sb.z * pick_bar(Ro.bb, kez));
+      const V3<K> dif = (xb + rb) - (xa + ra);
+      const K L2 = dot(dif, dif);
+      const K iL = rsqrt_(max_(L2, K(SK(1e-30))));
+      const K L = L2 * iL;
+      if (LAST) static_for<9>([&](auto tc) { constexpr int t = decltype(tc)::value; lag.tenL[t] = cvt<F>(bcast<t>(L)); });
+      const V3<K> u = iL * dif;
+      const V3<K> va = cvt3<K>(pick_bar(Ro.ba, v)) + cross(cvt3<K>(pick_bar(Ro.ba, w)), ra);
+      const V3<K> vb = cvt3<K>(pick_bar(Ro.bb, v)) + cross(cvt3<K>(pick_bar(Ro.bb, w)), rb);
+      const K Ld = dot(u, vb - va);
+      F cin = M.fd.ld(FCTRL + 5), ain = M.fd.ld(FACT + 5);  // my actuator's control / activation (lanes >= 6: unused)
+      for (int t = 4; t >= 0; t--) { cin = sel(Ro.r == t, M.fd.ld(FCTRL + t), cin); if (MODEL) ain = sel(Ro.r == t, M.fd.ld(FACT + t), ain); }
+      const K passive = -tk * (L - tL0) - tb * Ld;
+      K f, damp;
+      if (MODEL) {  // dyntype filter, no bias, no force limit (uneven xml:39)
+        f = sel(Ro.actuated, PK.gain * cvt<K>(ain), kzero) + passive;
+        damp = tb;
+      } else {
+        const K cc = clamp_(cvt<K>(cin), K(PK.ctrl_lo), K(PK.ctrl_hi));
+        const K fr = PK.gain * cc + PK.bias0 + PK.bias1 * L + PK.bias2 * Ld;
+        const K fa = clamp_(fr, K(PK.force_lo), K(PK.force_hi));
+        const auto clamped = (fa <= PK.force_lo) | (fa >= PK.force_hi);
+        K dact = K(-PK.bias2);
+        if (PK.skip_clamped) dact = sel(clamped, kzero, dact);
+        f = sel(Ro.actuated, fa, kzero) + passive;
+        damp = sel(Ro.actuated, dact, kzero) + tb;
+      }
+      f = sel(Ro.is_ten, f, kzero);
+      const V3<K> ma = cross(ra, u), mb = cross(rb, u);
+      st3(M.td, TU, cvt3<F>(u)); st3(M.td, TMA, cvt3<F>(ma)); st3(M.td, TMB, cvt3<F>(mb));
+      M.td.st(TDAMP, cvt<F>(sel(Ro.is_ten, damp, kzero)));
+      for (int b = 0; b < 3; b++) {
+        const auto onb = Ro.bb == b, ona = Ro.ba == b;
+        const K fb = sel(onb, f, kzero), fa_ = sel(ona, f, kzero);
+        // the force sum only feeds linear accelerations (fp32 resolves them); the torque sum decides the spin about the bar's own axis
+        V3<K> Fb = cvt3<K>(rowsum3(cvt3<F>((fb - fa_) * u)));
+        const V3<K> Tb = rowsum3(fb * mb - fa_ * ma);
+        Fb.z = Fb.z - PK.mass * PK.grav;
+        const V3<K> wk = cvt3<K>(w[b]);
+        const V3<K> Tq = Tb + (-(PK.Izz - PK.Ixx) * dot(kez[b], wk)) * cross(wk, kez[b]);  // gyroscopic
+        const V3<K> l0k = imk * Fb, a0k = inv_inertia(PK, kez[b], Tq);
+        st3(M.kd, KL0 + 3 * b, l0k); st3(M.kd, KA0 + 3 * b, a0k);
+        l0[b] = cvt3<F>(l0k); a0[b] = cvt3<F>(a0k);
+      }
+    }
+    // ---- contacts (slot role)
+    {
+      // caps on the floor: the distance is a small difference of pose quantities -> K
+      const V3<K> kzc = pick_bar(Ro.sB, kez), kxc = pick_bar(Ro.sB, kx);
+      const K kdist = kxc.z + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc.z - PK.cap_r;
+      const F dist = cvt<F>(kdist);
+      const V3<F> arm = (Ro.cap_sign * P.bar_half) * cvt3<F>(kzc);
+      F cc, dn;
+      contact_params(P, dist, S(1), cc, dn);
+      // bar pairs (every lane runs the routine; only pair lanes keep the outcome)
+      V3<F> xf[3];
+      for (int b = 0; b < 3; b++) xf[b] = cvt3<F>(kx[b]);
+      const V3<F> pxA = pick_bar0(Ro.sA, xf), pzA = pick_bar0(Ro.sA, ez), pxB = pick_bar0(Ro.sB, xf), pzB = pick_bar0(Ro.sB, ez);
+      RContact<F> p0, p1;
+      bar_pair_contacts(P, pxA, pzA, pxB, pzB, Ro.is_pair, p0, p1, dropped);
+      const auto s0 = Ro.sub == 0;
+      c.n = sel3(Ro.is_cap, mk<F>(zero, zero, F(S(1))), sel3(s0, p0.n, p1.n));
+      c.rA = sel3(Ro.is_cap, z3, sel3(s0, p0.rA, p1.rA));
+      c.rB = sel3(Ro.is_cap, mk<F>(arm.x, arm.y, arm.z - (P.cap_r + S(0.5) * dist)), sel3(s0, p0.rB, p1.rB));
+      c.c0 = sel(Ro.is_cap, cc, sel(s0, p0.c0, p1.c0));
+      c.Dn = sel(Ro.is_cap, dn, sel(s0, p0.Dn, p1.Dn));
+      c.active = sel(Ro.is_cap, dist < S(0), sel(Ro.is_pair, sel(s0, p0.active, p1.active), false));
+      dropped = sel(Ro.is_pair & s0, dropped, zero);
+    }
+    // my slot's residual at the unconstrained acceleration
+    {
+      V3<F> yl[3], ya[3];
+      for (int b = 0; b < 3; b++) { yl[b] = l0[b] + P.B * v[b]; ya[b] = a0[b] + P.B * w[b]; }
+      const V3<F> ylA = pick_bar0(Ro.sA, yl), yaA = pick_bar0(Ro.sA, ya), ylB = pick_bar0(Ro.sB, yl), yaB = pick_bar0(Ro.sB, ya);
+      jl0 = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
+      ja0 = yaB - yaA;
+    }
   }
   if (LAST) lag.overflow = rowsum(dropped);
   const auto any_contact = rowsum(sel(c.active, F(S(1)), zero)) > S(0);
-  // ---- Newton
-  // Stopping rule: sqrt(g^T M^-1 g) < tol, in sqrt(kg) m/s^2.  mujoco's rule -- the plain norm of g over (mean inertia x nv) -- lets a
-  // torque residual about a bar's own axis (inertia 0.0038 kg m^2) pass that still spins the bar up by 1e-2 rad/s^2; weighting by
-  // M^-1 bounds the acceleration error itself (H >= M), which is what the stated tolerance on qvel is about.
+  // ---- Newton on d = a - a0 (replicated).  Stopping rule: sqrt(g^T M^-1 g) < tol, in sqrt(kg) m/s^2.  mujoco's rule -- the plain norm
+  // of g over (mean inertia x nv) -- lets a torque residual about a bar's own axis (inertia 0.0038 kg m^2) pass that still spins the bar
+  // up by 1e-2 rad/s^2; weighting by M^-1 bounds the acceleration error itself (H >= M), which is what the tolerance on qvel is about.
   DofC<F> dc;
   dc.dof = Ro.is_dof; dc.ang = Ro.is_ang;
   dc.e = mk<F>(sel(Ro.is_dof & (Ro.k == 0), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 1), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 2), F(S(1)), zero));
-  for (int b = 0; b < 3; b++) { Sm.al[b] = l0[b]; Sm.aa[b] = a0[b]; }  // the iteration starts from the unconstrained acceleration
+  V3<F> dl[3], da[3];
+  for (int b = 0; b < 3; b++) { dl[b] = z3; da[b] = z3; }
   auto conv = !any_contact;
-  V3<K> fclk[3], fcak[3];  // constraint wrench per bar.  The wrench sum and the gradient are formed in K: the torque about a bar's own
-                           // axis is a 1e-6 N m question inside 10 N m cross products (and I d cancels to Izz d along the axis)
-  V3<F> fcl[3], fca[3];
+  V3<F> fcl[3];   // constraint force per bar (replicated)
+  V3<K> fcak[3];  // constraint torque per bar: summed in K -- the torque about a bar's own axis is a 1e-6 N m question inside 10 N m
+                  // cross products (and I d cancels to Izz d along the axis)
   F cfrc_max = zero, bar_force = zero;
   int n_it = 0, n_ls = 0;
   for (int it = 0;; it++) {
     // my slot's residual jar at the current iterate
-    V3<F> yl[3], ya[3];
-    for (int b = 0; b < 3; b++) { yl[b] = Sm.al[b] + P.B * Sm.v[b]; ya[b] = Sm.aa[b] + P.B * Sm.w[b]; }
-    const V3<F> ylA = pick_bar0(Ro.sA, yl), yaA = pick_bar0(Ro.sA, ya), ylB = pick_bar0(Ro.sB, yl), yaB = pick_bar0(Ro.sB, ya);
-    const V3<F> jl = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
-    const V3<F> ja = yaB - yaA;
+    const V3<F> dlA = pick_bar0(Ro.sA, dl), daA = pick_bar0(Ro.sA, da), dlB = pick_bar0(Ro.sB, dl), daB = pick_bar0(Ro.sB, da);
+    const V3<F> jl = jl0 + ((dlB + cross(daB, c.rB)) - (dlA + cross(daA, c.rA)));
+    const V3<F> ja = ja0 + (daB - daA);
     const RCone<F> o = cone_eval(P, c, jl, ja);
     // constraint wrench per bar, gradient
     const V3<K> kfl = cvt3<K>(o.fl), kfa = cvt3<K>(o.fa);
     const V3<K> tB = cross(cvt3<K>(c.rB), kfl) + kfa, tA = cross(cvt3<K>(c.rA), kfl) + kfa;
-    const V3<K> kz3 = mk<K>(kzero, kzero, kzero);
-    K gn = kzero;  // g^T M^-1 g: the M-norm of the acceleration error this residual can still hide (H >= M)
+    K gn = kzero;  // g^T M^-1 g
     cfrc_max = zero;
     V3<F> gl[3], ga[3];
     for (int b = 0; b < 3; b++) {
       const auto onb = Ro.sB == b, ona = Ro.sA == b;
-      fclk[b] = rowsum3(sel3(onb, kfl, kz3) - sel3(ona, kfl, kz3));
+      fcl[b] = rowsum3(sel3(onb, o.fl, z3) - sel3(ona, o.fl, z3));
       fcak[b] = rowsum3(sel3(onb, tB, kz3) - sel3(ona, tA, kz3));
-      fcl[b] = cvt3<F>(fclk[b]); fca[b] = cvt3<F>(fcak[b]);
-      const V3<K> glk = PK.mass * (cvt3<K>(Sm.al[b]) - l0k[b]) - fclk[b];
-      const V3<K> gak = inertia_mul(PK, kez[b], cvt3<K>(Sm.aa[b]) - a0k[b]) - fcak[b];
-      gn = gn + (SK(1) / PK.mass) * dot(glk, glk) + dot(gak, inv_inertia(PK, kez[b], gak));
-      gl[b] = cvt3<F>(glk); ga[b] = cvt3<F>(gak);
-      cfrc_max = max_(cfrc_max, max_(max_(max_(abs_(fcl[b].x), abs_(fcl[b].y)), abs_(fcl[b].z)), max_(max_(abs_(fca[b].x), abs_(fca[b].y)), abs_(fca[b].z))));
+      gl[b] = P.mass * dl[b] - fcl[b];
+      const V3<K> kz = ld3(M.kd, KEZ + 3 * b);
+      const V3<K> gak = inertia_mul(PK, kz, cvt3<K>(da[b])) - fcak[b];
+      gn = gn + cvt<K>(im * dot(gl[b], gl[b])) + dot(gak, inv_inertia(PK, kz, gak));
+      ga[b] = cvt3<F>(gak);
+      const V3<F> fa = cvt3<F>(fcak[b]);
+      cfrc_max = max_(cfrc_max, max_(max_(max_(abs_(fcl[b].x), abs_(fcl[b].y)), abs_(fcl[b].z)), max_(max_(abs_(fa.x), abs_(fa.y)), abs_(fa.z))));
     }
     if (LAST) bar_force = rowsum(sel(Ro.is_pair, sqrt_(dot(o.fl, o.fl)), zero));
     conv = conv | !(gn >= PK.tol * PK.tol);
@@ -746,10 +770,13 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<K,
     }
     for (int i = 0; i < 6; i++) { H.O10[i] = zero; H.O20[i] = zero; H.O21[i] = zero; }
     static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<0, decltype(cc)::value>(H, dc, c, o); });
+    // which bar pairs does any environment of the wavefront couple?  (uniform: lets the factorisation skip zero blocks)
+    const bool cp0 = any_slot<6>(c.active) || any_slot<7>(c.active), cp1 = any_slot<8>(c.active) || any_slot<9>(c.active),
+               cp2 = any_slot<10>(c.active) || any_slot<11>(c.active);
     // direction
     F gd[3], pr[3][6];
     for (int b = 0; b < 3; b++) gd[b] = sel(Ro.is_dof, sel(Ro.is_ang, pick_comp(Ro.k, ga[b]), pick_comp(Ro.k, gl[b])), zero);
-    newton_direction(H, gd, pr);
+    newton_direction(H, gd, pr, cp0, cp1, cp2);
     V3<F> pl[3], pa[3];
     for (int b = 0; b < 3; b++) {
       pl[b] = sel3(conv, z3, mk<F>(pr[b][0], pr[b][1], pr[b][2]));
@@ -759,7 +786,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<K,
     F g1 = zero, g2 = zero, d0 = zero;
     for (int b = 0; b < 3; b++) {
       const V3<F> Ipa = inertia_mul(P, ez[b], pa[b]);
-      g1 = g1 + P.mass * dot(pl[b], Sm.al[b] - l0[b]) + dot(Ipa, Sm.aa[b] - a0[b]);
+      g1 = g1 + P.mass * dot(pl[b], dl[b]) + dot(Ipa, da[b]);
       g2 = g2 + P.mass * dot(pl[b], pl[b]) + dot(Ipa, pa[b]);
       d0 = d0 + dot(pl[b], gl[b]) + dot(pa[b], ga[b]);
     }
@@ -790,7 +817,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<K,
       alpha = sel(go, na, alpha);
       if (!any_lane(!ls_done) || k + 1 >= P.ls_iter) break;
     }
-    for (int b = 0; b < 3; b++) { Sm.al[b] = Sm.al[b] + alpha * pl[b]; Sm.aa[b] = Sm.aa[b] + alpha * pa[b]; }
+    for (int b = 0; b < 3; b++) { dl[b] = dl[b] + alpha * pl[b]; da[b] = da[b] + alpha * pa[b]; }
   }
   lag.n_it += n_it; lag.n_ls += n_ls;
   lag.n_unconv = lag.n_unconv + sel(conv, zero, F(S(1)));
@@ -798,27 +825,34 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<K,
     lag.cfrc_absmax = cfrc_max;
     F sq = zero;
     for (int b = 0; b < 3; b++) {
+      const V3<F> fa = cvt3<F>(fcak[b]);
       const V3<F> a = mk<F>(clamp_(fcl[b].x, F(P.cf_lo), F(P.cf_hi)), clamp_(fcl[b].y, F(P.cf_lo), F(P.cf_hi)), clamp_(fcl[b].z, F(P.cf_lo), F(P.cf_hi)));
-      const V3<F> t = mk<F>(clamp_(fca[b].x, F(P.cf_lo), F(P.cf_hi)), clamp_(fca[b].y, F(P.cf_lo), F(P.cf_hi)), clamp_(fca[b].z, F(P.cf_lo), F(P.cf_hi)));
+      const V3<F> t = mk<F>(clamp_(fa.x, F(P.cf_lo), F(P.cf_hi)), clamp_(fa.y, F(P.cf_lo), F(P.cf_hi)), clamp_(fa.z, F(P.cf_lo), F(P.cf_hi)));
       sq = sq + dot(a, a) + dot(t, t);
     }
     lag.cfrc_clip_sq = sq;
     lag.bar_contact = bar_force;
+    for (int b = 0; b < 3; b++) {  // qacc of the last forward pass (what mujoco keeps as qacc_warmstart)
+      lag.al[b] = cvt3<F>(ld3(M.kd, KL0 + 3 * b)) + dl[b];
+      lag.aa[b] = cvt3<F>(ld3(M.kd, KA0 + 3 * b)) + da[b];
+    }
   }
   // ---- implicitfast: (M + h sum_t b_t J_t J_t^T) a_new = F_smooth + F_constraint  (Woodbury over the nine tendons, tendon role).
-  // yl/ya: the correction to the unconstrained acceleration (constraint part + damping part); a0 itself stays in K
-  V3<F> yl[3], ya[3];
-  V3<K> ylk[3], yak[3];  // acceleration by the constraint wrench (K)
-  for (int b = 0; b < 3; b++) {
-    ylk[b] = (SK(1) / PK.mass) * fclk[b]; yak[b] = inv_inertia(PK, kez[b], fcak[b]);
-    yl[b] = cvt3<F>(ylk[b]); ya[b] = cvt3<F>(yak[b]);
-  }
+  V3<K> yak[3];          // angular acceleration by the constraint torque (K)
+  V3<F> ylc[3];          // linear acceleration by the constraint force
+  V3<F> yl[3], ya[3];    // the damping correction
   {
-    const F sc = sqrt_(P.h * tdamp);
-    const V3<F> us = sc * tu, mas = sc * tma, mbs = sc * tmb;
+    V3<F> fl_[3], fa_[3];  // acceleration before the damping correction
+    for (int b = 0; b < 3; b++) {
+      const V3<K> kz = ld3(M.kd, KEZ + 3 * b);
+      yak[b] = inv_inertia(PK, kz, fcak[b]);
+      ylc[b] = im * fcl[b];
+      fl_[b] = cvt3<F>(ld3(M.kd, KL0 + 3 * b)) + ylc[b];
+      fa_[b] = cvt3<F>(ld3(M.kd, KA0 + 3 * b) + yak[b]);
+    }
+    const F sc = sqrt_(P.h * M.td.ld(TDAMP));
+    const V3<F> us = sc * ld3(M.td, TU), mas = sc * ld3(M.td, TMA), mbs = sc * ld3(M.td, TMB);
     const V3<F> was = inv_inertia(P, pick_bar(Ro.ba, ez), mas), wbs = inv_inertia(P, pick_bar(Ro.bb, ez), mbs);
-    V3<F> fl_[3], fa_[3];
-    for (int b = 0; b < 3; b++) { fl_[b] = l0[b] + yl[b]; fa_[b] = a0[b] + ya[b]; }
     F zt = dot(us, pick_bar(Ro.bb, fl_) - pick_bar(Ro.ba, fl_)) + dot(mbs, pick_bar(Ro.bb, fa_)) - dot(mas, pick_bar(Ro.ba, fa_));
     F Sr[9], il9[9];
     static_for<9>([&](auto sc_) {
@@ -838,7 +872,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<K,
     F zr[9], zd, zrep[9];
     rgather<9>(zt, zr);
     rbwd<9>(Sr, il9, zr, zd, zrep);
-    for (int b = 0; b < 3; b++) {  // from here on yl / ya hold only the damping correction
+    for (int b = 0; b < 3; b++) {
       const auto ona = Ro.ba == b, onb = Ro.bb == b;
       const F ca = sel(ona, zd, zero) - sel(onb, zd, zero);
       yl[b] = rowsum3((ca * im) * us);
@@ -847,11 +881,11 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<K,
   }
   // ---- advance: v += h a ; x += h v ; q <- exp(h w / 2) * q   (world-frame w: left multiplication)
   for (int b = 0; b < 3; b++) {
-    const V3<K> vk = cvt3<K>(Sm.v[b]) + PK.h * ((l0k[b] + ylk[b]) + cvt3<K>(yl[b]));
-    const V3<K> wk = cvt3<K>(Sm.w[b]) + PK.h * ((a0k[b] + yak[b]) + cvt3<K>(ya[b]));
-    Sm.v[b] = cvt3<F>(vk);
-    Sm.w[b] = cvt3<F>(wk);
-    Sm.x[b] = Sm.x[b] + PK.h * vk;
+    const V3<K> vk = cvt3<K>(ld3(M.fd, FV + 3 * b)) + PK.h * (ld3(M.kd, KL0 + 3 * b) + cvt3<K>(ylc[b] + yl[b]));
+    const V3<K> wk = cvt3<K>(ld3(M.fd, FW + 3 * b)) + PK.h * ((ld3(M.kd, KA0 + 3 * b) + yak[b]) + cvt3<K>(ya[b]));
+    st3(M.fd, FV + 3 * b, cvt3<F>(vk));
+    st3(M.fd, FW + 3 * b, cvt3<F>(wk));
+    st3(M.kd, KX + 3 * b, ld3(M.kd, KX + 3 * b) + PK.h * vk);
     const V3<K> w = wk;
     const SK hh = SK(0.5) * PK.h;
     const K x2 = (hh * hh) * dot(w, w);
@@ -860,15 +894,18 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<K,
     const K cs = SK(1) + x2 * (SK(-0.5) + x2 * (SK(1.0 / 24) + x2 * (SK(-1.0 / 720) + x2 * (SK(1.0 / 40320) + x2 * (SK(-1.0 / 3628800) + x2 * SK(1.0 / 479001600))))));
     const K k = hh * sinc;
     const K rw = cs, rx = k * w.x, ry = k * w.y, rz = k * w.z;
-    K* q = Sm.q[b];
-    const K nw = rw * q[0] - rx * q[1] - ry * q[2] - rz * q[3];
-    const K nx = rw * q[1] + rx * q[0] + ry * q[3] - rz * q[2];
-    const K ny = rw * q[2] - rx * q[3] + ry * q[0] + rz * q[1];
-    const K nz = rw * q[3] + rx * q[2] - ry * q[1] + rz * q[0];
-    q[0] = nw; q[1] = nx; q[2] = ny; q[3] = nz;
+    K q[4] = {M.kd.ld(KQ + 4 * b), M.kd.ld(KQ + 4 * b + 1), M.kd.ld(KQ + 4 * b + 2), M.kd.ld(KQ + 4 * b + 3)};
+    normalize_quat(q);  // (the same normalisation the sub-step started from)
+    M.kd.st(KQ + 4 * b, rw * q[0] - rx * q[1] - ry * q[2] - rz * q[3]);
+    M.kd.st(KQ + 4 * b + 1, rw * q[1] + rx * q[0] + ry * q[3] - rz * q[2]);
+    M.kd.st(KQ + 4 * b + 2, rw * q[2] - rx * q[3] + ry * q[0] + rz * q[1]);
+    M.kd.st(KQ + 4 * b + 3, rw * q[3] + rx * q[2] - ry * q[1] + rz * q[0]);
   }
   if (MODEL) {
-    for (int a = 0; a < 6; a++) Sm.act[a] = Sm.act[a] + P.h * (clamp_(Sm.ctrl[a], F(P.ctrl_lo), F(P.ctrl_hi)) - Sm.act[a]) * P.act_itau;
+    for (int a = 0; a < 6; a++) {
+      const F ac = M.fd.ld(FACT + a);
+      M.fd.st(FACT + a, ac + P.h * (clamp_(M.fd.ld(FCTRL + a), F(P.ctrl_lo), F(P.ctrl_hi)) - ac) * P.act_itau);
+    }
   }
 }
 }  // namespace row

@@ -760,40 +760,76 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
 // split the work by role.  No LDS in the physics (the observation tile is the only shared memory), no barrier inside a sub-step.
 // T: type of the state arrays / outputs; TK: type of pose, kinematics and tendon geometry inside the kernel (double in production).
 constexpr int ROW_ENVS = 16;  // environments per 256-thread block
+#ifndef TGR_ROW_WAVES
+#define TGR_ROW_WAVES 1       // wavefronts per SIMD the row kernels are compiled for (register budget 512 / TGR_ROW_WAVES)
+#endif
 
 template <typename T, typename TK> struct RowArgs { row::RParams<T> P; row::RParams<TK> PK; };
 
-template <typename T, typename TK>
-TGR_DEV void row_load(const T* st, int m, int e, row::RSim<TK, T>& S) {
+// the row's state slabs in shared memory (tgr_row.h RMem): written and read by the 16 lanes of the row alone, so no barrier guards them
+template <typename T, typename TK> struct RowShared {
+  TK kd[ROW_ENVS * row::K_SLAB];
+  TK rd[row::R_SLAB * 16];
+  T fd[ROW_ENVS * row::F_SLAB];
+  T td[ROW_ENVS * row::T_SLAB * 16];
+  T tile[ROW_ENVS * 49];
+};
+template <typename T, typename TK> TGR_DEV row::RMem<TK, T> row_mem(RowShared<T, TK>& sh, int slot, int r) {
+  row::RMem<TK, T> M;
+  M.kd = row::Slab<TK>{sh.kd + slot * row::K_SLAB, 1, 0};
+  M.fd = row::Slab<T>{sh.fd + slot * row::F_SLAB, 1, 0};
+  M.td = row::Slab<T>{sh.td + slot * row::T_SLAB * 16, 16, r};
+  M.rd = row::Slab<TK>{sh.rd, 16, r};
+  return M;
+}
+// state of the block kernels' layout -> the row's slabs
+template <typename T, typename TK> TGR_DEV void row_import(const Sim<T>& S, const row::RMem<TK, T>& M) {
 #pragma unroll
   for (int b = 0; b < 3; b++) {
-    S.x[b] = row::mk<TK>(TK(st[(F_QPOS + 7 * b + 0) * m + e]), TK(st[(F_QPOS + 7 * b + 1) * m + e]), TK(st[(F_QPOS + 7 * b + 2) * m + e]));
+    M.kd.st(row::KX + 3 * b, TK(S.x[b].x)); M.kd.st(row::KX + 3 * b + 1, TK(S.x[b].y)); M.kd.st(row::KX + 3 * b + 2, TK(S.x[b].z));
 #pragma unroll
-    for (int i = 0; i < 4; i++) S.q[b][i] = TK(st[(F_QPOS + 7 * b + 3 + i) * m + e]);
-    row::normalize_quat(S.q[b]);
-    const row::Rot<TK> R = row::quat_rot(S.q[b]);
-    S.v[b] = row::mk<T>(st[(F_QVEL + 6 * b + 0) * m + e], st[(F_QVEL + 6 * b + 1) * m + e], st[(F_QVEL + 6 * b + 2) * m + e]);
-    const row::V3<TK> wb = row::mk<TK>(TK(st[(F_QVEL + 6 * b + 3) * m + e]), TK(st[(F_QVEL + 6 * b + 4) * m + e]), TK(st[(F_QVEL + 6 * b + 5) * m + e]));
-    S.w[b] = row::cvt3<T>(row::rot_apply(R, wb));
-    S.al[b] = row::mk<T>(T(0), T(0), T(0)); S.aa[b] = S.al[b];  // every solve starts from the unconstrained acceleration
+    for (int i = 0; i < 4; i++) M.kd.st(row::KQ + 4 * b + i, TK(S.q[b][i]));
+    M.fd.st(row::FV + 3 * b, S.v[b].x); M.fd.st(row::FV + 3 * b + 1, S.v[b].y); M.fd.st(row::FV + 3 * b + 2, S.v[b].z);
+    M.fd.st(row::FW + 3 * b, S.w[b].x); M.fd.st(row::FW + 3 * b + 1, S.w[b].y); M.fd.st(row::FW + 3 * b + 2, S.w[b].z);
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) { S.ctrl[i] = st[(F_CTRL + i) * m + e]; S.act[i] = st[(F_ACT + i) * m + e]; }
+  for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, S.ctrl[i]); M.fd.st(row::FACT + i, S.act[i]); }
+}
+template <typename T, typename TK> TGR_DEV void row_load(const T* st, int m, int e, const row::RMem<TK, T>& M) {
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) M.kd.st(row::KX + 3 * b + i, TK(st[(F_QPOS + 7 * b + i) * m + e]));
+    TK q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = TK(st[(F_QPOS + 7 * b + 3 + i) * m + e]);
+    row::normalize_quat(q);
+#pragma unroll
+    for (int i = 0; i < 4; i++) M.kd.st(row::KQ + 4 * b + i, q[i]);
+    const row::Rot<TK> R = row::quat_rot(q);
+#pragma unroll
+    for (int i = 0; i < 3; i++) M.fd.st(row::FV + 3 * b + i, st[(F_QVEL + 6 * b + i) * m + e]);
+    const row::V3<TK> wb = row::mk<TK>(TK(st[(F_QVEL + 6 * b + 3) * m + e]), TK(st[(F_QVEL + 6 * b + 4) * m + e]), TK(st[(F_QVEL + 6 * b + 5) * m + e]));
+    row::st3(M.fd, row::FW + 3 * b, row::cvt3<T>(row::rot_apply(R, wb)));
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, st[(F_CTRL + i) * m + e]); M.fd.st(row::FACT + i, st[(F_ACT + i) * m + e]); }
 }
 // the env layer (finish_lane, settle_period_done, make_obs ...) works on the block kernels' structs
 template <typename T, typename TK>
-TGR_DEV void row_export(const row::RSim<TK, T>& R, const row::RLag<TK, T>& rl, Sim<T>& S, Lag<T>& lag) {
+TGR_DEV void row_export(const row::RMem<TK, T>& M, const row::RLag<TK, T>& rl, Sim<T>& S, Lag<T>& lag) {
 #pragma unroll
   for (int b = 0; b < 3; b++) {
-    S.x[b] = mk(T(R.x[b].x), T(R.x[b].y), T(R.x[b].z));
-    S.v[b] = mk(R.v[b].x, R.v[b].y, R.v[b].z); S.w[b] = mk(R.w[b].x, R.w[b].y, R.w[b].z);
-    S.al[b] = mk(R.al[b].x, R.al[b].y, R.al[b].z); S.aa[b] = mk(R.aa[b].x, R.aa[b].y, R.aa[b].z);
+    S.x[b] = mk(T(M.kd.ld(row::KX + 3 * b)), T(M.kd.ld(row::KX + 3 * b + 1)), T(M.kd.ld(row::KX + 3 * b + 2)));
+    S.v[b] = mk(M.fd.ld(row::FV + 3 * b), M.fd.ld(row::FV + 3 * b + 1), M.fd.ld(row::FV + 3 * b + 2));
+    S.w[b] = mk(M.fd.ld(row::FW + 3 * b), M.fd.ld(row::FW + 3 * b + 1), M.fd.ld(row::FW + 3 * b + 2));
+    S.al[b] = mk(rl.al[b].x, rl.al[b].y, rl.al[b].z); S.aa[b] = mk(rl.aa[b].x, rl.aa[b].y, rl.aa[b].z);
     lag.x[b] = mk(T(rl.x[b].x), T(rl.x[b].y), T(rl.x[b].z)); lag.z[b] = mk(T(rl.z[b].x), T(rl.z[b].y), T(rl.z[b].z));
 #pragma unroll
-    for (int i = 0; i < 4; i++) { S.q[b][i] = T(R.q[b][i]); lag.q[b][i] = T(rl.q[b][i]); }
+    for (int i = 0; i < 4; i++) { S.q[b][i] = T(M.kd.ld(row::KQ + 4 * b + i)); lag.q[b][i] = T(rl.q[b][i]); }
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) { S.ctrl[i] = R.ctrl[i]; S.act[i] = R.act[i]; }
+  for (int i = 0; i < 6; i++) { S.ctrl[i] = M.fd.ld(row::FCTRL + i); S.act[i] = M.fd.ld(row::FACT + i); }
 #pragma unroll
   for (int i = 0; i < 9; i++) lag.tenL[i] = rl.tenL[i];
   lag.cfrc_absmax = rl.cfrc_absmax; lag.cfrc_clip_sq = rl.cfrc_clip_sq; lag.bar_contact = rl.bar_contact;
@@ -805,8 +841,8 @@ template <typename T, typename TK> TGR_DEV void row_lag_init(row::RLag<TK, T>& r
   for (int i = 0; i < 9; i++) rl.tenL[i] = T(0);
 }
 
-template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256) void step_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
-  __shared__ T tile[ROW_ENVS * 49];
+template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, TGR_ROW_WAVES) void step_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
+  __shared__ RowShared<T, TK> sh;
   const int r = (int)(threadIdx.x & 15u);
   const int slot = (int)(threadIdx.x >> 4);  // environment of this row within the block
   const int gid = blockIdx.x * ROW_ENVS + slot;
@@ -822,42 +858,34 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256) 
   const int D = E.obs_dim;
   const int Dp = (D & 1) ? D : D + 1;
   if (__any(active)) {  // (a wavefront of idle donor rows has nothing to do; the block still meets at the tile barrier below)
-    row::RSim<TK, T> R;
+    const row::RMem<TK, T> M = row_mem<T, TK>(sh, slot, r);
     int episode = k.ist[I_EPISODE * m + e];
     if (donor_run && phase == PH_INIT) {
       Sim<T> S0;
       init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S0);
-#pragma unroll
-      for (int b = 0; b < 3; b++) {
-        R.x[b] = row::mk<TK>(TK(S0.x[b].x), TK(S0.x[b].y), TK(S0.x[b].z));
-#pragma unroll
-        for (int i = 0; i < 4; i++) R.q[b][i] = TK(S0.q[b][i]);
-        R.v[b] = row::mk<T>(S0.v[b].x, S0.v[b].y, S0.v[b].z); R.w[b] = row::mk<T>(S0.w[b].x, S0.w[b].y, S0.w[b].z);
-        R.al[b] = row::mk<T>(T(0), T(0), T(0)); R.aa[b] = R.al[b];
-      }
-#pragma unroll
-      for (int i = 0; i < 6; i++) { R.ctrl[i] = S0.ctrl[i]; R.act[i] = S0.act[i]; }
+      row_import<T, TK>(S0, M);
       phase = total;
       if (valid && r == 0) { k.ist[I_SRC * m + e] = e; k.ist[I_SRCEP * m + e] = episode; k.ist[I_EPISODE * m + e] = episode + 1; }
     } else {
-      row_load<T, TK>(k.st, m, e, R);
+      row_load<T, TK>(k.st, m, e, M);
     }
     if (live) {
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         const T a = T(k.actions[e * 6 + i]);
-        R.ctrl[i] = E.env_kind == TGR_ENV_TR ? R.ctrl[i] + (a - R.ctrl[i]) * E.dt : a;  // tr_env: _action_filter, k_FILTER = 1
+        const T c0 = M.fd.ld(row::FCTRL + i);
+        M.fd.st(row::FCTRL + i, E.env_kind == TGR_ENV_TR ? c0 + (a - c0) * E.dt : a);  // tr_env: _action_filter, k_FILTER = 1
       }
     }
-    const row::Roles<TK, T> Ro = row::make_roles<TK, T, TK, MODEL>(ra.PK);
+    const row::Roles<T> Ro = row::make_roles<TK, T, TK, MODEL>(ra.PK, M.rd);
     row::RLag<TK, T> rl;
     row_lag_init<T, TK>(rl);
 #pragma unroll 1
-    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, Ro, R, rl);
-    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, Ro, R, rl);
+    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, Ro, M, rl);
+    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, Ro, M, rl);
     Sim<T> S;
     Lag<T> lag;
-    row_export<T, TK>(R, rl, S, lag);
+    row_export<T, TK>(M, rl, S, lag);
     const bool w0 = r == 0;  // one lane of the row owns the env's global stores
     if ((threadIdx.x & 63u) == 0) {
       atomicAdd(&k.counters[3], (unsigned long long)lag.n_it);
@@ -869,7 +897,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256) 
       const int nact = __popcll(__ballot(active && w0));
       if ((threadIdx.x & 63u) == 0) atomicAdd(&k.counters[7], (unsigned long long)(nact * E.frame_skip));
     }
-    finish_lane(k, S, lag, e, valid, live, active, w0, phase, total, tile + slot * Dp);
+    finish_lane(k, S, lag, e, valid, live, active, w0, phase, total, sh.tile + slot * Dp);
   }
   // observations of the live envs of this block leave through the tile: coalesced stores into the [N][D] buffer
   const int base = blockIdx.x * ROW_ENVS;
@@ -878,14 +906,14 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256) 
     __syncthreads();
     for (int f = (int)threadIdx.x; f < rows * D; f += 256) {
       int rr = f / D, c = f - rr * D;
-      k.obs[(size_t)base * D + f] = tile[rr * Dp + c];
+      k.obs[(size_t)base * D + f] = sh.tile[rr * Dp + c];
     }
   }
 }
 
 // reset_model() in one go, row layout: one row per entry of list[] (tgr_reset, and live envs that found no ready donor)
-template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256) void settle_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
-  __shared__ T tile[ROW_ENVS * 49];
+template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, TGR_ROW_WAVES) void settle_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
+  __shared__ RowShared<T, TK> sh;
   const int r = (int)(threadIdx.x & 15u);
   const int slot = (int)(threadIdx.x >> 4);
   const int count = *k.list_count;
@@ -900,22 +928,13 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256) 
   const int episode = k.ist[I_EPISODE * m + e];
   Sim<T> S;
   init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
-  row::RSim<TK, T> R;
-#pragma unroll
-  for (int b = 0; b < 3; b++) {
-    R.x[b] = row::mk<TK>(TK(S.x[b].x), TK(S.x[b].y), TK(S.x[b].z));
-#pragma unroll
-    for (int i = 0; i < 4; i++) R.q[b][i] = TK(S.q[b][i]);
-    R.v[b] = row::mk<T>(S.v[b].x, S.v[b].y, S.v[b].z); R.w[b] = row::mk<T>(S.w[b].x, S.w[b].y, S.w[b].z);
-    R.al[b] = row::mk<T>(T(0), T(0), T(0)); R.aa[b] = R.al[b];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) { R.ctrl[i] = S.ctrl[i]; R.act[i] = S.act[i]; }
+  const row::RMem<TK, T> M = row_mem<T, TK>(sh, slot, r);
+  row_import<T, TK>(S, M);
   RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
   ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
   int step_num = 0;
   const int total = settle_total(E);
-  const row::Roles<TK, T> Ro = row::make_roles<TK, T, TK, MODEL>(ra.PK);
+  const row::Roles<T> Ro = row::make_roles<TK, T, TK, MODEL>(ra.PK, M.rd);
   row::RLag<TK, T> rl;
   row_lag_init<T, TK>(rl);
   Lag<T> lag;
@@ -926,9 +945,9 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256) 
 #pragma unroll 1
   for (int st = 0; st < total; st++) {
 #pragma unroll 1
-    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, Ro, R, rl);
-    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, Ro, R, rl);
-    row_export<T, TK>(R, rl, S, lag);
+    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, Ro, M, rl);
+    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, Ro, M, rl);
+    row_export<T, TK>(M, rl, S, lag);
     // the heading deque lives in global memory: one lane of the row pushes (the others would push the same value again)
     if (w0) settle_period_done(P, E, lag, st, ring, step_num, reset_psi, ms, xy_prev, lane_key(E, n, e), (unsigned long long)(unsigned)episode);
   }
@@ -945,7 +964,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256) 
   atomicAdd(&k.counters[1], 1ull);
   if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
   const int D = E.obs_dim;
-  T* orow = tile + slot * ((D & 1) ? D : D + 1);
+  T* orow = sh.tile + slot * ((D & 1) ? D : D + 1);
   make_obs(P, E, S, lag, wb, ms, orow);
   if (E.use_obs_noise) apply_obs_noise(E, lane_key(E, n, e), (unsigned)episode, 0, orow);
   T* op = e < n ? (k.obs_reset ? k.obs_reset + (size_t)e * D : nullptr) : k.dobs + (size_t)(e - n) * D;
@@ -1481,9 +1500,13 @@ template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, 
     fill_row_args<T>(h, k, ra);
     hipLaunchKernelGGL((settle_kernel_row<T, double, 0>), dim3((cnt + ROW_ENVS - 1) / ROW_ENVS), dim3(256), 0, s, k, ra);
   } else {
+#ifndef TGR_FAST_BUILD
     int blocks = (cnt + LW - 1) / LW;
     if (h->cfg.model_kind) hipLaunchKernelGGL((settle_kernel<T, LW, 1>), dim3(blocks), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((settle_kernel<T, LW, 0>), dim3(blocks), dim3(256), 0, s, k);
+#else
+    h->err = "development build (TGR_FAST_BUILD): block kernels not compiled"; return TGR_ERR_UNSUPPORTED;
+#endif
   }
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->list_count, 0, sizeof(int), s));
@@ -1494,7 +1517,12 @@ extern "C" int tgr_reset(tgr_handle* h, const uint8_t* mask_host, void* obs_dev,
   if (!h) return TGR_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)hip_stream;
+#ifdef TGR_FAST_BUILD  // development build: fp32 row kernels only (compiles in a fraction of the time)
+  if (h->cfg.precision == TGR_PRECISION_F64) { h->err = "development build (TGR_FAST_BUILD): fp32 only"; return TGR_ERR_UNSUPPORTED; }
+  return reset_impl<float>(h, mask_host, obs_dev, s);
+#else
   return h->cfg.precision == TGR_PRECISION_F64 ? reset_impl<double>(h, mask_host, obs_dev, s) : reset_impl<float>(h, mask_host, obs_dev, s);
+#endif
 }
 
 template <typename T>
@@ -1515,9 +1543,13 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
     fill_row_args<T>(h, k, ra);
     hipLaunchKernelGGL((step_kernel_row<T, double, 0>), dim3((h->m + ROW_ENVS - 1) / ROW_ENVS), dim3(256), 0, s, k, ra);
   } else {
+#ifndef TGR_FAST_BUILD
     int blocks = (h->m + LW - 1) / LW;
     if (h->cfg.model_kind) hipLaunchKernelGGL((step_kernel<T, LW, 1>), dim3(blocks), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((step_kernel<T, LW, 0>), dim3(blocks), dim3(256), 0, s, k);
+#else
+    h->err = "development build (TGR_FAST_BUILD): block kernels not compiled"; return TGR_ERR_UNSUPPORTED;
+#endif
   }
   HIP_TRY(h, hipGetLastError());
   if (h->cfg.auto_reset) {
@@ -1527,9 +1559,11 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
     if (rowk) {
       hipLaunchKernelGGL((settle_kernel_row<T, double, 0>), dim3((h->n + ROW_ENVS - 1) / ROW_ENVS), dim3(256), 0, s, k, ra);
     } else {
+#ifndef TGR_FAST_BUILD
       int sblocks = (h->n + LW - 1) / LW;
       if (h->cfg.model_kind) hipLaunchKernelGGL((settle_kernel<T, LW, 1>), dim3(sblocks), dim3(256), 0, s, k);
       else hipLaunchKernelGGL((settle_kernel<T, LW, 0>), dim3(sblocks), dim3(256), 0, s, k);
+#endif
     }
     HIP_TRY(h, hipGetLastError());
   }
@@ -1548,7 +1582,11 @@ extern "C" int tgr_step_f64(tgr_handle* h, const float* actions, double* obs, do
   if (!h) return TGR_ERR_INVALID;
   if (h->cfg.precision != TGR_PRECISION_F64) { h->err = "tgr_step_f64: handle is fp32, use tgr_step"; return TGR_ERR_INVALID; }
   HIP_TRY(h, hipSetDevice(h->device));
+#ifdef TGR_FAST_BUILD
+  h->err = "development build (TGR_FAST_BUILD): fp32 only"; return TGR_ERR_UNSUPPORTED;
+#else
   return step_impl<double>(h, actions, obs, reward, terminated, truncated, terminal_obs, info, (hipStream_t)hip_stream);
+#endif
 }
 
 // ---- state exchange (host arrays, double)

@@ -148,6 +148,18 @@ template <typename To, typename T> inline To cvt(const Ln<T>& x) { To r; for (in
 template <typename Fn, int... Is> TGR_RDEV void static_for_impl(Fn&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, typename Fn> TGR_RDEV void static_for(Fn&& f) { static_for_impl(static_cast<Fn&&>(f), std::make_integer_sequence<int, N>{}); }
 
+// A slab of lane values kept OUTSIDE the register file between uses: on the GPU a piece of LDS (all lanes of a row write the same
+// replicated value to the same address and read it back as a broadcast; lane-varying items use stride 16 + the lane as offset),
+// in the host emulation a plain array.  What lives here costs no register while the Newton solver runs.
+template <typename F> struct V3;
+template <typename L> struct Slab {
+  L* p; int stride, off;
+  TGR_RDEV L ld(int i) const { return p[i * stride + off]; }
+  TGR_RDEV void st(int i, L v) const { p[i * stride + off] = v; }
+};
+template <typename L> TGR_RDEV V3<L> ld3(const Slab<L>& s, int i);
+template <typename L> TGR_RDEV void st3(const Slab<L>& s, int i, V3<L> v);
+
 // ------------------------------------------------------------------ shared helpers (F = lane real: float/double or their Ln<>)
 template <typename F> TGR_RDEV F abs_(F x) { return sel(x < typename LaneTraits<F>::S(0), -x, x); }
 template <typename F> TGR_RDEV F max_(F a, F b) { return sel(a > b, a, b); }
@@ -166,6 +178,8 @@ template <typename F, typename B> TGR_RDEV V3<F> sel3(B c, V3<F> a, V3<F> b) { r
 template <int K, typename F> TGR_RDEV V3<F> bcast3(V3<F> a) { return mk<F>(bcast<K>(a.x), bcast<K>(a.y), bcast<K>(a.z)); }
 template <typename F> TGR_RDEV V3<F> rowsum3(V3<F> a) { return mk<F>(rowsum(a.x), rowsum(a.y), rowsum(a.z)); }
 template <typename To, typename From> TGR_RDEV V3<To> cvt3(V3<From> a) { return mk<To>(cvt<To>(a.x), cvt<To>(a.y), cvt<To>(a.z)); }
+template <typename L> TGR_RDEV V3<L> ld3(const Slab<L>& s, int i) { return mk<L>(s.ld(i), s.ld(i + 1), s.ld(i + 2)); }
+template <typename L> TGR_RDEV void st3(const Slab<L>& s, int i, V3<L> v) { s.st(i, v.x); s.st(i + 1, v.y); s.st(i + 2, v.z); }
 
 }  // namespace row
 }  // namespace tgr

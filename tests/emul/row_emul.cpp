@@ -46,39 +46,45 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
   RParams<TK> PK;
   fill_params<T>(params, P, hf, nrow, ncol);
   fill_params<TK>(params, PK, hf, nrow, ncol);
-  const Roles<K, F> Ro = make_roles<K, F, TK, MODEL>(PK);
   int bad = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : bad)
   for (int e = 0; e < n; e++) {
-    RSim<K, F> S;
+    K kd[K_SLAB], rd[R_SLAB];
+    F fd[F_SLAB], td[T_SLAB];
+    RMem<K, F> M;
+    M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0};
+    const Roles<F> Ro = make_roles<K, F, TK, MODEL>(PK, M.rd);
     RLag<K, F> lag;
     for (int b = 0; b < 3; b++) {
       const double* q = qpos + 21 * e + 7 * b;
-      S.x[b] = mk<K>(K(TK(q[0])), K(TK(q[1])), K(TK(q[2])));
-      for (int i = 0; i < 4; i++) S.q[b][i] = K(TK(q[3 + i]));
-      normalize_quat(S.q[b]);
-      const Rot<K> R = quat_rot(S.q[b]);
+      K qq[4];
+      for (int i = 0; i < 3; i++) kd[KX + 3 * b + i] = K(TK(q[i]));
+      for (int i = 0; i < 4; i++) qq[i] = K(TK(q[3 + i]));
+      normalize_quat(qq);
+      for (int i = 0; i < 4; i++) kd[KQ + 4 * b + i] = qq[i];
+      const Rot<K> R = quat_rot(qq);
       const double* v = qvel + 18 * e + 6 * b;
-      S.v[b] = mk<F>(F(T(v[0])), F(T(v[1])), F(T(v[2])));
-      S.w[b] = cvt3<F>(rot_apply(R, mk<K>(K(TK(v[3])), K(TK(v[4])), K(TK(v[5])))));
-      S.al[b] = mk<F>(F(T(0)), F(T(0)), F(T(0))); S.aa[b] = S.al[b];
+      for (int i = 0; i < 3; i++) fd[FV + 3 * b + i] = F(T(v[i]));
+      st3(M.fd, FW + 3 * b, cvt3<F>(rot_apply(R, mk<K>(K(TK(v[3])), K(TK(v[4])), K(TK(v[5]))))));
     }
-    for (int i = 0; i < 6; i++) { S.ctrl[i] = F(T(ctrl[6 * e + i])); S.act[i] = F(T(act[6 * e + i])); }
+    for (int i = 0; i < 6; i++) { fd[FCTRL + i] = F(T(ctrl[6 * e + i])); fd[FACT + i] = F(T(act[6 * e + i])); }
     lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = F(T(0)); lag.cfrc_absmax = F(T(0)); lag.cfrc_clip_sq = F(T(0)); lag.bar_contact = F(T(0)); lag.overflow = F(T(0));
-    for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, Ro, S, lag);
-    substep<K, F, TK, T, MODEL, true>(PK, P, Ro, S, lag);
+    for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, Ro, M, lag);
+    substep<K, F, TK, T, MODEL, true>(PK, P, Ro, M, lag);
     for (int b = 0; b < 3; b++) {
-      normalize_quat(S.q[b]);
-      const Rot<K> R = quat_rot(S.q[b]);
-      const V3<K> wb = rot_applyT(R, cvt3<K>(S.w[b]));
+      K qq[4] = {kd[KQ + 4 * b], kd[KQ + 4 * b + 1], kd[KQ + 4 * b + 2], kd[KQ + 4 * b + 3]};
+      normalize_quat(qq);
+      const Rot<K> R = quat_rot(qq);
+      const V3<K> wb = rot_applyT(R, cvt3<K>(ld3(M.fd, FW + 3 * b)));
       double* q = qpos + 21 * e + 7 * b;
       double* v = qvel + 18 * e + 6 * b;
-      bad += check_rep(S.x[b].x, "x", e) + check_rep(S.q[b][0], "q", e) + check_rep(S.v[b].z, "v", e) + check_rep(wb.x, "w", e) + check_rep(S.al[b].x, "a", e);
-      q[0] = S.x[b].x.v[0]; q[1] = S.x[b].y.v[0]; q[2] = S.x[b].z.v[0];
-      for (int i = 0; i < 4; i++) q[3 + i] = S.q[b][i].v[0];
-      v[0] = S.v[b].x.v[0]; v[1] = S.v[b].y.v[0]; v[2] = S.v[b].z.v[0]; v[3] = wb.x.v[0]; v[4] = wb.y.v[0]; v[5] = wb.z.v[0];
+      bad += check_rep(kd[KX + 3 * b], "x", e) + check_rep(qq[0], "q", e) + check_rep(fd[FV + 3 * b + 2], "v", e) + check_rep(wb.x, "w", e) + check_rep(lag.al[b].x, "a", e);
+      for (int i = 0; i < 3; i++) q[i] = kd[KX + 3 * b + i].v[0];
+      for (int i = 0; i < 4; i++) q[3 + i] = qq[i].v[0];
+      for (int i = 0; i < 3; i++) v[i] = fd[FV + 3 * b + i].v[0];
+      v[3] = wb.x.v[0]; v[4] = wb.y.v[0]; v[5] = wb.z.v[0];
     }
-    for (int i = 0; i < 6; i++) act[6 * e + i] = S.act[i].v[0];
+    for (int i = 0; i < 6; i++) act[6 * e + i] = fd[FACT + i].v[0];
     double* o = out + 32 * e;
     for (int t = 0; t < 9; t++) { o[t] = lag.tenL[t].v[0]; bad += check_rep(lag.tenL[t], "tenL", e); }
     for (int b = 0; b < 3; b++) { o[9 + 3 * b] = lag.x[b].x.v[0]; o[10 + 3 * b] = lag.x[b].y.v[0]; o[11 + 3 * b] = lag.x[b].z.v[0]; }
