@@ -29,7 +29,7 @@ template <typename S> struct RParams {
   S invweight;
   S tol, ls_tol;
   S cf_lo, cf_hi;
-  int max_iter, ls_iter, skip_clamped;
+  int max_iter, ls_iter, skip_clamped, warm_start;
   S act_itau;
   S hf_rx, hf_ry, hf_ez, hf_x0, hf_y0, hf_z0, hf_dx, hf_dy;
   int hf_nrow, hf_ncol;
@@ -66,6 +66,7 @@ template <typename K, typename F> struct RLag {
   V3<F> al[3], aa[3];  // qacc of the last forward pass (angular part in the world frame)
   F overflow;   // dropped bar-bar contacts in the last sub-step (a count, kept as a real)
   F n_unconv;   // sub-steps this environment left the solver at the iteration cap
+  F n_own;      // Newton iterations this environment itself still needed (the wavefront runs until its slowest one is done)
   int n_it, n_ls;
 };
 template <typename F> struct Rot { V3<F> ex, ey, ez; };
@@ -410,14 +411,19 @@ template <int N, typename F> TGR_RDEV void rsyrk(F* C, const F* X, const F* Y) {
     C[k] = s;
   });
 }
-// forward substitution y <- L^-1 y, y distributed (lane i holds y_i)
-template <int N, typename F> TGR_RDEV void rfwd(const F* Lr, const F* il, F& y) {
+// forward substitution L x = y: y distributed (lane i holds y_i; destroyed), the solution comes out REPLICATED in xr[N].
+// (lanes r <= j hold rounding dust in Lr[j] after rchol; their y is no longer read once x_r has been taken)
+template <int N, typename F> TGR_RDEV void rfwd(const F* Lr, const F* il, F& y, F* xr) {
   static_for<N>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    const F yj = bcast<j>(y) * il[j];
-    const auto r = lane_id();
-    y = sel(r == j, yj, sel(r > j, y - Lr[j] * yj, y));
+    const F xj = bcast<j>(y) * il[j];
+    xr[j] = xj;
+    y = y - Lr[j] * xj;
   });
+}
+// y <- y - X z  with z replicated (row i: y_i -= sum_m X_i[m] z[m])
+template <int N, typename F> TGR_RDEV void rgemv_rep(const F* X, const F* z, F& y) {
+  static_for<N>([&](auto mc) { constexpr int m = decltype(mc)::value; y = y - X[m] * z[m]; });
 }
 // y <- y - X z  with z distributed over the N lanes (row i: y_i -= sum_m X_i[m] z_m)
 template <int N, typename F> TGR_RDEV void rgemv(const F* X, F z, F& y) {
@@ -554,34 +560,31 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
   if (c02) rsyrk<6>(H.D[2], H.O20, H.O20);
   if (n21) rsyrk<6>(H.D[2], H.O21, H.O21);
   rchol<6>(H.D[2], il2);
-  // forward: L y = g
-  F y0 = gd[0], y1 = gd[1], y2 = gd[2];
-  rfwd<6>(H.D[0], il0, y0);
-  if (c01) rgemv<6>(H.O10, y0, y1);
-  if (c02) rgemv<6>(H.O20, y0, y2);
-  rfwd<6>(H.D[1], il1, y1);
-  if (n21) rgemv<6>(H.O21, y1, y2);
-  rfwd<6>(H.D[2], il2, y2);
+  // forward: L y = g  (the y of each block comes out replicated)
+  F y0 = gd[0], y1 = gd[1], y2 = gd[2], yr0[6], yr1[6], yr2[6];
+  rfwd<6>(H.D[0], il0, y0, yr0);
+  if (c01) rgemv_rep<6>(H.O10, yr0, y1);
+  if (c02) rgemv_rep<6>(H.O20, yr0, y2);
+  rfwd<6>(H.D[1], il1, y1, yr1);
+  if (n21) rgemv_rep<6>(H.O21, yr1, y2);
+  rfwd<6>(H.D[2], il2, y2, yr2);
   // backward: L^T x = y
-  F x0, x1, x2, t[6], yr[6];
-  rgather<6>(y2, yr);
-  rbwd<6>(H.D[2], il2, yr, x2, pr[2]);
-  rgather<6>(y1, yr);
+  F x0, x1, x2, t[6];
+  rbwd<6>(H.D[2], il2, yr2, x2, pr[2]);
   if (n21) {
     rgemvT<6>(H.O21, x2, t);
-    for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
+    for (int i = 0; i < 6; i++) yr1[i] = yr1[i] - t[i];
   }
-  rbwd<6>(H.D[1], il1, yr, x1, pr[1]);
-  rgather<6>(y0, yr);
+  rbwd<6>(H.D[1], il1, yr1, x1, pr[1]);
   if (c01) {
     rgemvT<6>(H.O10, x1, t);
-    for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
+    for (int i = 0; i < 6; i++) yr0[i] = yr0[i] - t[i];
   }
   if (c02) {
     rgemvT<6>(H.O20, x2, t);
-    for (int i = 0; i < 6; i++) yr[i] = yr[i] - t[i];
+    for (int i = 0; i < 6; i++) yr0[i] = yr0[i] - t[i];
   }
-  rbwd<6>(H.D[0], il0, yr, x0, pr[0]);
+  rbwd<6>(H.D[0], il0, yr0, x0, pr[0]);
   for (int b = 0; b < 3; b++)
     for (int i = 0; i < 6; i++) pr[b][i] = -pr[b][i];
 }
@@ -591,10 +594,11 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
 //   kd (K, replicated): pose x, q; unconstrained acceleration l0, a0; bar axes ez       fd (F, replicated): v, w, ctrl, act
 //   td (F, per lane):   tendon-role results u, ra x u, rb x u, damping                  rd (K, per lane, per block): tendon-role constants
 enum : int { KX = 0, KQ = 9, KL0 = 21, KA0 = 30, KEZ = 39, K_SLAB = 48 };
-enum : int { FV = 0, FW = 9, FCTRL = 18, FACT = 24, F_SLAB = 30 };
+enum : int { FV = 0, FW = 9, FCTRL = 18, FACT = 24, FDL = 30, FDA = 39, F_SLAB = 48 };  // FDL / FDA: last sub-step's d = a - a0
 enum : int { TU = 0, TMA = 3, TMB = 6, TDAMP = 9, T_SLAB = 10 };
+enum : int { AMB = 0, AMA = 3, AZB = 6, AZA = 9, A_SLAB = 12 };  // ad (K, per lane): my slot's axial levers z x r and axes z of its two bars
 enum : int { RSA = 0, RSB = 3, RTK = 6, RTB = 7, RTL0 = 8, R_SLAB = 9 };
-template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; };
+template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; };
 
 // `LAST`: what only the last sub-step of a control period records (lagged kinematics, tendon lengths, contact wrench).
 // K / PK: lane and scalar type of the pose, the kinematics, the tendon geometry and the smooth forces; F / P: of the rest.
@@ -613,6 +617,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
   V3<F> jl0, ja0;  // my slot's residual at the unconstrained acceleration: J (a0 + B v) + c0 n
   F dropped;
   {
+TGR_PHASE(0);
     // ---- kinematics (replicated)
     V3<K> kx[3], kex[3], key[3], kez[3];
     for (int b = 0; b < 3; b++) {
@@ -630,6 +635,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
     }
     V3<F> v[3], w[3];
     for (int b = 0; b < 3; b++) { v[b] = ld3(M.fd, FV + 3 * b); w[b] = ld3(M.fd, FW + 3 * b); }
+    TGR_PHASE(1);
     // ---- tendons (tendon role): geometry, force, Jacobian pieces; smooth wrench per bar (replicated)
     V3<F> l0[3], a0[3];
     {
@@ -682,6 +688,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
         l0[b] = cvt3<F>(l0k); a0[b] = cvt3<F>(a0k);
       }
     }
+    TGR_PHASE(2);
     // ---- contacts (slot role)
     {
       // caps on the floor: the distance is a small difference of pose quantities -> K
@@ -705,6 +712,13 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
       c.Dn = sel(Ro.is_cap, dn, sel(s0, p0.Dn, p1.Dn));
       c.active = sel(Ro.is_cap, dist < S(0), sel(Ro.is_pair, sel(s0, p0.active, p1.active), false));
       dropped = sel(Ro.is_pair & s0, dropped, zero);
+      // The torque of my contact force about the OWN AXIS of each of its bars is the one place where fp32 is not enough (1e-6 N m inside
+      // 10 N m cross products; the bar's inertia about that axis is 0.0038 kg m^2):  z . (r x f + t) = f . (z x r) + t . z, with the
+      // levers z x r in K.  For a cap the axial part of r drops out of z x r exactly, so only its small offset from the bar end is used.
+      const V3<K> kzA = pick_bar0(Ro.sA, kez);
+      const V3<K> offB = cvt3<K>(sel3(Ro.is_cap, c.rB - arm, c.rB));
+      st3(M.ad, AMB, cross(kzc, offB)); st3(M.ad, AMA, cross(kzA, cvt3<K>(c.rA)));
+      st3(M.ad, AZB, kzc); st3(M.ad, AZA, kzA);
     }
     // my slot's residual at the unconstrained acceleration
     {
@@ -724,41 +738,52 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
   dc.dof = Ro.is_dof; dc.ang = Ro.is_ang;
   dc.e = mk<F>(sel(Ro.is_dof & (Ro.k == 0), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 1), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 2), F(S(1)), zero));
   V3<F> dl[3], da[3];
-  for (int b = 0; b < 3; b++) { dl[b] = z3; da[b] = z3; }
+  // start: last sub-step's constraint acceleration d (P.warm_start) -- a contact's reference acceleration moves by ~B h a every sub-step, so
+  // last sub-step's ACCELERATION is a poor guess, but the part of it the contacts produced is a good one -- or zero
+  for (int b = 0; b < 3; b++) {
+    dl[b] = P.warm_start ? sel3(any_contact, ld3(M.fd, FDL + 3 * b), z3) : z3;
+    da[b] = P.warm_start ? sel3(any_contact, ld3(M.fd, FDA + 3 * b), z3) : z3;
+  }
   auto conv = !any_contact;
-  V3<F> fcl[3];   // constraint force per bar (replicated)
-  V3<K> fcak[3];  // constraint torque per bar: summed in K -- the torque about a bar's own axis is a 1e-6 N m question inside 10 N m
-                  // cross products (and I d cancels to Izz d along the axis)
+  V3<F> fcl[3], fca[3];  // constraint force / torque per bar (replicated)
+  K tax[3];              // ... and the torque about each bar's own axis once more, summed in K
   F cfrc_max = zero, bar_force = zero;
   int n_it = 0, n_ls = 0;
   for (int it = 0;; it++) {
+    TGR_PHASE(3);
     // my slot's residual jar at the current iterate
     const V3<F> dlA = pick_bar0(Ro.sA, dl), daA = pick_bar0(Ro.sA, da), dlB = pick_bar0(Ro.sB, dl), daB = pick_bar0(Ro.sB, da);
     const V3<F> jl = jl0 + ((dlB + cross(daB, c.rB)) - (dlA + cross(daA, c.rA)));
     const V3<F> ja = ja0 + (daB - daA);
     const RCone<F> o = cone_eval(P, c, jl, ja);
+    TGR_PHASE(4);
     // constraint wrench per bar, gradient
+    const V3<F> tB = cross(c.rB, o.fl) + o.fa, tA = cross(c.rA, o.fl) + o.fa;
     const V3<K> kfl = cvt3<K>(o.fl), kfa = cvt3<K>(o.fa);
-    const V3<K> tB = cross(cvt3<K>(c.rB), kfl) + kfa, tA = cross(cvt3<K>(c.rA), kfl) + kfa;
+    const K tauB = dot(kfl, ld3(M.ad, AMB)) + dot(kfa, ld3(M.ad, AZB)), tauA = dot(kfl, ld3(M.ad, AMA)) + dot(kfa, ld3(M.ad, AZA));
     K gn = kzero;  // g^T M^-1 g
     cfrc_max = zero;
     V3<F> gl[3], ga[3];
     for (int b = 0; b < 3; b++) {
       const auto onb = Ro.sB == b, ona = Ro.sA == b;
       fcl[b] = rowsum3(sel3(onb, o.fl, z3) - sel3(ona, o.fl, z3));
-      fcak[b] = rowsum3(sel3(onb, tB, kz3) - sel3(ona, tA, kz3));
+      fca[b] = rowsum3(sel3(onb, tB, z3) - sel3(ona, tA, z3));
+      tax[b] = rowsum(sel(onb, tauB, kzero) - sel(ona, tauA, kzero));
       gl[b] = P.mass * dl[b] - fcl[b];
-      const V3<K> kz = ld3(M.kd, KEZ + 3 * b);
-      const V3<K> gak = inertia_mul(PK, kz, cvt3<K>(da[b])) - fcak[b];
-      gn = gn + cvt<K>(im * dot(gl[b], gl[b])) + dot(gak, inv_inertia(PK, kz, gak));
-      ga[b] = cvt3<F>(gak);
-      const V3<F> fa = cvt3<F>(fcak[b]);
-      cfrc_max = max_(cfrc_max, max_(max_(max_(abs_(fcl[b].x), abs_(fcl[b].y)), abs_(fcl[b].z)), max_(max_(abs_(fa.x), abs_(fa.y)), abs_(fa.z))));
+      ga[b] = inertia_mul(P, ez[b], da[b]) - fca[b];
+      // M-norm of the residual: force and transverse torque in F, the axial torque from K
+      const K gax = PK.Izz * dot(ld3(M.kd, KEZ + 3 * b), cvt3<K>(da[b])) - tax[b];
+      const F gz = dot(ez[b], ga[b]);
+      gn = gn + cvt<K>(im * dot(gl[b], gl[b]) + (dot(ga[b], ga[b]) - gz * gz) * (S(1) / P.Ixx)) + gax * gax * (SK(1) / PK.Izz);
+      ga[b] = ga[b] + (cvt<F>(gax) - gz) * ez[b];  // the direction is solved for the same axial residual the test looks at
+      cfrc_max = max_(cfrc_max, max_(max_(max_(abs_(fcl[b].x), abs_(fcl[b].y)), abs_(fcl[b].z)), max_(max_(abs_(fca[b].x), abs_(fca[b].y)), abs_(fca[b].z))));
     }
     if (LAST) bar_force = rowsum(sel(Ro.is_pair, sqrt_(dot(o.fl, o.fl)), zero));
     conv = conv | !(gn >= PK.tol * PK.tol);
     if (!any_lane(!conv) || it >= P.max_iter) break;
     n_it++;
+    lag.n_own = lag.n_own + sel(conv, zero, F(S(1)));
+    TGR_PHASE(5);
     // Hessian rows (dof role)
     RHess<F> H;
     for (int b = 0; b < 3; b++) {
@@ -773,6 +798,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
     // which bar pairs does any environment of the wavefront couple?  (uniform: lets the factorisation skip zero blocks)
     const bool cp0 = any_slot<6>(c.active) || any_slot<7>(c.active), cp1 = any_slot<8>(c.active) || any_slot<9>(c.active),
                cp2 = any_slot<10>(c.active) || any_slot<11>(c.active);
+    TGR_PHASE(6);
     // direction
     F gd[3], pr[3][6];
     for (int b = 0; b < 3; b++) gd[b] = sel(Ro.is_dof, sel(Ro.is_ang, pick_comp(Ro.k, ga[b]), pick_comp(Ro.k, gl[b])), zero);
@@ -782,6 +808,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
       pl[b] = sel3(conv, z3, mk<F>(pr[b][0], pr[b][1], pr[b][2]));
       pa[b] = sel3(conv, z3, mk<F>(pr[b][3], pr[b][4], pr[b][5]));
     }
+    TGR_PHASE(7);
     // line search: Gauss part (replicated), cone part (slot role)
     F g1 = zero, g2 = zero, d0 = zero;
     for (int b = 0; b < 3; b++) {
@@ -819,13 +846,16 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
     }
     for (int b = 0; b < 3; b++) { dl[b] = dl[b] + alpha * pl[b]; da[b] = da[b] + alpha * pa[b]; }
   }
+  TGR_PHASE(8);
+  if (P.warm_start)
+    for (int b = 0; b < 3; b++) { st3(M.fd, FDL + 3 * b, sel3(any_contact, dl[b], z3)); st3(M.fd, FDA + 3 * b, sel3(any_contact, da[b], z3)); }
   lag.n_it += n_it; lag.n_ls += n_ls;
   lag.n_unconv = lag.n_unconv + sel(conv, zero, F(S(1)));
   if (LAST) {
     lag.cfrc_absmax = cfrc_max;
     F sq = zero;
     for (int b = 0; b < 3; b++) {
-      const V3<F> fa = cvt3<F>(fcak[b]);
+      const V3<F> fa = fca[b];
       const V3<F> a = mk<F>(clamp_(fcl[b].x, F(P.cf_lo), F(P.cf_hi)), clamp_(fcl[b].y, F(P.cf_lo), F(P.cf_hi)), clamp_(fcl[b].z, F(P.cf_lo), F(P.cf_hi)));
       const V3<F> t = mk<F>(clamp_(fa.x, F(P.cf_lo), F(P.cf_hi)), clamp_(fa.y, F(P.cf_lo), F(P.cf_hi)), clamp_(fa.z, F(P.cf_lo), F(P.cf_hi)));
       sq = sq + dot(a, a) + dot(t, t);
@@ -844,8 +874,10 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
   {
     V3<F> fl_[3], fa_[3];  // acceleration before the damping correction
     for (int b = 0; b < 3; b++) {
+      // angular acceleration by the constraint torque: transverse part from the F sum, axial part from the K sum
       const V3<K> kz = ld3(M.kd, KEZ + 3 * b);
-      yak[b] = inv_inertia(PK, kz, fcak[b]);
+      const V3<K> kf = cvt3<K>(fca[b]);
+      yak[b] = (SK(1) / PK.Ixx) * kf + (tax[b] * (SK(1) / PK.Izz) - dot(kz, kf) * (SK(1) / PK.Ixx)) * kz;
       ylc[b] = im * fcl[b];
       fl_[b] = cvt3<F>(ld3(M.kd, KL0 + 3 * b)) + ylc[b];
       fa_[b] = cvt3<F>(ld3(M.kd, KA0 + 3 * b) + yak[b]);
@@ -868,9 +900,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
       Sr[s] = sel(Ro.is_ten, v, zero);
     });
     rchol<9>(Sr, il9);
-    rfwd<9>(Sr, il9, zt);
     F zr[9], zd, zrep[9];
-    rgather<9>(zt, zr);
+    rfwd<9>(Sr, il9, zt, zr);
     rbwd<9>(Sr, il9, zr, zd, zrep);
     for (int b = 0; b < 3; b++) {
       const auto ona = Ro.ba == b, onb = Ro.bb == b;
@@ -879,6 +910,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
       ya[b] = rowsum3(sel(ona, zd, zero) * was - sel(onb, zd, zero) * wbs);
     }
   }
+  TGR_PHASE(9);
   // ---- advance: v += h a ; x += h v ; q <- exp(h w / 2) * q   (world-frame w: left multiplication)
   for (int b = 0; b < 3; b++) {
     const V3<K> vk = cvt3<K>(ld3(M.fd, FV + 3 * b)) + PK.h * (ld3(M.kd, KL0 + 3 * b) + cvt3<K>(ylc[b] + yl[b]));

@@ -770,6 +770,7 @@ template <typename T, typename TK> struct RowArgs { row::RParams<T> P; row::RPar
 template <typename T, typename TK> struct RowShared {
   TK kd[ROW_ENVS * row::K_SLAB];
   TK rd[row::R_SLAB * 16];
+  TK ad[ROW_ENVS * row::A_SLAB * 16];
   T fd[ROW_ENVS * row::F_SLAB];
   T td[ROW_ENVS * row::T_SLAB * 16];
   T tile[ROW_ENVS * 49];
@@ -780,6 +781,7 @@ template <typename T, typename TK> TGR_DEV row::RMem<TK, T> row_mem(RowShared<T,
   M.fd = row::Slab<T>{sh.fd + slot * row::F_SLAB, 1, 0};
   M.td = row::Slab<T>{sh.td + slot * row::T_SLAB * 16, 16, r};
   M.rd = row::Slab<TK>{sh.rd, 16, r};
+  M.ad = row::Slab<TK>{sh.ad + slot * row::A_SLAB * 16, 16, r};
   return M;
 }
 // state of the block kernels' layout -> the row's slabs
@@ -794,6 +796,8 @@ template <typename T, typename TK> TGR_DEV void row_import(const Sim<T>& S, cons
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, S.ctrl[i]); M.fd.st(row::FACT + i, S.act[i]); }
+#pragma unroll
+  for (int i = 0; i < 18; i++) M.fd.st(row::FDL + i, T(0));
 }
 template <typename T, typename TK> TGR_DEV void row_load(const T* st, int m, int e, const row::RMem<TK, T>& M) {
 #pragma unroll
@@ -814,6 +818,8 @@ template <typename T, typename TK> TGR_DEV void row_load(const T* st, int m, int
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, st[(F_CTRL + i) * m + e]); M.fd.st(row::FACT + i, st[(F_ACT + i) * m + e]); }
+#pragma unroll
+  for (int i = 0; i < 18; i++) M.fd.st(row::FDL + i, T(0));
 }
 // the env layer (finish_lane, settle_period_done, make_obs ...) works on the block kernels' structs
 template <typename T, typename TK>
@@ -836,7 +842,7 @@ TGR_DEV void row_export(const row::RMem<TK, T>& M, const row::RLag<TK, T>& rl, S
   lag.overflow = (int)rl.overflow; lag.n_it = rl.n_it; lag.n_ls = rl.n_ls; lag.n_unconv = (int)rl.n_unconv;
 }
 template <typename T, typename TK> TGR_DEV void row_lag_init(row::RLag<TK, T>& rl) {
-  rl.cfrc_absmax = T(0); rl.cfrc_clip_sq = T(0); rl.bar_contact = T(0); rl.overflow = T(0); rl.n_unconv = T(0); rl.n_it = 0; rl.n_ls = 0;
+  rl.cfrc_absmax = T(0); rl.cfrc_clip_sq = T(0); rl.bar_contact = T(0); rl.overflow = T(0); rl.n_unconv = T(0); rl.n_own = T(0); rl.n_it = 0; rl.n_ls = 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) rl.tenL[i] = T(0);
 }
@@ -898,16 +904,10 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, 
       if ((threadIdx.x & 63u) == 0) atomicAdd(&k.counters[7], (unsigned long long)(nact * E.frame_skip));
     }
     finish_lane(k, S, lag, e, valid, live, active, w0, phase, total, sh.tile + slot * Dp);
-  }
-  // observations of the live envs of this block leave through the tile: coalesced stores into the [N][D] buffer
-  const int base = blockIdx.x * ROW_ENVS;
-  const int rows = min(ROW_ENVS, n - base);
-  if (rows > 0) {
-    __syncthreads();
-    for (int f = (int)threadIdx.x; f < rows * D; f += 256) {
-      int rr = f / D, c = f - rr * D;
-      k.obs[(size_t)base * D + f] = sh.tile[rr * Dp + c];
-    }
+    // the observation of a live env leaves through the row's tile line: lane 0 wrote it, the 16 lanes store it (LDS operations of one
+    // wavefront complete in order, so no barrier is needed)
+    if (live)
+      for (int c = r; c < D; c += 16) k.obs[(size_t)e * D + c] = sh.tile[slot * Dp + c];
   }
 }
 
@@ -1265,6 +1265,7 @@ static int obs_dim_of(const tgr_config& c) {
   return d;
 }
 
+static bool use_row_kernels(const tgr_handle* h);
 template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   const tgr_config& c = h->cfg;
   Params<T>& P = k.P;
@@ -1366,6 +1367,7 @@ template <typename T> static void params_to_row(const Params<T>& P, const tgr_co
   R.f0 = P.f0; R.f1sq = P.f1sq; R.f3sq = P.f3sq; R.f4sq = P.f4sq; R.impratio = P.impratio; R.invweight = P.invweight;
   R.ls_tol = P.ls_tol; R.cf_lo = P.cf_lo; R.cf_hi = P.cf_hi;
   R.skip_clamped = P.skip_clamped; R.act_itau = P.act_itau;
+  R.warm_start = c.solver_warm_start >= 0 ? 1 : 0;  // row kernels: every solve starts from last sub-step's CONSTRAINT acceleration unless -1
   R.hf_rx = P.hf_rx; R.hf_ry = P.hf_ry; R.hf_ez = P.hf_ez; R.hf_x0 = P.hf_x0; R.hf_y0 = P.hf_y0; R.hf_z0 = P.hf_z0; R.hf_dx = P.hf_dx; R.hf_dy = P.hf_dy;
   R.hf_nrow = P.hf_nrow; R.hf_ncol = P.hf_ncol; R.hf = P.hf;
   const bool f32 = c.precision != TGR_PRECISION_F64;

@@ -30,6 +30,7 @@ namespace row {
 constexpr int ROW = 16;
 
 #ifndef TGR_ROW_EMUL
+#define TGR_PHASE(i) ((void)0)
 // ------------------------------------------------------------------ device: a lane value is a plain scalar
 template <typename T> using Ln = T;
 template <typename F> struct LaneTraits;
@@ -82,14 +83,24 @@ template <typename T> struct Ln {
   Ln() {}
   Ln(T s) { for (int i = 0; i < ROW; i++) v[i] = s; }
 };
+// optional operation census of the emulation (TGR_ROW_OPCOUNT): lane-value operations per phase, fp64 ones counted separately
+#ifdef TGR_ROW_OPCOUNT
+struct OpCount { long long n[2][16]; int phase; };
+inline OpCount& opcount() { static thread_local OpCount c = {}; return c; }
+template <typename T> inline void op_tick() { OpCount& c = opcount(); c.n[sizeof(T) == 8 ? 1 : 0][c.phase]++; }
+#define TGR_PHASE(i) (::tgr::row::opcount().phase = (i))
+#else
+template <typename T> inline void op_tick() {}
+#define TGR_PHASE(i) ((void)0)
+#endif
 template <typename F> struct LaneTraits;
 template <> struct LaneTraits<Ln<float>> { typedef float S; typedef Ln<int> I; typedef Ln<bool> B; };
 template <> struct LaneTraits<Ln<double>> { typedef double S; typedef Ln<int> I; typedef Ln<bool> B; };
 
 #define TGR_EMUL_BIN(OP)                                                                                                   \
-  template <typename T> inline Ln<T> operator OP(const Ln<T>& a, const Ln<T>& b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] OP b.v[i]; return r; } \
-  template <typename T> inline Ln<T> operator OP(const Ln<T>& a, T b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] OP b; return r; }               \
-  template <typename T> inline Ln<T> operator OP(T a, const Ln<T>& b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = a OP b.v[i]; return r; }
+  template <typename T> inline Ln<T> operator OP(const Ln<T>& a, const Ln<T>& b) { op_tick<T>(); Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] OP b.v[i]; return r; } \
+  template <typename T> inline Ln<T> operator OP(const Ln<T>& a, T b) { op_tick<T>(); Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] OP b; return r; }               \
+  template <typename T> inline Ln<T> operator OP(T a, const Ln<T>& b) { op_tick<T>(); Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = a OP b.v[i]; return r; }
 TGR_EMUL_BIN(+) TGR_EMUL_BIN(-) TGR_EMUL_BIN(*) TGR_EMUL_BIN(/)
 #undef TGR_EMUL_BIN
 #define TGR_EMUL_CMP(OP)                                                                                                   \
@@ -116,9 +127,9 @@ inline Ln<int> operator>>(const Ln<int>& a, int s) { Ln<int> r; for (int i = 0; 
 inline Ln<int> operator&(const Ln<int>& a, int m) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = a.v[i] & m; return r; }
 
 inline Ln<int> lane_id() { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = i; return r; }
-template <typename T> inline Ln<T> sel(const Ln<bool>& c, const Ln<T>& a, const Ln<T>& b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
-template <typename T> inline Ln<T> sel(const Ln<bool>& c, const Ln<T>& a, T b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a.v[i] : b; return r; }
-template <typename T> inline Ln<T> sel(const Ln<bool>& c, T a, const Ln<T>& b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a : b.v[i]; return r; }
+template <typename T> inline Ln<T> sel(const Ln<bool>& c, const Ln<T>& a, const Ln<T>& b) { op_tick<T>(); Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+template <typename T> inline Ln<T> sel(const Ln<bool>& c, const Ln<T>& a, T b) { op_tick<T>(); Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a.v[i] : b; return r; }
+template <typename T> inline Ln<T> sel(const Ln<bool>& c, T a, const Ln<T>& b) { op_tick<T>(); Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a : b.v[i]; return r; }
 template <typename T> inline Ln<T> sel(const Ln<bool>& c, T a, T b) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a : b; return r; }
 inline Ln<bool> sel(const Ln<bool>& c, const Ln<bool>& a, bool b) { Ln<bool> r; for (int i = 0; i < ROW; i++) r.v[i] = c.v[i] ? a.v[i] : b; return r; }
 template <typename T> inline T sel(bool c, T a, T b) { return c ? a : b; }
@@ -133,10 +144,10 @@ TGR_EMUL_FN(rcp_, T(1) / x) TGR_EMUL_FN(sqrt_, std::sqrt(x)) TGR_EMUL_FN(rsqrt_,
 #undef TGR_EMUL_FN
 template <typename T> inline Ln<int> to_int(const Ln<T>& a) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = (int)a.v[i]; return r; }
 template <typename T> inline Ln<T> from_int(const Ln<int>& a, Ln<T>) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = (T)a.v[i]; return r; }
-template <int K, typename T> inline Ln<T> bcast(const Ln<T>& x) { return Ln<T>(x.v[K]); }
+template <int K, typename T> inline Ln<T> bcast(const Ln<T>& x) { op_tick<T>(); return Ln<T>(x.v[K]); }
 template <typename T> inline Ln<T> rowsum(const Ln<T>& x) {  // same butterfly as the device's row_ror:8,4,2,1
   Ln<T> a = x, b;
-  for (int s = 8; s >= 1; s >>= 1) { for (int i = 0; i < ROW; i++) b.v[i] = a.v[i] + a.v[(i + s) & 15]; a = b; }
+  for (int s = 8; s >= 1; s >>= 1) { op_tick<T>(); for (int i = 0; i < ROW; i++) b.v[i] = a.v[i] + a.v[(i + s) & 15]; a = b; }
   return a;
 }
 template <typename T> inline Ln<T> rowmax(const Ln<T>& x) { T m = x.v[0]; for (int i = 1; i < ROW; i++) m = x.v[i] > m ? x.v[i] : m; return Ln<T>(m); }

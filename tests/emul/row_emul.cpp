@@ -7,6 +7,8 @@
 #include <cstdio>
 
 using namespace tgr::row;
+static int g_warm_start = 0;
+extern "C" void tgr_row_emul_set_warm_start(int w) { g_warm_start = w; }
 
 template <typename T> static void fill_params(const double* p, RParams<T>& P, const float* hf, int nrow, int ncol) {
   int i = 0;
@@ -22,6 +24,7 @@ template <typename T> static void fill_params(const double* p, RParams<T>& P, co
   P.f0 = T(p[i++]); P.f1sq = T(p[i++]); P.f3sq = T(p[i++]); P.f4sq = T(p[i++]); P.impratio = T(p[i++]); P.invweight = T(p[i++]);
   P.tol = T(p[i++]); P.ls_tol = T(p[i++]); P.cf_lo = T(p[i++]); P.cf_hi = T(p[i++]);
   P.max_iter = (int)p[i++]; P.ls_iter = (int)p[i++]; P.skip_clamped = (int)p[i++]; P.act_itau = T(p[i++]);
+  P.warm_start = 0;
   P.hf_rx = T(p[i++]); P.hf_ry = T(p[i++]); P.hf_ez = T(p[i++]); P.hf_x0 = T(p[i++]); P.hf_y0 = T(p[i++]); P.hf_z0 = T(p[i++]);
   P.hf = hf; P.hf_nrow = nrow; P.hf_ncol = ncol;
   P.hf_dx = T(ncol > 1 ? 2 * p[i - 6] / (ncol - 1) : 1.0); P.hf_dy = T(nrow > 1 ? 2 * p[i - 5] / (nrow - 1) : 1.0);
@@ -46,13 +49,14 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
   RParams<TK> PK;
   fill_params<T>(params, P, hf, nrow, ncol);
   fill_params<TK>(params, PK, hf, nrow, ncol);
+  P.warm_start = PK.warm_start = g_warm_start;
   int bad = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : bad)
   for (int e = 0; e < n; e++) {
-    K kd[K_SLAB], rd[R_SLAB];
+    K kd[K_SLAB], rd[R_SLAB], ad[A_SLAB];
     F fd[F_SLAB], td[T_SLAB];
     RMem<K, F> M;
-    M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0};
+    M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0};
     const Roles<F> Ro = make_roles<K, F, TK, MODEL>(PK, M.rd);
     RLag<K, F> lag;
     for (int b = 0; b < 3; b++) {
@@ -68,7 +72,8 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
       st3(M.fd, FW + 3 * b, cvt3<F>(rot_apply(R, mk<K>(K(TK(v[3])), K(TK(v[4])), K(TK(v[5]))))));
     }
     for (int i = 0; i < 6; i++) { fd[FCTRL + i] = F(T(ctrl[6 * e + i])); fd[FACT + i] = F(T(act[6 * e + i])); }
-    lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = F(T(0)); lag.cfrc_absmax = F(T(0)); lag.cfrc_clip_sq = F(T(0)); lag.bar_contact = F(T(0)); lag.overflow = F(T(0));
+    for (int i = 0; i < 18; i++) fd[FDL + i] = F(T(0));
+    lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = F(T(0)); lag.n_own = F(T(0)); lag.cfrc_absmax = F(T(0)); lag.cfrc_clip_sq = F(T(0)); lag.bar_contact = F(T(0)); lag.overflow = F(T(0));
     for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, Ro, M, lag);
     substep<K, F, TK, T, MODEL, true>(PK, P, Ro, M, lag);
     for (int b = 0; b < 3; b++) {
@@ -89,12 +94,18 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
     for (int t = 0; t < 9; t++) { o[t] = lag.tenL[t].v[0]; bad += check_rep(lag.tenL[t], "tenL", e); }
     for (int b = 0; b < 3; b++) { o[9 + 3 * b] = lag.x[b].x.v[0]; o[10 + 3 * b] = lag.x[b].y.v[0]; o[11 + 3 * b] = lag.x[b].z.v[0]; }
     o[18] = lag.cfrc_absmax.v[0]; o[19] = lag.cfrc_clip_sq.v[0]; o[20] = lag.bar_contact.v[0]; o[21] = lag.overflow.v[0];
-    o[22] = lag.n_unconv.v[0]; o[23] = lag.n_it; o[24] = lag.n_ls;
+    o[22] = lag.n_unconv.v[0]; o[23] = lag.n_it; o[24] = lag.n_ls; o[25] = lag.n_own.v[0];
     bad += check_rep(lag.cfrc_absmax, "cfrc", e) + check_rep(lag.bar_contact, "bar_contact", e) + check_rep(lag.n_unconv, "n_unconv", e);
   }
   return bad;
 }
 
+#ifdef TGR_ROW_OPCOUNT
+extern "C" void tgr_row_opcount(long long* out /* [2][16] */, int reset) {
+  OpCount& c = opcount();
+  for (int p = 0; p < 2; p++) for (int i = 0; i < 16; i++) { out[p * 16 + i] = c.n[p][i]; if (reset) c.n[p][i] = 0; }
+}
+#endif
 // precision: 0 = fp32 throughout, 1 = fp64 throughout, 2 = mixed (pose / kinematics / tendons fp64, the rest fp32)
 extern "C" int tgr_row_emul(int precision, int model, const double* params, const float* hf, int nrow, int ncol, int n, int nsub, double* qpos,
                             double* qvel, const double* ctrl, double* act, double* out) {

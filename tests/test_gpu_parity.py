@@ -20,7 +20,8 @@ CASES = [("tensegrity_env", "straight"), ("tensegrity_env", "turn"), ("tr_env", 
 def _run(oracle, kind, action, prec, n, steps, seed=0, **kw):
     from tensegrity_rl_amd import TensegrityVecEnv
     O = oracle
-    ob = O.OracleBatch(O.make_cfg(kind, action, **kw), n, seed=1234)
+    okw = {k: v for k, v in kw.items() if k not in ("kernel_layout",)}  # execution options the oracle does not have
+    ob = O.OracleBatch(O.make_cfg(kind, action, **okw), n, seed=1234)
     ob.reset()
     env = TensegrityVecEnv(n, kind + "-v0", desired_action=action, precision=prec, auto_reset=False, **kw)
     rng = np.random.default_rng(seed)
@@ -66,16 +67,26 @@ def test_fp64_contact_cost_matches_oracle(oracle):
 
 @pytest.mark.parametrize("kind,action", [("tensegrity_env", "straight"), ("tr_env", "straight")])
 def test_fp32_within_stated_tolerance(oracle, kind, action):
-    rows, stats = _run(oracle, kind, action, "f32", 256, 5)
+    """BASELINE.json: per-step qpos / qvel within 1e-4 relative of the reference engine on identical (state, action).  The production
+    path (fp32 handle, row kernels: pose / kinematics / tendon geometry / axial torques in fp64 inside the kernel, stopping rule
+    sqrt(g^T M^-1 g) < 1e-3) on 512 envs x 6 control periods: at least 99 % of the env-steps inside the bound, for qpos AND qvel.
+    What is left outside are contact-timing flips (a cap whose distance to the floor changes sign within rounding of zero)."""
+    rows, stats = _run(oracle, kind, action, "f32", 512, 6)
+    qpos = np.concatenate([r["qpos"] for r in rows]); qvel = np.concatenate([r["qvel"] for r in rows])
+    assert np.mean(qpos < 1e-4) >= 0.99 and np.mean(qvel < 1e-4) >= 0.99, (np.mean(qpos < 1e-4), np.mean(qvel < 1e-4))
+    assert np.median(qpos) < 1e-6 and np.median(qvel) < 2e-5
+    assert np.median(np.concatenate([r["rew"] for r in rows])) < 1e-4
+    assert np.mean(np.concatenate([r["term"] for r in rows])) < 0.01
+    # the solver reaches its tolerance: lane-sub-steps that hit the iteration cap stay a small minority
+    assert stats["unconverged_lane_substeps"] <= 0.03 * stats["lane_substeps"], stats
+
+
+def test_block_kernels_remain_a_cross_check(oracle):
+    """kernel_layout="block": the LDS-column kernels (all arithmetic in the handle's precision, mujoco's stopping rule) still agree with
+    the oracle in fp64 -- two independent mappings of the same sub-step onto the machine"""
+    rows, stats = _run(oracle, "tensegrity_env", "straight", "f64", 64, 3, kernel_layout="block")
     for r in rows:
-        assert np.median(r["qpos"]) < 1e-5 and r["qpos"].max() < 3e-2       # 1e-4 relative for qpos: all but chatter cases
-        assert np.mean(r["qpos"] < 1e-4) > 0.96
-        # BASELINE.json: 1e-4 relative for the typical env.  tr_env envs sit almost at rest (|qvel| ~ 0.05), where the same
-        # absolute fp32 error (~3e-5, concentrated in the spin about the bar axis, inertia 0.0038 kg m^2) reads 3x larger
-        assert np.median(r["qvel"]) < (1e-4 if kind == "tensegrity_env" else 3e-4)
-        assert np.mean(r["qvel"] < 1e-2) > 0.85                               # chatter outliers are a minority
-        assert np.median(r["rew"]) < 1e-4
-        assert np.mean(r["term"]) < 0.02
+        assert r["qpos"].max() < 1e-7 and r["qvel"].max() < 1e-5 and not r["term"].any()
 
 
 FIXTURES = ["tensegrity_env_straight_d1.npz", "tensegrity_env_straight_d-1_terminate_when_unhealthy-0.npz", "tensegrity_env_turn_d1.npz",
@@ -198,3 +209,28 @@ def test_fp64_clamped_actuator_derivative_option_matches_oracle(oracle):
         differs = max(differs, np.abs(ref.get_state()["qvel"] - v2).max())
     assert differs > 1e-6  # the switch does change the dynamics (actuators do sit on their limits under random actions)
     env.close(); ref.close(); ob.close()
+
+
+def test_full_size_rollout_counters_stay_inside_their_bounds():
+    """BASELINE size, production settings (4096 envs, fp32, auto-reset through donor lanes, random actions): what the solver and the
+    contact slots leave unresolved is counted on the device and bounded here --
+      * bar-bar contacts beyond the two slots per bar pair (the deepest are kept): < 3 per 1000 env-steps,
+      * lane-sub-steps that left the Newton solver at its iteration cap: < 3 %,
+      * no env ever waited for a synchronous settle (donor lanes always had an episode ready), every observation finite."""
+    import torch
+    from tensegrity_rl_amd import TensegrityVecEnv
+    n, steps = 4096, 80
+    env = TensegrityVecEnv(n, "tensegrity_env-v0", seed=7)
+    env.reset_tensors()
+    s0 = env.stats()
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    bad = 0
+    for t in range(steps):
+        o, r, te, tr, tobs, info = env.step_tensors(torch.rand((n, 6), device="cuda", generator=g) * 0.6 - 0.45)
+        bad += int((~torch.isfinite(o).all(dim=1)).sum().item()) if t % 8 == 0 else 0
+    s1 = env.stats()
+    assert bad == 0
+    assert s1["dropped_contacts"] - s0["dropped_contacts"] < 3e-3 * n * steps, s1
+    assert s1["unconverged_lane_substeps"] - s0["unconverged_lane_substeps"] < 0.03 * (s1["lane_substeps"] - s0["lane_substeps"]), s1
+    assert s1["settle_kernel_resets"] == s0["settle_kernel_resets"] and s1["donor_resets"] > 0, s1
+    env.close()
