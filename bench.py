@@ -21,30 +21,29 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-def profiled_valu():
-    """wave-level VALU instructions per step_kernel launch from the committed SQ counter pass (same command as the traffic passes);
-    x 64 lanes / kernel time = lane-operations per second (an FMA counts once).  None when the profile is not there."""
-    import json as _j, os as _o
-    f = _o.path.join(_o.path.dirname(_o.path.abspath(__file__)), "profiles", "round1_bench_rocprofv3_summary_v4.json")
-    try:
-        sq = _j.load(open(f))["sq"]["tgr::step_kernel"]
-        return sq["SQ_INSTS_VALU"] / sq["dispatches"]
-    except Exception:
-        return None
+PROFILE = os.path.join(ROOT, "profiles", "round2_bench_rocprofv3_summary.json")
 
 
-def profiled_traffic():
-    """HBM bytes per step_kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/round1_bench_rocprofv3_summary_v4.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB per
-    dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).  None when the profile is not there."""
-    import json as _j, os as _o
-    f = _o.path.join(_o.path.dirname(_o.path.abspath(__file__)), "profiles", "round1_bench_rocprofv3_summary_v4.json")
+def profiled():
+    """Counters of the dominant kernel from the committed rocprofv3 passes of this same command (tests/prof_bench.sh: FETCH_SIZE and
+    WRITE_SIZE in separate passes, KB per dispatch, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note; SQ_INSTS_VALU).  They are
+    NOT measured by this run: the line says where they come from, and they are dropped (null) when the kernel sources have changed
+    since the profile was taken (hash of csrc/ + build flags stored with the profile)."""
+    out = {"traffic": None, "valu_per_launch": None, "source": None}
     try:
-        d = _j.load(open(f))
-        fe, wr = d["fetch"]["tgr::step_kernel"], d["write"]["tgr::step_kernel"]
-        return (2.0 * fe["FETCH_SIZE"] / fe["dispatches"] + wr["WRITE_SIZE"] / wr["dispatches"]) * 1024.0
-    except Exception:
-        return None
+        from tensegrity_rl_amd import build as _b
+        d = json.load(open(PROFILE))
+        if d.get("src_hash") != _b._src_hash():
+            out["source"] = f"{os.path.relpath(PROFILE, ROOT)} is stale (kernel sources changed since): dropped"
+            return out
+        kn = d["dominant_kernel"]
+        fe, wr, sq = d["fetch"][kn], d["write"][kn], d["sq"][kn]
+        out["traffic"] = (2.0 * fe["FETCH_SIZE"] / fe["dispatches"] + wr["WRITE_SIZE"] / wr["dispatches"]) * 1024.0
+        out["valu_per_launch"] = sq["SQ_INSTS_VALU"] / sq["dispatches"]
+        out["source"] = f"{os.path.relpath(PROFILE, ROOT)} ({kn}, src_hash {d['src_hash'][:12]})"
+    except Exception as e:
+        out["source"] = f"no profile ({type(e).__name__})"
+    return out
 
 
 BYTES_PER_ENV_STEP = 674  # fp32: 61 state words in + 6 action words in, 61 state words + 39 obs words + reward + 2 flags out
@@ -150,7 +149,10 @@ def main():
     ap.add_argument("--env-id", default="tensegrity_env-v0")
     ap.add_argument("--model", default="flat", choices=["flat", "uneven"],
                     help="uneven: BASELINE config #4 (heightfield floor, tests/golden/terrain_100.npy); not the headline metric")
-    ap.add_argument("--donors", type=int, default=-1)
+    ap.add_argument("--donors", type=int, default=None,
+                    help="donor lanes per GPU (episodes being settled for the next resets); default 5/4 of the envs: an env lives ~47 steps "
+                         "under random actions and reset_model() costs 50, so ~1.06 N lanes are busy settling at any time")
+    ap.add_argument("--kernel-layout", default="auto", choices=["auto", "row", "block"])
     ap.add_argument("--gather-every", type=int, default=16)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -199,8 +201,10 @@ def main():
     if args.model == "uneven":
         import numpy as np
         extra = dict(model="uneven", terrain=np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "terrain_100.npy")))
+    donors = args.donors if args.donors is not None else (5 * n_local // 4 if args.kernel_layout != "block" and args.model == "flat" else 2 * n_local)
     env = TensegrityVecEnv(n_local, args.env_id, device=local_rank, desired_action="straight", desired_direction=1,
-                           seed=1234, first_env_id=lo, n_donors=args.donors, **extra)
+                           seed=1234, first_env_id=lo, n_donors=donors, kernel_layout=args.kernel_layout, **extra)
+    row_layout = args.kernel_layout != "block" and args.model == "flat"
     env.reset_tensors()
     g = torch.Generator(device=dev); g.manual_seed(rank)
     acts = [(torch.rand((n_local, 6), device=dev, generator=g) * 0.6 - 0.45).contiguous() for _ in range(32)]
@@ -245,26 +249,34 @@ def main():
         launch_bytes = BYTES_PER_ENV_STEP * n_local
         achieved = launch_bytes / (kern_ms * 1e-3) / 1e9
         resets = stats1["donor_resets"] - stats0["donor_resets"] + stats1["settle_kernel_resets"] - stats0["settle_kernel_resets"]
+        prof = profiled()
+        lane_sub = max(stats1["lane_substeps"] - stats0["lane_substeps"], 1)
         out = {
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"3-bar {'uneven-ground (heightfield)' if args.model == 'uneven' else 'flat-ground'} {args.env_id} straight/+1, N_envs={n_local} per GPU ({n_total} total), "
                                    "random-action rollout U[-0.45,0.15]^6, auto-reset via donor lanes, 20 sub-steps of 1 ms per step",
-                       "envs_per_gpu": n_local, "donor_lanes_per_gpu": env.cfg.n_donors if env.cfg.n_donors >= 0 else 2 * n_local,
+                       "envs_per_gpu": n_local, "donor_lanes_per_gpu": donors,
+                       "kernel_layout": "row (one env per 16-lane DPP row; fp32 with pose / kinematics / tendon geometry / axial torques in fp64)" if row_layout
+                                        else "block (64 envs x 4 wavefronts, LDS columns; fp32 throughout)",
                        "gather_every": args.gather_every if world > 1 else None,
                        "resets_per_step_rank0": resets / args.steps,
                        "newton_iters_per_substep": stats1["newton_iters_per_substep"],
+                       "unconverged_lane_substeps_per_env_step": (stats1["unconverged_lane_substeps"] - stats0["unconverged_lane_substeps"]) / (n_local * args.steps),
+                       "unconverged_fraction_of_lane_substeps": (stats1["unconverged_lane_substeps"] - stats0["unconverged_lane_substeps"]) / lane_sub,
+                       "dropped_contacts_per_env_step": (stats1["dropped_contacts"] - stats0["dropped_contacts"]) / (n_local * args.steps),
                        "starved_resets_rank0": stats1["settle_kernel_resets"] - stats0["settle_kernel_resets"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": profiled_traffic(),
-                         "note": "step_kernel: 674 algorithmic B per env-step x envs per launch / mean launch duration (HIP events around "
+                         "traffic": prof["traffic"], "traffic_source": prof["source"],
+                         "note": "step kernel: 674 algorithmic B per env-step x envs per launch / mean launch duration (HIP events around "
                                  "the step+match+settle launches of one step); the path is VALU-issue bound (~1e6 flop per env-step), "
                                  "not HBM bound: see DESIGN.md",
                          "kernel_ms": kern_ms, "kernel_ms_p50": step_ms[len(step_ms) // 2],
-                         # the practical bound is VALU issue/latency of few resident waves, so report those too
-                         "resident_waves": 4 * ((n_local + (env.cfg.n_donors if env.cfg.n_donors >= 0 else 2 * n_local) + 63) // 64),
-                         "valu_lane_ops_per_s": (profiled_valu() * 64 / (kern_ms * 1e-3)) if profiled_valu() else None},
+                         # the practical bound is VALU issue of the resident waves, so report those too
+                         "resident_waves": ((n_local + donors + 3) // 4) if row_layout else 4 * ((n_local + donors + 63) // 64),
+                         "valu_lane_ops_per_s": (prof["valu_per_launch"] * 64 / (kern_ms * 1e-3)) if prof["valu_per_launch"] else None,
+                         "valu_frac_of_peak": (prof["valu_per_launch"] * 64 / (kern_ms * 1e-3) / 78.6e12) if prof["valu_per_launch"] else None},
         }
         if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed once: rank 0 of the one-GPU run
             try:

@@ -23,6 +23,12 @@ for tag in ("fetch", "write", "sq"):
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
         res[tag] = {k: {"dispatches": len(disp[k]), **{c: v for c, v in d.items()}} for k, d in acc.items()}
 res["bench_line_under_trace"] = open(out + "/trace.json").read().strip()
+import sys, os
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+from tensegrity_rl_amd import build as _b
+res["src_hash"] = _b._src_hash()
+ks = sorted(res.get("kernel_stats", []), key=lambda r: -float(r["TotalDurationNs"]))
+res["dominant_kernel"] = ks[0]["Name"].split("<")[0].replace("void ", "") if ks else None
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY
