@@ -546,7 +546,7 @@ TGR_RDEV void hess_add_slot(RHess<F>& H, const DofC<F>& d, const RContact<F>& c,
 // p = -H^-1 g.  g: per bar distributed (lane r: component r of the bar's 6-vector); returns p replicated, pr[b][0..6)
 // c01 / c02 / c12: does ANY environment of the wavefront couple bars (0,1) / (0,2) / (1,2)?  (uniform flags; an off-diagonal block
 // nobody fills is zero and its part of the factorisation is skipped.  O21 also fills in through O20 O10^T.)
-template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F pr[3][6], bool c01, bool c02, bool c12) {
+template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F pr[3][6], F& gx, bool c01, bool c02, bool c12) {
   typedef typename LaneTraits<F>::S S;
   const bool n21 = c12 || (c01 && c02);
   F il0[6], il1[6], il2[6];
@@ -585,6 +585,7 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
     for (int i = 0; i < 6; i++) yr0[i] = yr0[i] - t[i];
   }
   rbwd<6>(H.D[0], il0, yr0, x0, pr[0]);
+  gx = gd[0] * x0 + gd[1] * x1 + gd[2] * x2;  // lane i: its three terms of g . x
   for (int b = 0; b < 3; b++)
     for (int i = 0; i < 6; i++) pr[b][i] = -pr[b][i];
 }
@@ -593,12 +594,13 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
 // Between its uses the environment's state lives in slabs (LDS on the GPU), not in registers:
 //   kd (K, replicated): pose x, q; unconstrained acceleration l0, a0; bar axes ez       fd (F, replicated): v, w, ctrl, act
 //   td (F, per lane):   tendon-role results u, ra x u, rb x u, damping                  rd (K, per lane, per block): tendon-role constants
-enum : int { KX = 0, KQ = 9, KL0 = 21, KA0 = 30, KEZ = 39, K_SLAB = 48 };
-enum : int { FV = 0, FW = 9, FCTRL = 18, FACT = 24, FDL = 30, FDA = 39, F_SLAB = 48 };  // FDL / FDA: last sub-step's d = a - a0
+enum : int { KX = 0, KQ = 9, KL0 = 21, KA0 = 30, KEZ = 39, KTAX = 48, K_SLAB = 51 };
+enum : int { FV = 0, FW = 9, FCTRL = 18, FACT = 24, FDL = 30, FDA = 39, FEZ = 48, FFCL = 57, FFCA = 66, F_SLAB = 75 };  // FDL / FDA: d = a - a0
 enum : int { TU = 0, TMA = 3, TMB = 6, TDAMP = 9, T_SLAB = 10 };
+enum : int { CN = 0, CRA = 3, CRB = 6, CC0 = 9, CDN = 10, CACT = 11, CJL0 = 12, CJA0 = 15, CDLA = 18, CDAA = 21, CDLB = 24, CDAB = 27, C_SLAB = 30 };  // cd (F, per lane): my contact slot
 enum : int { AMB = 0, AMA = 3, AZB = 6, AZA = 9, A_SLAB = 12 };  // ad (K, per lane): my slot's axial levers z x r and axes z of its two bars
 enum : int { RSA = 0, RSB = 3, RTK = 6, RTB = 7, RTL0 = 8, R_SLAB = 9 };
-template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; };
+template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; };
 
 // `LAST`: what only the last sub-step of a control period records (lagged kinematics, tendon lengths, contact wrench).
 // K / PK: lane and scalar type of the pose, the kinematics, the tendon geometry and the smooth forces; F / P: of the rest.
@@ -737,46 +739,65 @@ TGR_PHASE(0);
   DofC<F> dc;
   dc.dof = Ro.is_dof; dc.ang = Ro.is_ang;
   dc.e = mk<F>(sel(Ro.is_dof & (Ro.k == 0), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 1), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 2), F(S(1)), zero));
-  V3<F> dl[3], da[3];
-  // start: last sub-step's constraint acceleration d (P.warm_start) -- a contact's reference acceleration moves by ~B h a every sub-step, so
-  // last sub-step's ACCELERATION is a poor guess, but the part of it the contacts produced is a good one -- or zero
-  for (int b = 0; b < 3; b++) {
-    dl[b] = P.warm_start ? sel3(any_contact, ld3(M.fd, FDL + 3 * b), z3) : z3;
-    da[b] = P.warm_start ? sel3(any_contact, ld3(M.fd, FDA + 3 * b), z3) : z3;
+  // Everything the iterations share lives in the slabs, not in registers: the iterate d (fd: FDL / FDA, and picked for my slot's two
+  // bars in cd), my contact slot (cd), the bar axes (fd: FEZ), the constraint wrench of the last assembly (fd: FFCL / FFCA, kd: KTAX).
+  // Start: last sub-step's constraint acceleration (P.warm_start) -- a contact's reference acceleration moves by ~B h a every sub-step,
+  // so last sub-step's ACCELERATION is a poor guess, but the part of it the contacts produced is a good one -- or zero.
+  {
+    V3<F> dl[3], da[3];
+    for (int b = 0; b < 3; b++) {
+      dl[b] = P.warm_start ? sel3(any_contact, ld3(M.fd, FDL + 3 * b), z3) : z3;
+      da[b] = P.warm_start ? sel3(any_contact, ld3(M.fd, FDA + 3 * b), z3) : z3;
+      st3(M.fd, FDL + 3 * b, dl[b]); st3(M.fd, FDA + 3 * b, da[b]);
+      st3(M.fd, FEZ + 3 * b, ez[b]);
+    }
+    st3(M.cd, CDLA, pick_bar0(Ro.sA, dl)); st3(M.cd, CDAA, pick_bar0(Ro.sA, da));
+    st3(M.cd, CDLB, pick_bar0(Ro.sB, dl)); st3(M.cd, CDAB, pick_bar0(Ro.sB, da));
+    st3(M.cd, CN, c.n); st3(M.cd, CRA, c.rA); st3(M.cd, CRB, c.rB);
+    M.cd.st(CC0, c.c0); M.cd.st(CDN, c.Dn); M.cd.st(CACT, sel(c.active, F(S(1)), zero));
+    st3(M.cd, CJL0, jl0); st3(M.cd, CJA0, ja0);
   }
   auto conv = !any_contact;
-  V3<F> fcl[3], fca[3];  // constraint force / torque per bar (replicated)
-  K tax[3];              // ... and the torque about each bar's own axis once more, summed in K
   F cfrc_max = zero, bar_force = zero;
   int n_it = 0, n_ls = 0;
+  TGR_FENCE();
   for (int it = 0;; it++) {
     TGR_PHASE(3);
-    // my slot's residual jar at the current iterate
-    const V3<F> dlA = pick_bar0(Ro.sA, dl), daA = pick_bar0(Ro.sA, da), dlB = pick_bar0(Ro.sB, dl), daB = pick_bar0(Ro.sB, da);
-    const V3<F> jl = jl0 + ((dlB + cross(daB, c.rB)) - (dlA + cross(daA, c.rA)));
-    const V3<F> ja = ja0 + (daB - daA);
-    const RCone<F> o = cone_eval(P, c, jl, ja);
+    // ---- my slot's residual jar at the current iterate, cone force
+    RContact<F> cs;
+    cs.n = ld3(M.cd, CN); cs.rA = ld3(M.cd, CRA); cs.rB = ld3(M.cd, CRB);
+    cs.c0 = M.cd.ld(CC0); cs.Dn = M.cd.ld(CDN); cs.active = M.cd.ld(CACT) != S(0);
+    const V3<F> jl = ld3(M.cd, CJL0) + ((ld3(M.cd, CDLB) + cross(ld3(M.cd, CDAB), cs.rB)) - (ld3(M.cd, CDLA) + cross(ld3(M.cd, CDAA), cs.rA)));
+    const V3<F> ja = ld3(M.cd, CJA0) + (ld3(M.cd, CDAB) - ld3(M.cd, CDAA));
+    const RCone<F> o = cone_eval(P, cs, jl, ja);
     TGR_PHASE(4);
-    // constraint wrench per bar, gradient
-    const V3<F> tB = cross(c.rB, o.fl) + o.fa, tA = cross(c.rA, o.fl) + o.fa;
-    const V3<K> kfl = cvt3<K>(o.fl), kfa = cvt3<K>(o.fa);
-    const K tauB = dot(kfl, ld3(M.ad, AMB)) + dot(kfa, ld3(M.ad, AZB)), tauA = dot(kfl, ld3(M.ad, AMA)) + dot(kfa, ld3(M.ad, AZA));
+    // ---- constraint wrench per bar, gradient (dof role: component r of each bar's residual)
+    const V3<F> tB = cross(cs.rB, o.fl) + o.fa, tA = cross(cs.rA, o.fl) + o.fa;
+    K tauB, tauA;
+    {
+      const V3<K> kfl = cvt3<K>(o.fl), kfa = cvt3<K>(o.fa);
+      tauB = dot(kfl, ld3(M.ad, AMB)) + dot(kfa, ld3(M.ad, AZB));
+      tauA = dot(kfl, ld3(M.ad, AMA)) + dot(kfa, ld3(M.ad, AZA));
+    }
     K gn = kzero;  // g^T M^-1 g
     cfrc_max = zero;
-    V3<F> gl[3], ga[3];
+    F gd[3];
     for (int b = 0; b < 3; b++) {
       const auto onb = Ro.sB == b, ona = Ro.sA == b;
-      fcl[b] = rowsum3(sel3(onb, o.fl, z3) - sel3(ona, o.fl, z3));
-      fca[b] = rowsum3(sel3(onb, tB, z3) - sel3(ona, tA, z3));
-      tax[b] = rowsum(sel(onb, tauB, kzero) - sel(ona, tauA, kzero));
-      gl[b] = P.mass * dl[b] - fcl[b];
-      ga[b] = inertia_mul(P, ez[b], da[b]) - fca[b];
+      const V3<F> fcl = rowsum3(sel3(onb, o.fl, z3) - sel3(ona, o.fl, z3));
+      const V3<F> fca = rowsum3(sel3(onb, tB, z3) - sel3(ona, tA, z3));
+      const K tax = rowsum(sel(onb, tauB, kzero) - sel(ona, tauA, kzero));
+      st3(M.fd, FFCL + 3 * b, fcl); st3(M.fd, FFCA + 3 * b, fca); M.kd.st(KTAX + b, tax);
+      const V3<F> dl = ld3(M.fd, FDL + 3 * b), da = ld3(M.fd, FDA + 3 * b), ezb = ld3(M.fd, FEZ + 3 * b);
+      const V3<F> gl = P.mass * dl - fcl;
+      V3<F> ga = inertia_mul(P, ezb, da) - fca;
       // M-norm of the residual: force and transverse torque in F, the axial torque from K
-      const K gax = PK.Izz * dot(ld3(M.kd, KEZ + 3 * b), cvt3<K>(da[b])) - tax[b];
-      const F gz = dot(ez[b], ga[b]);
-      gn = gn + cvt<K>(im * dot(gl[b], gl[b]) + (dot(ga[b], ga[b]) - gz * gz) * (S(1) / P.Ixx)) + gax * gax * (SK(1) / PK.Izz);
-      ga[b] = ga[b] + (cvt<F>(gax) - gz) * ez[b];  // the direction is solved for the same axial residual the test looks at
-      cfrc_max = max_(cfrc_max, max_(max_(max_(abs_(fcl[b].x), abs_(fcl[b].y)), abs_(fcl[b].z)), max_(max_(abs_(fca[b].x), abs_(fca[b].y)), abs_(fca[b].z))));
+      const K gax = PK.Izz * dot(ld3(M.kd, KEZ + 3 * b), cvt3<K>(da)) - tax;
+      const F gz = dot(ezb, ga);
+      gn = gn + cvt<K>(im * dot(gl, gl) + (dot(ga, ga) - gz * gz) * (S(1) / P.Ixx)) + gax * gax * (SK(1) / PK.Izz);
+      ga = ga + (cvt<F>(gax) - gz) * ezb;  // the direction is solved for the same axial residual the test looks at
+      gd[b] = sel(Ro.is_dof, sel(Ro.is_ang, pick_comp(Ro.k, ga), pick_comp(Ro.k, gl)), zero);
+      cfrc_max = max_(cfrc_max, max_(max_(max_(abs_(fcl.x), abs_(fcl.y)), abs_(fcl.z)), max_(max_(abs_(fca.x), abs_(fca.y)), abs_(fca.z))));
     }
     if (LAST) bar_force = rowsum(sel(Ro.is_pair, sqrt_(dot(o.fl, o.fl)), zero));
     conv = conv | !(gn >= PK.tol * PK.tol);
@@ -784,43 +805,41 @@ TGR_PHASE(0);
     n_it++;
     lag.n_own = lag.n_own + sel(conv, zero, F(S(1)));
     TGR_PHASE(5);
-    // Hessian rows (dof role)
+    // ---- Hessian rows (dof role)
     RHess<F> H;
     for (int b = 0; b < 3; b++) {
       const S dI = P.Izz - P.Ixx;
-      const F ze = dot(dc.e, ez[b]);
+      const V3<F> ezb = ld3(M.fd, FEZ + 3 * b);
+      const F ze = dot(dc.e, ezb);
       const V3<F> lin = sel3(dc.ang, z3, P.mass * dc.e);
-      const V3<F> ang = sel3(dc.ang, P.Ixx * dc.e + (dI * ze) * ez[b], z3);
+      const V3<F> ang = sel3(dc.ang, P.Ixx * dc.e + (dI * ze) * ezb, z3);
       H.D[b][0] = lin.x; H.D[b][1] = lin.y; H.D[b][2] = lin.z; H.D[b][3] = ang.x; H.D[b][4] = ang.y; H.D[b][5] = ang.z;
     }
     for (int i = 0; i < 6; i++) { H.O10[i] = zero; H.O20[i] = zero; H.O21[i] = zero; }
-    static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<0, decltype(cc)::value>(H, dc, c, o); });
+    static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<0, decltype(cc)::value>(H, dc, cs, o); });
     // which bar pairs does any environment of the wavefront couple?  (uniform: lets the factorisation skip zero blocks)
-    const bool cp0 = any_slot<6>(c.active) || any_slot<7>(c.active), cp1 = any_slot<8>(c.active) || any_slot<9>(c.active),
-               cp2 = any_slot<10>(c.active) || any_slot<11>(c.active);
+    const bool cp0 = any_slot<6>(cs.active) || any_slot<7>(cs.active), cp1 = any_slot<8>(cs.active) || any_slot<9>(cs.active),
+               cp2 = any_slot<10>(cs.active) || any_slot<11>(cs.active);
     TGR_PHASE(6);
-    // direction
-    F gd[3], pr[3][6];
-    for (int b = 0; b < 3; b++) gd[b] = sel(Ro.is_dof, sel(Ro.is_ang, pick_comp(Ro.k, ga[b]), pick_comp(Ro.k, gl[b])), zero);
-    newton_direction(H, gd, pr, cp0, cp1, cp2);
+    // ---- direction p = -H^-1 g
+    F pr[3][6], gx;
+    newton_direction(H, gd, pr, gx, cp0, cp1, cp2);
+    const F d0 = sel(conv, zero, -rowsum(gx));  // p . g
+    TGR_PHASE(7);
+    // ---- line search: Gauss part (replicated), cone part (slot role)
     V3<F> pl[3], pa[3];
+    F g1 = zero, g2 = zero;
     for (int b = 0; b < 3; b++) {
       pl[b] = sel3(conv, z3, mk<F>(pr[b][0], pr[b][1], pr[b][2]));
       pa[b] = sel3(conv, z3, mk<F>(pr[b][3], pr[b][4], pr[b][5]));
-    }
-    TGR_PHASE(7);
-    // line search: Gauss part (replicated), cone part (slot role)
-    F g1 = zero, g2 = zero, d0 = zero;
-    for (int b = 0; b < 3; b++) {
-      const V3<F> Ipa = inertia_mul(P, ez[b], pa[b]);
-      g1 = g1 + P.mass * dot(pl[b], dl[b]) + dot(Ipa, da[b]);
+      const V3<F> Ipa = inertia_mul(P, ld3(M.fd, FEZ + 3 * b), pa[b]);
+      g1 = g1 + P.mass * dot(pl[b], ld3(M.fd, FDL + 3 * b)) + dot(Ipa, ld3(M.fd, FDA + 3 * b));
       g2 = g2 + P.mass * dot(pl[b], pl[b]) + dot(Ipa, pa[b]);
-      d0 = d0 + dot(pl[b], gl[b]) + dot(pa[b], ga[b]);
     }
     const V3<F> plA = pick_bar0(Ro.sA, pl), paA = pick_bar0(Ro.sA, pa), plB = pick_bar0(Ro.sB, pl), paB = pick_bar0(Ro.sB, pa);
-    const V3<F> ql = (plB + cross(paB, c.rB)) - (plA + cross(paA, c.rA));
+    const V3<F> ql = (plB + cross(paB, cs.rB)) - (plA + cross(paA, cs.rA));
     const V3<F> qa = paB - paA;
-    const RLSlot<F> ls = ls_make(c, jl, ja, ql, qa);
+    const RLSlot<F> ls = ls_make(cs, jl, ja, ql, qa);
     conv = conv | !(abs_(d0) >= P.tol * P.tol);  // Newton decrement g^T H^-1 g (<= g^T M^-1 g) below tolerance
     conv = conv | !(d0 < S(0));                  // no descent left at working precision
     F alpha = sel(conv, zero, F(S(1))), lo = zero, hi = F(S(-1));
@@ -844,27 +863,32 @@ TGR_PHASE(0);
       alpha = sel(go, na, alpha);
       if (!any_lane(!ls_done) || k + 1 >= P.ls_iter) break;
     }
-    for (int b = 0; b < 3; b++) { dl[b] = dl[b] + alpha * pl[b]; da[b] = da[b] + alpha * pa[b]; }
+    for (int b = 0; b < 3; b++) {
+      st3(M.fd, FDL + 3 * b, ld3(M.fd, FDL + 3 * b) + alpha * pl[b]);
+      st3(M.fd, FDA + 3 * b, ld3(M.fd, FDA + 3 * b) + alpha * pa[b]);
+    }
+    st3(M.cd, CDLA, ld3(M.cd, CDLA) + alpha * plA); st3(M.cd, CDAA, ld3(M.cd, CDAA) + alpha * paA);
+    st3(M.cd, CDLB, ld3(M.cd, CDLB) + alpha * plB); st3(M.cd, CDAB, ld3(M.cd, CDAB) + alpha * paB);
+    TGR_FENCE();
   }
   TGR_PHASE(8);
-  if (P.warm_start)
-    for (int b = 0; b < 3; b++) { st3(M.fd, FDL + 3 * b, sel3(any_contact, dl[b], z3)); st3(M.fd, FDA + 3 * b, sel3(any_contact, da[b], z3)); }
+  TGR_FENCE();
   lag.n_it += n_it; lag.n_ls += n_ls;
   lag.n_unconv = lag.n_unconv + sel(conv, zero, F(S(1)));
   if (LAST) {
     lag.cfrc_absmax = cfrc_max;
     F sq = zero;
     for (int b = 0; b < 3; b++) {
-      const V3<F> fa = fca[b];
-      const V3<F> a = mk<F>(clamp_(fcl[b].x, F(P.cf_lo), F(P.cf_hi)), clamp_(fcl[b].y, F(P.cf_lo), F(P.cf_hi)), clamp_(fcl[b].z, F(P.cf_lo), F(P.cf_hi)));
+      const V3<F> fl = ld3(M.fd, FFCL + 3 * b), fa = ld3(M.fd, FFCA + 3 * b);
+      const V3<F> a = mk<F>(clamp_(fl.x, F(P.cf_lo), F(P.cf_hi)), clamp_(fl.y, F(P.cf_lo), F(P.cf_hi)), clamp_(fl.z, F(P.cf_lo), F(P.cf_hi)));
       const V3<F> t = mk<F>(clamp_(fa.x, F(P.cf_lo), F(P.cf_hi)), clamp_(fa.y, F(P.cf_lo), F(P.cf_hi)), clamp_(fa.z, F(P.cf_lo), F(P.cf_hi)));
       sq = sq + dot(a, a) + dot(t, t);
     }
     lag.cfrc_clip_sq = sq;
     lag.bar_contact = bar_force;
     for (int b = 0; b < 3; b++) {  // qacc of the last forward pass (what mujoco keeps as qacc_warmstart)
-      lag.al[b] = cvt3<F>(ld3(M.kd, KL0 + 3 * b)) + dl[b];
-      lag.aa[b] = cvt3<F>(ld3(M.kd, KA0 + 3 * b)) + da[b];
+      lag.al[b] = cvt3<F>(ld3(M.kd, KL0 + 3 * b)) + ld3(M.fd, FDL + 3 * b);
+      lag.aa[b] = cvt3<F>(ld3(M.kd, KA0 + 3 * b)) + ld3(M.fd, FDA + 3 * b);
     }
   }
   // ---- implicitfast: (M + h sum_t b_t J_t J_t^T) a_new = F_smooth + F_constraint  (Woodbury over the nine tendons, tendon role).
@@ -876,15 +900,17 @@ TGR_PHASE(0);
     for (int b = 0; b < 3; b++) {
       // angular acceleration by the constraint torque: transverse part from the F sum, axial part from the K sum
       const V3<K> kz = ld3(M.kd, KEZ + 3 * b);
-      const V3<K> kf = cvt3<K>(fca[b]);
-      yak[b] = (SK(1) / PK.Ixx) * kf + (tax[b] * (SK(1) / PK.Izz) - dot(kz, kf) * (SK(1) / PK.Ixx)) * kz;
-      ylc[b] = im * fcl[b];
+      const V3<K> kf = cvt3<K>(ld3(M.fd, FFCA + 3 * b));
+      yak[b] = (SK(1) / PK.Ixx) * kf + (M.kd.ld(KTAX + b) * (SK(1) / PK.Izz) - dot(kz, kf) * (SK(1) / PK.Ixx)) * kz;
+      ylc[b] = im * ld3(M.fd, FFCL + 3 * b);
       fl_[b] = cvt3<F>(ld3(M.kd, KL0 + 3 * b)) + ylc[b];
       fa_[b] = cvt3<F>(ld3(M.kd, KA0 + 3 * b) + yak[b]);
     }
     const F sc = sqrt_(P.h * M.td.ld(TDAMP));
     const V3<F> us = sc * ld3(M.td, TU), mas = sc * ld3(M.td, TMA), mbs = sc * ld3(M.td, TMB);
-    const V3<F> was = inv_inertia(P, pick_bar(Ro.ba, ez), mas), wbs = inv_inertia(P, pick_bar(Ro.bb, ez), mbs);
+    V3<F> ezl[3];
+    for (int b = 0; b < 3; b++) ezl[b] = ld3(M.fd, FEZ + 3 * b);
+    const V3<F> was = inv_inertia(P, pick_bar(Ro.ba, ezl), mas), wbs = inv_inertia(P, pick_bar(Ro.bb, ezl), mbs);
     F zt = dot(us, pick_bar(Ro.bb, fl_) - pick_bar(Ro.ba, fl_)) + dot(mbs, pick_bar(Ro.bb, fa_)) - dot(mas, pick_bar(Ro.ba, fa_));
     F Sr[9], il9[9];
     static_for<9>([&](auto sc_) {

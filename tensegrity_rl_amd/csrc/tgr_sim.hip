@@ -760,8 +760,10 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
 // split the work by role.  No LDS in the physics (the observation tile is the only shared memory), no barrier inside a sub-step.
 // T: type of the state arrays / outputs; TK: type of pose, kinematics and tendon geometry inside the kernel (double in production).
 constexpr int ROW_ENVS = 16;  // environments per 256-thread block
+// wavefronts per SIMD the row kernels are compiled for (register budget 512 / waves): two for fp32 handles -- the donor rows of a
+// 4096-env random-action rollout bring the grid to ~2300 wavefronts on 1024 SIMDs -- one for the fp64 parity instantiation
 #ifndef TGR_ROW_WAVES
-#define TGR_ROW_WAVES 1       // wavefronts per SIMD the row kernels are compiled for (register budget 512 / TGR_ROW_WAVES)
+#define TGR_ROW_WAVES(T) (sizeof(T) == 4 ? 2 : 1)
 #endif
 
 template <typename T, typename TK> struct RowArgs { row::RParams<T> P; row::RParams<TK> PK; };
@@ -773,6 +775,7 @@ template <typename T, typename TK> struct RowShared {
   TK ad[ROW_ENVS * row::A_SLAB * 16];
   T fd[ROW_ENVS * row::F_SLAB];
   T td[ROW_ENVS * row::T_SLAB * 16];
+  T cd[ROW_ENVS * row::C_SLAB * 16];
   T tile[ROW_ENVS * 49];
 };
 template <typename T, typename TK> TGR_DEV row::RMem<TK, T> row_mem(RowShared<T, TK>& sh, int slot, int r) {
@@ -782,6 +785,7 @@ template <typename T, typename TK> TGR_DEV row::RMem<TK, T> row_mem(RowShared<T,
   M.td = row::Slab<T>{sh.td + slot * row::T_SLAB * 16, 16, r};
   M.rd = row::Slab<TK>{sh.rd, 16, r};
   M.ad = row::Slab<TK>{sh.ad + slot * row::A_SLAB * 16, 16, r};
+  M.cd = row::Slab<T>{sh.cd + slot * row::C_SLAB * 16, 16, r};
   return M;
 }
 // state of the block kernels' layout -> the row's slabs
@@ -847,7 +851,7 @@ template <typename T, typename TK> TGR_DEV void row_lag_init(row::RLag<TK, T>& r
   for (int i = 0; i < 9; i++) rl.tenL[i] = T(0);
 }
 
-template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, TGR_ROW_WAVES) void step_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
+template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, TGR_ROW_WAVES(T)) void step_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
   __shared__ RowShared<T, TK> sh;
   const int r = (int)(threadIdx.x & 15u);
   const int slot = (int)(threadIdx.x >> 4);  // environment of this row within the block
@@ -912,7 +916,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, 
 }
 
 // reset_model() in one go, row layout: one row per entry of list[] (tgr_reset, and live envs that found no ready donor)
-template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, TGR_ROW_WAVES) void settle_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
+template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, TGR_ROW_WAVES(T)) void settle_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
   __shared__ RowShared<T, TK> sh;
   const int r = (int)(threadIdx.x & 15u);
   const int slot = (int)(threadIdx.x >> 4);

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstring>
 #define TGR_RDEV inline
+#define TGR_FENCE() ((void)0)
 #endif
 
 namespace tgr {
@@ -31,6 +32,8 @@ constexpr int ROW = 16;
 
 #ifndef TGR_ROW_EMUL
 #define TGR_PHASE(i) ((void)0)
+// values parked in a slab must really be re-read after this point (no forwarding through registers), and nothing is scheduled across it
+#define TGR_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 // ------------------------------------------------------------------ device: a lane value is a plain scalar
 template <typename T> using Ln = T;
 template <typename F> struct LaneTraits;

@@ -89,6 +89,14 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
             getattr(cfg, dst)[0], getattr(cfg, dst)[1] = float(lo), float(hi)
     if "reward_delay_seconds" in kwargs:
         cfg.reward_delay_steps = int(kwargs.pop("reward_delay_seconds") / (cfg.timestep * cfg.frame_skip))
+    for k, v in (kwargs.pop("config_overrides", None) or {}).items():
+        # raw tgr_config fields (model constants such as gain / bias / ten_stiffness): for known-answer tests of the physics
+        cur = getattr(cfg, k)
+        if hasattr(cur, "__len__"):
+            for i, x in enumerate(v):
+                cur[i] = x
+        else:
+            setattr(cfg, k, type(cur)(v))
     if "kernel_layout" in kwargs:
         cfg.kernel_layout = N.KERNEL_LAYOUT[kwargs.pop("kernel_layout")]
     for k in ("actuator_deriv_skip_clamped", "solver_tolerance", "solver_iterations", "n_donors", "solver_warm_start"):

@@ -54,9 +54,9 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : bad)
   for (int e = 0; e < n; e++) {
     K kd[K_SLAB], rd[R_SLAB], ad[A_SLAB];
-    F fd[F_SLAB], td[T_SLAB];
+    F fd[F_SLAB], td[T_SLAB], cd[C_SLAB];
     RMem<K, F> M;
-    M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0};
+    M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0}; M.cd = Slab<F>{cd, 1, 0};
     const Roles<F> Ro = make_roles<K, F, TK, MODEL>(PK, M.rd);
     RLag<K, F> lag;
     for (int b = 0; b < 3; b++) {
