@@ -103,7 +103,8 @@ def launch_ranks(n_ranks, argv):
     line = None
     for ln in proc.stdout.splitlines():
         try:
-            if "metric" in json.loads(ln):
+            d = json.loads(ln)
+            if isinstance(d, dict) and "metric" in d:
                 line = ln
                 continue
         except ValueError:

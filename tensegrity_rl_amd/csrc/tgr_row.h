@@ -116,34 +116,42 @@ template <typename F> struct Roles {
   // dof role
   B is_dof, is_ang; I k;
 };
-template <typename K, typename F, typename SK, int MODEL> TGR_RDEV Roles<F> make_roles(const RParams<SK>& P, const Slab<K>& rd) {
+// the role constants that are not worth a register: tendon t's site coordinates, stiffness, damping, spring length -> role slab
+template <typename K, typename F, typename SK, int MODEL> TGR_RDEV void store_role_consts(const RParams<SK>& P, const Slab<K>& rd) {
   typedef typename LaneTraits<F>::I I;
-  typedef typename LaneTraits<F>::S S;
-  typedef SK SKK;
-  Roles<F> R;
   const I r = lane_id();
-  R.r = r;
-  R.is_ten = r < 9;
-  I ba = I(0), bb = I(0), sia = I(0), sib = I(0);
-  K tk = K(SKK(0)), tb = K(SKK(0)), tL0 = K(SKK(0));
+  I sia = I(0), sib = I(0);
+  K tk = K(SK(0)), tb = K(SK(0)), tL0 = K(SK(0));
   static_for<9>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     const auto m = r == t;
-    ba = sel(m, I(RTab::TEN0[t][0]), ba); bb = sel(m, I(RTab::TEN0[t][2]), bb);
     sia = sel(m, I(MODEL ? RTab::TEN1[t][1] : RTab::TEN0[t][1]), sia); sib = sel(m, I(MODEL ? RTab::TEN1[t][3] : RTab::TEN0[t][3]), sib);
     tk = sel(m, K(P.ten_k[t]), tk); tb = sel(m, K(P.ten_b[t]), tb); tL0 = sel(m, K(P.ten_L0[t]), tL0);
   });
-  R.ba = ba; R.bb = bb;
   rd.st(6, tk); rd.st(7, tb); rd.st(8, tL0);  // RTK, RTB, RTL0
-  R.actuated = r < 6;
-  V3<K> sa = mk<K>(K(SKK(0)), K(SKK(0)), K(SKK(0))), sb = sa;
+  V3<K> sa = mk<K>(K(SK(0)), K(SK(0)), K(SK(0))), sb = sa;
   static_for<6>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
-    const V3<K> loc = MODEL ? mk<K>(K(SKK(RTab::S1[s][0]) * P.site_off), K(SKK(RTab::S1[s][1]) * P.site_off), K(SKK(RTab::S1[s][2]) * P.site_z))
-                            : mk<K>(K(SKK(RTab::S0[s][0]) * P.site_off), K(SKK(RTab::S0[s][1]) * P.site_off), K(SKK(RTab::S0[s][2]) * P.site_z));
+    const V3<K> loc = MODEL ? mk<K>(K(SK(RTab::S1[s][0]) * P.site_off), K(SK(RTab::S1[s][1]) * P.site_off), K(SK(RTab::S1[s][2]) * P.site_z))
+                            : mk<K>(K(SK(RTab::S0[s][0]) * P.site_off), K(SK(RTab::S0[s][1]) * P.site_off), K(SK(RTab::S0[s][2]) * P.site_z));
     sa = sel3(sia == s, loc, sa); sb = sel3(sib == s, loc, sb);
   });
   st3(rd, 0, sa); st3(rd, 3, sb);  // RSA, RSB
+}
+// what lane r does: pure arithmetic on the lane number, recomputed where it is needed (a role kept in a register for the whole kernel
+// costs more than the few instructions that rebuild it)
+template <typename F, int MODEL> TGR_RDEV Roles<F> lane_roles() {
+  typedef typename LaneTraits<F>::I I;
+  typedef typename LaneTraits<F>::S S;
+  Roles<F> R;
+  I r = lane_id();
+  TGR_LAUNDER(r);
+  R.r = r;
+  R.is_ten = r < 9;
+  // bars of tendon r (both models): TEN0[t][0], TEN0[t][2]
+  R.ba = sel((r == 2) | (r == 5) | (r == 8), I(1), I(0));
+  R.bb = sel((r == 1) | (r == 4) | (r == 7), I(1), I(2));
+  R.actuated = r < 6;
   R.is_cap = r < 6;
   R.is_pair = (r >= 6) & (r < 12);
   R.is_rod = MODEL ? ((r >= 12) & (r < 15)) : (r < 0);
@@ -157,6 +165,10 @@ template <typename K, typename F, typename SK, int MODEL> TGR_RDEV Roles<F> make
   R.k = sel(r < 3, r, r - 3);
   return R;
 }
+static_assert(RTab::TEN0[2][0] == 1 && RTab::TEN0[5][0] == 1 && RTab::TEN0[8][0] == 1 && RTab::TEN0[0][0] == 0 && RTab::TEN0[1][0] == 0 &&
+              RTab::TEN0[3][0] == 0 && RTab::TEN0[4][0] == 0 && RTab::TEN0[6][0] == 0 && RTab::TEN0[7][0] == 0, "lane_roles: bar a of a tendon");
+static_assert(RTab::TEN0[1][2] == 1 && RTab::TEN0[4][2] == 1 && RTab::TEN0[7][2] == 1 && RTab::TEN0[0][2] == 2 && RTab::TEN0[2][2] == 2 &&
+              RTab::TEN0[3][2] == 2 && RTab::TEN0[5][2] == 2 && RTab::TEN0[6][2] == 2 && RTab::TEN0[8][2] == 2, "lane_roles: bar b of a tendon");
 
 // ------------------------------------------------------------------ contacts
 template <typename F> struct RContact {
@@ -594,18 +606,18 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
 // Between its uses the environment's state lives in slabs (LDS on the GPU), not in registers:
 //   kd (K, replicated): pose x, q; unconstrained acceleration l0, a0; bar axes ez       fd (F, replicated): v, w, ctrl, act
 //   td (F, per lane):   tendon-role results u, ra x u, rb x u, damping                  rd (K, per lane, per block): tendon-role constants
-enum : int { KX = 0, KQ = 9, KL0 = 21, KA0 = 30, KEZ = 39, KTAX = 48, K_SLAB = 51 };
-enum : int { FV = 0, FW = 9, FCTRL = 18, FACT = 24, FDL = 30, FDA = 39, FEZ = 48, FFCL = 57, FFCA = 66, F_SLAB = 75 };  // FDL / FDA: d = a - a0
-enum : int { TU = 0, TMA = 3, TMB = 6, TDAMP = 9, T_SLAB = 10 };
-enum : int { CN = 0, CRA = 3, CRB = 6, CC0 = 9, CDN = 10, CACT = 11, CJL0 = 12, CJA0 = 15, CDLA = 18, CDAA = 21, CDLB = 24, CDAB = 27, C_SLAB = 30 };  // cd (F, per lane): my contact slot
-enum : int { AMB = 0, AMA = 3, AZB = 6, AZA = 9, A_SLAB = 12 };  // ad (K, per lane): my slot's axial levers z x r and axes z of its two bars
-enum : int { RSA = 0, RSB = 3, RTK = 6, RTB = 7, RTL0 = 8, R_SLAB = 9 };
+constexpr int KX = 0, KQ = 9, KL0 = 21, KA0 = 30, KEZ = 39, KTAX = 48, K_SLAB = 51;
+constexpr int FV = 0, FW = 9, FCTRL = 18, FACT = 24, FDL = 30, FDA = 39, FEZ = 48, FFCL = 57, FFCA = 66, F_SLAB = 75;  // FDL / FDA: d = a - a0
+constexpr int TU = 0, TMA = 3, TMB = 6, TDAMP = 9, T_SLAB = 10;
+constexpr int CN = 0, CRA = 3, CRB = 6, CC0 = 9, CDN = 10, CACT = 11, CJL0 = 12, CJA0 = 15, CDLA = 18, CDAA = 21, CDLB = 24, CDAB = 27, C_SLAB = 30;  // cd (F, per lane): my contact slot
+constexpr int AMB = 0, AMA = 3, AZB = 6, AZA = 9, A_SLAB = 12;  // ad (K, per lane): my slot's axial levers z x r and axes z of its two bars
+constexpr int RSA = 0, RSB = 3, RTK = 6, RTB = 7, RTL0 = 8, R_SLAB = 9;
 template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; };
 
 // `LAST`: what only the last sub-step of a control period records (lagged kinematics, tendon lengths, contact wrench).
 // K / PK: lane and scalar type of the pose, the kinematics, the tendon geometry and the smooth forces; F / P: of the rest.
 template <typename K, typename F, typename SK, typename S, int MODEL, bool LAST>
-TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>& Ro, const RMem<K, F>& M, RLag<K, F>& lag) {
+TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, F>& M, RLag<K, F>& lag) {
   typedef typename LaneTraits<F>::I I;
   typedef typename LaneTraits<F>::B B;
   const F zero = F(S(0));
@@ -614,56 +626,60 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const Roles<F>
   const V3<K> kz3 = mk<K>(kzero, kzero, kzero);
   const S im = S(1) / P.mass;
   const SK imk = SK(1) / PK.mass;
-  V3<F> ez[3];
   RContact<F> c;
   V3<F> jl0, ja0;  // my slot's residual at the unconstrained acceleration: J (a0 + B v) + c0 n
   F dropped;
   {
-TGR_PHASE(0);
-    // ---- kinematics (replicated)
-    V3<K> kx[3], kex[3], key[3], kez[3];
+    TGR_PHASE(0);
+    const Roles<F> Ro = lane_roles<F, MODEL>();
+    // ---- kinematics (replicated): normalised orientation and bar axis of every bar, back into the slabs
     for (int b = 0; b < 3; b++) {
-      kx[b] = ld3(M.kd, KX + 3 * b);
       K q[4] = {M.kd.ld(KQ + 4 * b), M.kd.ld(KQ + 4 * b + 1), M.kd.ld(KQ + 4 * b + 2), M.kd.ld(KQ + 4 * b + 3)};
       normalize_quat(q);
-      const Rot<K> R = quat_rot(q);
-      kex[b] = R.ex; key[b] = R.ey; kez[b] = R.ez;
-      ez[b] = cvt3<F>(R.ez);
-      st3(M.kd, KEZ + 3 * b, R.ez);
+      for (int i = 0; i < 4; i++) M.kd.st(KQ + 4 * b + i, q[i]);
+      const V3<K> kz = mk<K>(SK(2) * (q[1] * q[3] + q[0] * q[2]), SK(2) * (q[2] * q[3] - q[0] * q[1]), q[0] * q[0] - q[1] * q[1] - q[2] * q[2] + q[3] * q[3]);
+      st3(M.kd, KEZ + 3 * b, kz);
+      st3(M.fd, FEZ + 3 * b, cvt3<F>(kz));
       if (LAST) {
-        lag.x[b] = kx[b]; lag.z[b] = R.ez;
+        lag.x[b] = ld3(M.kd, KX + 3 * b); lag.z[b] = kz;
         for (int i = 0; i < 4; i++) lag.q[b][i] = q[i];
       }
     }
-    V3<F> v[3], w[3];
-    for (int b = 0; b < 3; b++) { v[b] = ld3(M.fd, FV + 3 * b); w[b] = ld3(M.fd, FW + 3 * b); }
     TGR_PHASE(1);
-    // ---- tendons (tendon role): geometry, force, Jacobian pieces; smooth wrench per bar (replicated)
-    V3<F> l0[3], a0[3];
+    // ---- tendons (tendon role): geometry, force, Jacobian pieces; smooth wrench per bar (replicated).  Each lane reads the pose of
+    // ITS two bars straight from the slab (a lane-dependent LDS address), so no lane ever holds all three bars
     {
-      const V3<K> sa = ld3(M.rd, RSA), sb = ld3(M.rd, RSB);
-      const K tk = M.rd.ld(RTK), tb = M.rd.ld(RTB), tL0 = M.rd.ld(RTL0);
-      const V3<K> xa = pick_bar(Ro.ba, kx), xb = pick_bar(Ro.bb, kx);
-      const V3<K> ra = sa.x * pick_bar(Ro.ba, kex) + (sa.y * pick_bar(Ro.ba, key) + sa.z * pick_bar(Ro.ba, kez));
-      const V3<K> rb = sb.x * pick_bar(Ro.bb, kex) + (sb.y * pick_bar(Ro.bb, key) + sb.z * pick_bar(Ro.bb, kez));
-      const V3<K> dif = (xb + rb) - (xa + ra);
+      const I ia = Ro.ba, ib = Ro.bb;
+      auto site = [&](I bar, V3<K> s) {  // world offset of a site: rotate its local coordinates by the bar's quaternion
+        const K w = M.kd.ld(KQ + 4 * bar);
+        const V3<K> qv = ld3(M.kd, KQ + 4 * bar + 1);
+        const V3<K> t = SK(2) * cross(qv, s);
+        return s + w * t + cross(qv, t);
+      };
+      const V3<K> ra = site(ia, ld3(M.rd, RSA));
+      TGR_SCHED();
+      const V3<K> rb = site(ib, ld3(M.rd, RSB));
+      TGR_SCHED();
+      const V3<K> dif = (ld3(M.kd, KX + 3 * ib) + rb) - (ld3(M.kd, KX + 3 * ia) + ra);
       const K L2 = dot(dif, dif);
       const K iL = rsqrt_(max_(L2, K(SK(1e-30))));
       const K L = L2 * iL;
       if (LAST) static_for<9>([&](auto tc) { constexpr int t = decltype(tc)::value; lag.tenL[t] = cvt<F>(bcast<t>(L)); });
       const V3<K> u = iL * dif;
-      const V3<K> va = cvt3<K>(pick_bar(Ro.ba, v)) + cross(cvt3<K>(pick_bar(Ro.ba, w)), ra);
-      const V3<K> vb = cvt3<K>(pick_bar(Ro.bb, v)) + cross(cvt3<K>(pick_bar(Ro.bb, w)), rb);
+      TGR_SCHED();
+      const V3<K> va = cvt3<K>(ld3(M.fd, FV + 3 * ia)) + cross(cvt3<K>(ld3(M.fd, FW + 3 * ia)), ra);
+      const V3<K> vb = cvt3<K>(ld3(M.fd, FV + 3 * ib)) + cross(cvt3<K>(ld3(M.fd, FW + 3 * ib)), rb);
       const K Ld = dot(u, vb - va);
-      F cin = M.fd.ld(FCTRL + 5), ain = M.fd.ld(FACT + 5);  // my actuator's control / activation (lanes >= 6: unused)
-      for (int t = 4; t >= 0; t--) { cin = sel(Ro.r == t, M.fd.ld(FCTRL + t), cin); if (MODEL) ain = sel(Ro.r == t, M.fd.ld(FACT + t), ain); }
+      TGR_SCHED();
+      const I ti = sel(Ro.actuated, Ro.r, I(0));  // my actuator (lanes >= 6: unused)
+      const K tk = M.rd.ld(RTK), tb = M.rd.ld(RTB), tL0 = M.rd.ld(RTL0);
       const K passive = -tk * (L - tL0) - tb * Ld;
       K f, damp;
       if (MODEL) {  // dyntype filter, no bias, no force limit (uneven xml:39)
-        f = sel(Ro.actuated, PK.gain * cvt<K>(ain), kzero) + passive;
+        f = sel(Ro.actuated, PK.gain * cvt<K>(M.fd.ld(FACT + ti)), kzero) + passive;
         damp = tb;
       } else {
-        const K cc = clamp_(cvt<K>(cin), K(PK.ctrl_lo), K(PK.ctrl_hi));
+        const K cc = clamp_(cvt<K>(M.fd.ld(FCTRL + ti)), K(PK.ctrl_lo), K(PK.ctrl_hi));
         const K fr = PK.gain * cc + PK.bias0 + PK.bias1 * L + PK.bias2 * Ld;
         const K fa = clamp_(fr, K(PK.force_lo), K(PK.force_hi));
         const auto clamped = (fa <= PK.force_lo) | (fa >= PK.force_hi);
@@ -673,39 +689,41 @@ TGR_PHASE(0);
         damp = sel(Ro.actuated, dact, kzero) + tb;
       }
       f = sel(Ro.is_ten, f, kzero);
+      TGR_SCHED();
       const V3<K> ma = cross(ra, u), mb = cross(rb, u);
       st3(M.td, TU, cvt3<F>(u)); st3(M.td, TMA, cvt3<F>(ma)); st3(M.td, TMB, cvt3<F>(mb));
       M.td.st(TDAMP, cvt<F>(sel(Ro.is_ten, damp, kzero)));
       for (int b = 0; b < 3; b++) {
-        const auto onb = Ro.bb == b, ona = Ro.ba == b;
+        const auto onb = ib == b, ona = ia == b;
         const K fb = sel(onb, f, kzero), fa_ = sel(ona, f, kzero);
         // the force sum only feeds linear accelerations (fp32 resolves them); the torque sum decides the spin about the bar's own axis
         V3<K> Fb = cvt3<K>(rowsum3(cvt3<F>((fb - fa_) * u)));
         const V3<K> Tb = rowsum3(fb * mb - fa_ * ma);
         Fb.z = Fb.z - PK.mass * PK.grav;
-        const V3<K> wk = cvt3<K>(w[b]);
-        const V3<K> Tq = Tb + (-(PK.Izz - PK.Ixx) * dot(kez[b], wk)) * cross(wk, kez[b]);  // gyroscopic
-        const V3<K> l0k = imk * Fb, a0k = inv_inertia(PK, kez[b], Tq);
-        st3(M.kd, KL0 + 3 * b, l0k); st3(M.kd, KA0 + 3 * b, a0k);
-        l0[b] = cvt3<F>(l0k); a0[b] = cvt3<F>(a0k);
+        const V3<K> wk = cvt3<K>(ld3(M.fd, FW + 3 * b)), kz = ld3(M.kd, KEZ + 3 * b);
+        const V3<K> Tq = Tb + (-(PK.Izz - PK.Ixx) * dot(kz, wk)) * cross(wk, kz);  // gyroscopic
+        st3(M.kd, KL0 + 3 * b, imk * Fb); st3(M.kd, KA0 + 3 * b, inv_inertia(PK, kz, Tq));
+        TGR_SCHED();
       }
     }
     TGR_PHASE(2);
     // ---- contacts (slot role)
+    const I jb = sel(Ro.sB >= 0, Ro.sB, I(0)), ja_ = sel(Ro.sA >= 0, Ro.sA, I(0));  // my slot's bars (a missing one reads bar 0 and is masked)
+    const auto hasA = Ro.sA >= 0;
     {
       // caps on the floor: the distance is a small difference of pose quantities -> K
-      const V3<K> kzc = pick_bar(Ro.sB, kez), kxc = pick_bar(Ro.sB, kx);
+      const V3<K> kzc = ld3(M.kd, KEZ + 3 * jb), kxc = ld3(M.kd, KX + 3 * jb);
       const K kdist = kxc.z + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc.z - PK.cap_r;
       const F dist = cvt<F>(kdist);
       const V3<F> arm = (Ro.cap_sign * P.bar_half) * cvt3<F>(kzc);
       F cc, dn;
       contact_params(P, dist, S(1), cc, dn);
       // bar pairs (every lane runs the routine; only pair lanes keep the outcome)
-      V3<F> xf[3];
-      for (int b = 0; b < 3; b++) xf[b] = cvt3<F>(kx[b]);
-      const V3<F> pxA = pick_bar0(Ro.sA, xf), pzA = pick_bar0(Ro.sA, ez), pxB = pick_bar0(Ro.sB, xf), pzB = pick_bar0(Ro.sB, ez);
+      const V3<F> pxA = cvt3<F>(ld3(M.kd, KX + 3 * ja_)), pzA = ld3(M.fd, FEZ + 3 * ja_), pxB = cvt3<F>(kxc), pzB = cvt3<F>(kzc);
       RContact<F> p0, p1;
+      TGR_SCHED();
       bar_pair_contacts(P, pxA, pzA, pxB, pzB, Ro.is_pair, p0, p1, dropped);
+      TGR_SCHED();
       const auto s0 = Ro.sub == 0;
       c.n = sel3(Ro.is_cap, mk<F>(zero, zero, F(S(1))), sel3(s0, p0.n, p1.n));
       c.rA = sel3(Ro.is_cap, z3, sel3(s0, p0.rA, p1.rA));
@@ -717,16 +735,16 @@ TGR_PHASE(0);
       // The torque of my contact force about the OWN AXIS of each of its bars is the one place where fp32 is not enough (1e-6 N m inside
       // 10 N m cross products; the bar's inertia about that axis is 0.0038 kg m^2):  z . (r x f + t) = f . (z x r) + t . z, with the
       // levers z x r in K.  For a cap the axial part of r drops out of z x r exactly, so only its small offset from the bar end is used.
-      const V3<K> kzA = pick_bar0(Ro.sA, kez);
+      const V3<K> kzA = sel3(hasA, ld3(M.kd, KEZ + 3 * ja_), kz3);
       const V3<K> offB = cvt3<K>(sel3(Ro.is_cap, c.rB - arm, c.rB));
       st3(M.ad, AMB, cross(kzc, offB)); st3(M.ad, AMA, cross(kzA, cvt3<K>(c.rA)));
       st3(M.ad, AZB, kzc); st3(M.ad, AZA, kzA);
     }
     // my slot's residual at the unconstrained acceleration
     {
-      V3<F> yl[3], ya[3];
-      for (int b = 0; b < 3; b++) { yl[b] = l0[b] + P.B * v[b]; ya[b] = a0[b] + P.B * w[b]; }
-      const V3<F> ylA = pick_bar0(Ro.sA, yl), yaA = pick_bar0(Ro.sA, ya), ylB = pick_bar0(Ro.sB, yl), yaB = pick_bar0(Ro.sB, ya);
+      const V3<F> ylB = cvt3<F>(ld3(M.kd, KL0 + 3 * jb)) + P.B * ld3(M.fd, FV + 3 * jb), yaB = cvt3<F>(ld3(M.kd, KA0 + 3 * jb)) + P.B * ld3(M.fd, FW + 3 * jb);
+      const V3<F> ylA = sel3(hasA, cvt3<F>(ld3(M.kd, KL0 + 3 * ja_)) + P.B * ld3(M.fd, FV + 3 * ja_), z3);
+      const V3<F> yaA = sel3(hasA, cvt3<F>(ld3(M.kd, KA0 + 3 * ja_)) + P.B * ld3(M.fd, FW + 3 * ja_), z3);
       jl0 = (ylB + cross(yaB, c.rB)) - (ylA + cross(yaA, c.rA)) + c.c0 * c.n;
       ja0 = yaB - yaA;
     }
@@ -736,20 +754,17 @@ TGR_PHASE(0);
   // ---- Newton on d = a - a0 (replicated).  Stopping rule: sqrt(g^T M^-1 g) < tol, in sqrt(kg) m/s^2.  mujoco's rule -- the plain norm
   // of g over (mean inertia x nv) -- lets a torque residual about a bar's own axis (inertia 0.0038 kg m^2) pass that still spins the bar
   // up by 1e-2 rad/s^2; weighting by M^-1 bounds the acceleration error itself (H >= M), which is what the tolerance on qvel is about.
-  DofC<F> dc;
-  dc.dof = Ro.is_dof; dc.ang = Ro.is_ang;
-  dc.e = mk<F>(sel(Ro.is_dof & (Ro.k == 0), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 1), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 2), F(S(1)), zero));
   // Everything the iterations share lives in the slabs, not in registers: the iterate d (fd: FDL / FDA, and picked for my slot's two
   // bars in cd), my contact slot (cd), the bar axes (fd: FEZ), the constraint wrench of the last assembly (fd: FFCL / FFCA, kd: KTAX).
   // Start: last sub-step's constraint acceleration (P.warm_start) -- a contact's reference acceleration moves by ~B h a every sub-step,
   // so last sub-step's ACCELERATION is a poor guess, but the part of it the contacts produced is a good one -- or zero.
   {
+    const Roles<F> Ro = lane_roles<F, MODEL>();
     V3<F> dl[3], da[3];
     for (int b = 0; b < 3; b++) {
       dl[b] = P.warm_start ? sel3(any_contact, ld3(M.fd, FDL + 3 * b), z3) : z3;
       da[b] = P.warm_start ? sel3(any_contact, ld3(M.fd, FDA + 3 * b), z3) : z3;
       st3(M.fd, FDL + 3 * b, dl[b]); st3(M.fd, FDA + 3 * b, da[b]);
-      st3(M.fd, FEZ + 3 * b, ez[b]);
     }
     st3(M.cd, CDLA, pick_bar0(Ro.sA, dl)); st3(M.cd, CDAA, pick_bar0(Ro.sA, da));
     st3(M.cd, CDLB, pick_bar0(Ro.sB, dl)); st3(M.cd, CDAB, pick_bar0(Ro.sB, da));
@@ -763,6 +778,10 @@ TGR_PHASE(0);
   TGR_FENCE();
   for (int it = 0;; it++) {
     TGR_PHASE(3);
+    const Roles<F> Ro = lane_roles<F, MODEL>();
+    DofC<F> dc;
+    dc.dof = Ro.is_dof; dc.ang = Ro.is_ang;
+    dc.e = mk<F>(sel(Ro.is_dof & (Ro.k == 0), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 1), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 2), F(S(1)), zero));
     // ---- my slot's residual jar at the current iterate, cone force
     RContact<F> cs;
     cs.n = ld3(M.cd, CN); cs.rA = ld3(M.cd, CRA); cs.rB = ld3(M.cd, CRB);
@@ -892,26 +911,27 @@ TGR_PHASE(0);
     }
   }
   // ---- implicitfast: (M + h sum_t b_t J_t J_t^T) a_new = F_smooth + F_constraint  (Woodbury over the nine tendons, tendon role).
-  V3<K> yak[3];          // angular acceleration by the constraint torque (K)
-  V3<F> ylc[3];          // linear acceleration by the constraint force
   V3<F> yl[3], ya[3];    // the damping correction
   {
-    V3<F> fl_[3], fa_[3];  // acceleration before the damping correction
-    for (int b = 0; b < 3; b++) {
-      // angular acceleration by the constraint torque: transverse part from the F sum, axial part from the K sum
-      const V3<K> kz = ld3(M.kd, KEZ + 3 * b);
-      const V3<K> kf = cvt3<K>(ld3(M.fd, FFCA + 3 * b));
-      yak[b] = (SK(1) / PK.Ixx) * kf + (M.kd.ld(KTAX + b) * (SK(1) / PK.Izz) - dot(kz, kf) * (SK(1) / PK.Ixx)) * kz;
-      ylc[b] = im * ld3(M.fd, FFCL + 3 * b);
-      fl_[b] = cvt3<F>(ld3(M.kd, KL0 + 3 * b)) + ylc[b];
-      fa_[b] = cvt3<F>(ld3(M.kd, KA0 + 3 * b) + yak[b]);
-    }
+    const Roles<F> Ro = lane_roles<F, MODEL>();
+    // acceleration before the damping correction, at my tendon's two bars (lane-indexed slab reads)
+    auto accel = [&](I bar, V3<F>& al_, V3<F>& aa_) {
+      const V3<K> kz = ld3(M.kd, KEZ + 3 * bar);
+      const V3<K> kf = cvt3<K>(ld3(M.fd, FFCA + 3 * bar));
+      const V3<K> yak = (SK(1) / PK.Ixx) * kf + (M.kd.ld(KTAX + bar) * (SK(1) / PK.Izz) - dot(kz, kf) * (SK(1) / PK.Ixx)) * kz;
+      al_ = cvt3<F>(ld3(M.kd, KL0 + 3 * bar)) + im * ld3(M.fd, FFCL + 3 * bar);
+      aa_ = cvt3<F>(ld3(M.kd, KA0 + 3 * bar) + yak);
+    };
+    V3<F> flA, faA, flB, faB;
+    accel(Ro.ba, flA, faA);
+    TGR_SCHED();
+    accel(Ro.bb, flB, faB);
+    TGR_SCHED();
     const F sc = sqrt_(P.h * M.td.ld(TDAMP));
     const V3<F> us = sc * ld3(M.td, TU), mas = sc * ld3(M.td, TMA), mbs = sc * ld3(M.td, TMB);
-    V3<F> ezl[3];
-    for (int b = 0; b < 3; b++) ezl[b] = ld3(M.fd, FEZ + 3 * b);
-    const V3<F> was = inv_inertia(P, pick_bar(Ro.ba, ezl), mas), wbs = inv_inertia(P, pick_bar(Ro.bb, ezl), mbs);
-    F zt = dot(us, pick_bar(Ro.bb, fl_) - pick_bar(Ro.ba, fl_)) + dot(mbs, pick_bar(Ro.bb, fa_)) - dot(mas, pick_bar(Ro.ba, fa_));
+    const V3<F> was = inv_inertia(P, ld3(M.fd, FEZ + 3 * Ro.ba), mas), wbs = inv_inertia(P, ld3(M.fd, FEZ + 3 * Ro.bb), mbs);
+    F zt = dot(us, flB - flA) + dot(mbs, faB) - dot(mas, faA);
+    TGR_SCHED();
     F Sr[9], il9[9];
     static_for<9>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
@@ -925,10 +945,12 @@ TGR_PHASE(0);
       v = v - sel(Ro.bb == as, uu + dot(mbs, wa2), zero);
       Sr[s] = sel(Ro.is_ten, v, zero);
     });
+    TGR_SCHED();
     rchol<9>(Sr, il9);
-    F zr[9], zd, zrep[9];
+    TGR_SCHED();
+    F zr[9], zd;
     rfwd<9>(Sr, il9, zt, zr);
-    rbwd<9>(Sr, il9, zr, zd, zrep);
+    rbwd<9>(Sr, il9, zr, zd, zr);
     for (int b = 0; b < 3; b++) {
       const auto ona = Ro.ba == b, onb = Ro.bb == b;
       const F ca = sel(ona, zd, zero) - sel(onb, zd, zero);
@@ -939,8 +961,12 @@ TGR_PHASE(0);
   TGR_PHASE(9);
   // ---- advance: v += h a ; x += h v ; q <- exp(h w / 2) * q   (world-frame w: left multiplication)
   for (int b = 0; b < 3; b++) {
-    const V3<K> vk = cvt3<K>(ld3(M.fd, FV + 3 * b)) + PK.h * (ld3(M.kd, KL0 + 3 * b) + cvt3<K>(ylc[b] + yl[b]));
-    const V3<K> wk = cvt3<K>(ld3(M.fd, FW + 3 * b)) + PK.h * ((ld3(M.kd, KA0 + 3 * b) + yak[b]) + cvt3<K>(ya[b]));
+    // acceleration = unconstrained (K) + by the constraint wrench (force and transverse torque from the F sums, axial torque from K) + damping
+    const V3<K> kz = ld3(M.kd, KEZ + 3 * b);
+    const V3<K> kf = cvt3<K>(ld3(M.fd, FFCA + 3 * b));
+    const V3<K> yak = (SK(1) / PK.Ixx) * kf + (M.kd.ld(KTAX + b) * (SK(1) / PK.Izz) - dot(kz, kf) * (SK(1) / PK.Ixx)) * kz;
+    const V3<K> vk = cvt3<K>(ld3(M.fd, FV + 3 * b)) + PK.h * (ld3(M.kd, KL0 + 3 * b) + cvt3<K>(im * ld3(M.fd, FFCL + 3 * b) + yl[b]));
+    const V3<K> wk = cvt3<K>(ld3(M.fd, FW + 3 * b)) + PK.h * ((ld3(M.kd, KA0 + 3 * b) + yak) + cvt3<K>(ya[b]));
     st3(M.fd, FV + 3 * b, cvt3<F>(vk));
     st3(M.fd, FW + 3 * b, cvt3<F>(wk));
     st3(M.kd, KX + 3 * b, ld3(M.kd, KX + 3 * b) + PK.h * vk);
@@ -952,8 +978,7 @@ TGR_PHASE(0);
     const K cs = SK(1) + x2 * (SK(-0.5) + x2 * (SK(1.0 / 24) + x2 * (SK(-1.0 / 720) + x2 * (SK(1.0 / 40320) + x2 * (SK(-1.0 / 3628800) + x2 * SK(1.0 / 479001600))))));
     const K k = hh * sinc;
     const K rw = cs, rx = k * w.x, ry = k * w.y, rz = k * w.z;
-    K q[4] = {M.kd.ld(KQ + 4 * b), M.kd.ld(KQ + 4 * b + 1), M.kd.ld(KQ + 4 * b + 2), M.kd.ld(KQ + 4 * b + 3)};
-    normalize_quat(q);  // (the same normalisation the sub-step started from)
+    const K q[4] = {M.kd.ld(KQ + 4 * b), M.kd.ld(KQ + 4 * b + 1), M.kd.ld(KQ + 4 * b + 2), M.kd.ld(KQ + 4 * b + 3)};  // (normalised at the start)
     M.kd.st(KQ + 4 * b, rw * q[0] - rx * q[1] - ry * q[2] - rz * q[3]);
     M.kd.st(KQ + 4 * b + 1, rw * q[1] + rx * q[0] + ry * q[3] - rz * q[2]);
     M.kd.st(KQ + 4 * b + 2, rw * q[2] - rx * q[3] + ry * q[0] + rz * q[1]);

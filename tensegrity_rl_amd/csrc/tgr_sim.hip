@@ -887,12 +887,12 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, 
         M.fd.st(row::FCTRL + i, E.env_kind == TGR_ENV_TR ? c0 + (a - c0) * E.dt : a);  // tr_env: _action_filter, k_FILTER = 1
       }
     }
-    const row::Roles<T> Ro = row::make_roles<TK, T, TK, MODEL>(ra.PK, M.rd);
+    row::store_role_consts<TK, T, TK, MODEL>(ra.PK, M.rd);
     row::RLag<TK, T> rl;
     row_lag_init<T, TK>(rl);
 #pragma unroll 1
-    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, Ro, M, rl);
-    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, Ro, M, rl);
+    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, M, rl);
+    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, M, rl);
     Sim<T> S;
     Lag<T> lag;
     row_export<T, TK>(M, rl, S, lag);
@@ -938,7 +938,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, 
   ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
   int step_num = 0;
   const int total = settle_total(E);
-  const row::Roles<T> Ro = row::make_roles<TK, T, TK, MODEL>(ra.PK, M.rd);
+  row::store_role_consts<TK, T, TK, MODEL>(ra.PK, M.rd);
   row::RLag<TK, T> rl;
   row_lag_init<T, TK>(rl);
   Lag<T> lag;
@@ -949,8 +949,8 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, 
 #pragma unroll 1
   for (int st = 0; st < total; st++) {
 #pragma unroll 1
-    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, Ro, M, rl);
-    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, Ro, M, rl);
+    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, M, rl);
+    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, M, rl);
     row_export<T, TK>(M, rl, S, lag);
     // the heading deque lives in global memory: one lane of the row pushes (the others would push the same value again)
     if (w0) settle_period_done(P, E, lag, st, ring, step_num, reset_psi, ms, xy_prev, lane_key(E, n, e), (unsigned long long)(unsigned)episode);

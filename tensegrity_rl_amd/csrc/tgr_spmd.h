@@ -23,6 +23,8 @@
 #include <cstring>
 #define TGR_RDEV inline
 #define TGR_FENCE() ((void)0)
+#define TGR_SCHED() ((void)0)
+#define TGR_LAUNDER(x) ((void)0)
 #endif
 
 namespace tgr {
@@ -31,7 +33,12 @@ namespace row {
 constexpr int ROW = 16;
 
 #ifndef TGR_ROW_EMUL
-#define TGR_PHASE(i) ((void)0)
+// nothing is scheduled across a phase mark: the machine scheduler otherwise hoists the next phase's loads over this phase's arithmetic
+// and the register allocator pays for it
+#define TGR_PHASE(i) __builtin_amdgcn_sched_barrier(0)
+#define TGR_SCHED() __builtin_amdgcn_sched_barrier(0)
+// the compiler must not connect this value with an earlier copy of it (so it is recomputed here instead of kept alive since there)
+#define TGR_LAUNDER(x) asm volatile("" : "+v"(x))
 // values parked in a slab must really be re-read after this point (no forwarding through registers), and nothing is scheduled across it
 #define TGR_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 // ------------------------------------------------------------------ device: a lane value is a plain scalar
@@ -170,8 +177,12 @@ template <typename L> struct Slab {
   L* p; int stride, off;
   TGR_RDEV L ld(int i) const { return p[i * stride + off]; }
   TGR_RDEV void st(int i, L v) const { p[i * stride + off] = v; }
+#ifdef TGR_ROW_EMUL
+  // lane-varying index (on the GPU that is the same ld(): every lane computes its own LDS address)
+  L ld(const Ln<int>& i) const { L r; for (int l = 0; l < ROW; l++) r.v[l] = p[i.v[l] * stride + off].v[l]; return r; }
+#endif
 };
-template <typename L> TGR_RDEV V3<L> ld3(const Slab<L>& s, int i);
+template <typename L, typename Ix> TGR_RDEV V3<L> ld3(const Slab<L>& s, Ix i);
 template <typename L> TGR_RDEV void st3(const Slab<L>& s, int i, V3<L> v);
 
 // ------------------------------------------------------------------ shared helpers (F = lane real: float/double or their Ln<>)
@@ -192,7 +203,7 @@ template <typename F, typename B> TGR_RDEV V3<F> sel3(B c, V3<F> a, V3<F> b) { r
 template <int K, typename F> TGR_RDEV V3<F> bcast3(V3<F> a) { return mk<F>(bcast<K>(a.x), bcast<K>(a.y), bcast<K>(a.z)); }
 template <typename F> TGR_RDEV V3<F> rowsum3(V3<F> a) { return mk<F>(rowsum(a.x), rowsum(a.y), rowsum(a.z)); }
 template <typename To, typename From> TGR_RDEV V3<To> cvt3(V3<From> a) { return mk<To>(cvt<To>(a.x), cvt<To>(a.y), cvt<To>(a.z)); }
-template <typename L> TGR_RDEV V3<L> ld3(const Slab<L>& s, int i) { return mk<L>(s.ld(i), s.ld(i + 1), s.ld(i + 2)); }
+template <typename L, typename Ix> TGR_RDEV V3<L> ld3(const Slab<L>& s, Ix i) { return mk<L>(s.ld(i), s.ld(i + 1), s.ld(i + 2)); }
 template <typename L> TGR_RDEV void st3(const Slab<L>& s, int i, V3<L> v) { s.st(i, v.x); s.st(i + 1, v.y); s.st(i + 2, v.z); }
 
 }  // namespace row

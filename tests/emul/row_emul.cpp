@@ -57,7 +57,7 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
     F fd[F_SLAB], td[T_SLAB], cd[C_SLAB];
     RMem<K, F> M;
     M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0}; M.cd = Slab<F>{cd, 1, 0};
-    const Roles<F> Ro = make_roles<K, F, TK, MODEL>(PK, M.rd);
+    store_role_consts<K, F, TK, MODEL>(PK, M.rd);
     RLag<K, F> lag;
     for (int b = 0; b < 3; b++) {
       const double* q = qpos + 21 * e + 7 * b;
@@ -74,8 +74,8 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
     for (int i = 0; i < 6; i++) { fd[FCTRL + i] = F(T(ctrl[6 * e + i])); fd[FACT + i] = F(T(act[6 * e + i])); }
     for (int i = 0; i < 18; i++) fd[FDL + i] = F(T(0));
     lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = F(T(0)); lag.n_own = F(T(0)); lag.cfrc_absmax = F(T(0)); lag.cfrc_clip_sq = F(T(0)); lag.bar_contact = F(T(0)); lag.overflow = F(T(0));
-    for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, Ro, M, lag);
-    substep<K, F, TK, T, MODEL, true>(PK, P, Ro, M, lag);
+    for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, M, lag);
+    substep<K, F, TK, T, MODEL, true>(PK, P, M, lag);
     for (int b = 0; b < 3; b++) {
       K qq[4] = {kd[KQ + 4 * b], kd[KQ + 4 * b + 1], kd[KQ + 4 * b + 2], kd[KQ + 4 * b + 3]};
       normalize_quat(qq);
