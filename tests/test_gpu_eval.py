@@ -57,3 +57,28 @@ def test_gym_env_info_carries_reference_keys():
     assert np.array_equal(info["real_observation"], obs)  # no observation noise: the same vector (tr_env.py:484-507)
     assert info["tendon_length"].shape == (9,) and np.allclose(info["tendon_length"], obs[36:45], atol=1e-5)
     env.close()
+
+
+def test_tracking_policy_whole_episode_statistics(golden_dir):
+    """The MuJoCo-trained tracking policy rolled for whole episodes (`_step_num > 1000`, tr_env.py:458) on all six reset poses,
+    deterministic and stochastic, against the statistics recorded at 4096 robots (tests/golden/tracking_policy_stats.json, written by
+    tests/gpu_tracking_stats.py on MI355X).  Quantities: arrival within 0.5 m of the way-point 3 m ahead, progress of more than a metre,
+    and how episodes end (1500 N rule / robot at rest = "unhealthy" / step limit).  This quantifies the behavioural anchor -- it does
+    not pin the physics: MuJoCo's own numbers for this policy are inside a pickle the loader rules forbid reading."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from gpu_tracking_stats import measure
+    ref = json.load(open(os.path.join(golden_dir, "tracking_policy_stats.json")))
+    for mode, det in (("deterministic", True), ("stochastic", False)):
+        got = measure(1024, det)
+        for k, v in ref[mode]["all"].items():
+            assert abs(got["all"][k] - v) < 0.06, (mode, k, got["all"][k], v)
+        for p in range(6):
+            for k in ("arrived_within_0.5m", "progressed_1m", "ended_by_step_limit"):
+                assert abs(got["per_pose"][str(p)][k] - ref[mode]["per_pose"][str(p)][k]) < 0.13, (mode, p, k)
+        assert abs(got["start_distance_median"] - 3.0) < 0.1
+    # what the numbers say: the gait depends on the start pose (poses 0 and 3 arrive 4-5x as often as 1 and 4), the stochastic policy
+    # (as in training) keeps moving to the step limit in > 80 % of the episodes, and the 1500 N rule ends < 10 %
+    s = ref["stochastic"]["all"]
+    assert s["ended_by_step_limit"] > 0.8 and s["ended_by_contact_force"] < 0.1
