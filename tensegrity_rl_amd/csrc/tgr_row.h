@@ -382,6 +382,151 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, V3<F> xA, V3<F> zA, V3<F> x
   dropped = sel(count > S(1), count - S(1), zero);
 }
 
+// ------------------------------------------------------------------ heightfield floor (MODEL 1), slot role, select form
+// closest point of triangle (a, b, c) to p (Ericson, Real-Time Collision Detection 5.1.5): every region evaluated, the first that applies
+// taken -- lanes of a row sit in different regions, so there is nothing to branch on
+template <typename F> TGR_RDEV V3<F> closest_on_triangle(V3<F> p, V3<F> a, V3<F> b, V3<F> c) {
+  typedef typename LaneTraits<F>::S S;
+  const V3<F> ab = b - a, ac = c - a, ap = p - a, bp = p - b, cp = p - c;
+  const F d1 = dot(ab, ap), d2 = dot(ac, ap), d3 = dot(ab, bp), d4 = dot(ac, bp), d5 = dot(ab, cp), d6 = dot(ac, cp);
+  const F vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+  const auto rA = (d1 <= S(0)) & (d2 <= S(0));
+  const auto rB = (d3 >= S(0)) & (d4 <= d3);
+  const auto rAB = (vc <= S(0)) & (d1 >= S(0)) & (d3 <= S(0));
+  const auto rC = (d6 >= S(0)) & (d5 <= d6);
+  const auto rAC = (vb <= S(0)) & (d2 >= S(0)) & (d6 <= S(0));
+  const auto rBC = (va <= S(0)) & ((d4 - d3) >= S(0)) & ((d5 - d6) >= S(0));
+  const V3<F> qAB = a + (d1 / (d1 - d3)) * ab;
+  const V3<F> qAC = a + (d2 / (d2 - d6)) * ac;
+  const V3<F> qBC = b + ((d4 - d3) / ((d4 - d3) + (d5 - d6))) * (c - b);
+  const F den = S(1) / (va + vb + vc);
+  const V3<F> qI = a + (vb * den) * ab + (vc * den) * ac;
+  return sel3(rA, a, sel3(rB, b, sel3(rAB, qAB, sel3(rC, c, sel3(rAC, qAC, sel3(rBC, qBC, qI))))));
+}
+// normalised elevation at grid vertex (cc, rr), clamped to the grid
+template <typename F, typename I, typename S> TGR_RDEV F hf_at(const RParams<S>& P, I cc, I rr) {
+  const I c = clampi(cc, 0, P.hf_ncol - 1), r = clampi(rr, 0, P.hf_nrow - 1);
+  return cvt<F>(gather_f(P.hf, r * P.hf_ncol + c)) * P.hf_ez;
+}
+// cap sphere (centre given relative to the heightfield's origin, K) against the terrain: the two deepest triangles of the (at most 2x2)
+// cells under it.  dist >= 0: no contact.  Same rules as tgr_device.h hfield_cap; coordinates are taken relative to the corner of the first
+// cell before they become F, so that a robot 30 m from the origin resolves its contact distance as well as one at the origin.
+template <typename K, typename F, typename SK, typename S>
+TGR_RDEV void hfield_cap(const RParams<SK>& PK, const RParams<S>& P, V3<K> pk, F* dist_out, V3<F>* n_out) {
+  typedef typename LaneTraits<F>::I I;
+  const S rad = P.cap_r;
+  const F zero = F(S(0));
+  const F px = cvt<F>(pk.x), py = cvt<F>(pk.y), pz = cvt<F>(pk.z);
+  const auto inb = !((px < -P.hf_rx - rad) | (px > P.hf_rx + rad) | (py < -P.hf_ry - rad) | (py > P.hf_ry + rad) | (pz > P.hf_ez + rad));
+  const S idx = S(1) / P.hf_dx, idy = S(1) / P.hf_dy;
+  I c0 = to_int(floor_((px - rad + P.hf_rx) * idx)), c1 = to_int(floor_((px + rad + P.hf_rx) * idx));
+  I r0 = to_int(floor_((py - rad + P.hf_ry) * idy)), r1 = to_int(floor_((py + rad + P.hf_ry) * idy));
+  c0 = clampi(c0, 0, P.hf_ncol - 2); r0 = clampi(r0, 0, P.hf_nrow - 2);   // (an out-of-range cap is masked by inb)
+  c1 = clampi(c1, 0, P.hf_ncol - 2); r1 = clampi(r1, 0, P.hf_nrow - 2);
+  F hz[3][3];
+  for (int j = 0; j < 3; j++)
+    for (int i = 0; i < 3; i++) hz[j][i] = hf_at<F>(P, c0 + i, r0 + j);
+  // position relative to the corner vertex (c0, r0), formed in K
+  const K x0 = cvt<K>(from_int(c0, F())) * PK.hf_dx - PK.hf_rx, y0 = cvt<K>(from_int(r0, F())) * PK.hf_dy - PK.hf_ry;
+  const V3<F> p = mk<F>(cvt<F>(pk.x - x0), cvt<F>(pk.y - y0), pz);
+  F bd0 = F(S(1)), bd1 = F(S(1));
+  V3<F> bq0 = p, bq1 = p;
+  for (int j = 0; j < 2; j++)
+    for (int i = 0; i < 2; i++) {
+      const auto cell = inb & ((c0 + i) <= c1) & ((r0 + j) <= r1);
+      const S xa = S(i) * P.hf_dx, ya = S(j) * P.hf_dy;
+      const V3<F> v[4] = {mk<F>(F(xa), F(ya), hz[j][i]), mk<F>(F(xa), F(ya + P.hf_dy), hz[j + 1][i]), mk<F>(F(xa + P.hf_dx), F(ya), hz[j][i + 1]),
+                          mk<F>(F(xa + P.hf_dx), F(ya + P.hf_dy), hz[j + 1][i + 1])};  // (c,r) (c,r+1) (c+1,r) (c+1,r+1)
+      for (int tri = 0; tri < 2; tri++) {
+        const V3<F> q = closest_on_triangle(p, v[tri], v[tri + 1], v[tri + 2]);
+        const V3<F> df = p - q;
+        const F dist = sqrt_(dot(df, df)) - rad;
+        const auto hit = cell & (dist < S(0));
+        const auto first = hit & (dist < bd0), second = hit & !(dist < bd0) & (dist < bd1);
+        bd1 = sel(first, bd0, sel(second, dist, bd1)); bq1 = sel3(first, bq0, sel3(second, q, bq1));
+        bd0 = sel(first, dist, bd0); bq0 = sel3(first, q, bq0);
+      }
+    }
+  {
+    const V3<F> df = p - bq0;
+    const F nn = sqrt_(dot(df, df));
+    const auto ok = (bd0 < S(0)) & (nn > S(1e-12));
+    dist_out[0] = sel(ok, bd0, F(S(1))); n_out[0] = sel3(ok, rcp_(max_(nn, F(S(1e-30)))) * df, mk<F>(zero, zero, F(S(1))));
+  }
+  {
+    const V3<F> df = p - bq1;
+    const F nn = sqrt_(dot(df, df));
+    const auto ok = (bd1 < S(0)) & (nn > S(1e-12));
+    dist_out[1] = sel(ok, bd1, F(S(1))); n_out[1] = sel3(ok, rcp_(max_(nn, F(S(1e-30)))) * df, mk<F>(zero, zero, F(S(1))));
+  }
+}
+// closest points of two segments c + s a (|s| <= ha) and c2 + t a2 (|t| <= hb), unit axes (Ericson 5.1.9), select form
+template <typename F, typename S> TGR_RDEV void seg_seg_closest(V3<F> ca, V3<F> aa, S ha, V3<F> cb, V3<F> ab, F hb, F& s_out, F& t_out) {
+  const V3<F> w = ca - cb;
+  const F b = dot(aa, ab), dA = dot(aa, w), dB = dot(ab, w);
+  const F den = S(1) - b * b;
+  const auto skew = den > S(1e-12);
+  const F iden = rcp_(sel(skew, den, F(S(1))));
+  const F s = sel(skew, (b * dB - dA) * iden, F(S(0))), t = sel(skew, (dB - b * dA) * iden, dB);
+  const auto interior = skew & (abs_(s) < ha) & (abs_(t) < hb);
+  const F s2 = clamp_(s, F(-ha), F(ha));
+  const F t2 = clamp_(dB + b * s2, -hb, hb);
+  const F s3 = clamp_(b * t2 - dA, F(-ha), F(ha));
+  s_out = sel(interior, s, s3); t_out = sel(interior, t, t2);
+}
+// the r-cylinder of a bar (centre relative to the heightfield's origin in K, axis az) against the terrain: deepest grid edge under the bar,
+// the bar taken as a capsule of the cylinder's radius.  Same rules as tgr_device.h hfield_rod.  Returns dist (>= 0: none), normal, arm.
+template <typename K, typename F, typename SK, typename S>
+TGR_RDEV F hfield_rod(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, V3<F> az, V3<F>& n_out, V3<F>& arm_out) {
+  typedef typename LaneTraits<F>::I I;
+  const S rad = P.rcyl_r, H = P.bar_half;
+  const F zero = F(S(0));
+  const F cx = cvt<F>(ck.x), cy = cvt<F>(ck.y), cz = cvt<F>(ck.z);
+  const F ex = abs_(az.x) * H + rad, ey = abs_(az.y) * H + rad;
+  auto inb = !((cx + ex < -P.hf_rx) | (cx - ex > P.hf_rx) | (cy + ey < -P.hf_ry) | (cy - ey > P.hf_ry));
+  inb = inb & !(cz - abs_(az.z) * H - rad > P.hf_ez);
+  const S idx = S(1) / P.hf_dx, idy = S(1) / P.hf_dy;
+  I c0 = to_int(floor_((cx - ex + P.hf_rx) * idx)), c1 = to_int(floor_((cx + ex + P.hf_rx) * idx));
+  I r0 = to_int(floor_((cy - ey + P.hf_ry) * idy)), r1 = to_int(floor_((cy + ey + P.hf_ry) * idy));
+  c0 = clampi(c0, 0, P.hf_ncol - 2); r0 = clampi(r0, 0, P.hf_nrow - 2);
+  c1 = clampi(c1, 0, P.hf_ncol - 2); r1 = clampi(r1, 0, P.hf_nrow - 2);
+  c1 = sel(c1 > c0 + 2, c0 + 2, c1); r1 = sel(r1 > r0 + 2, r0 + 2, r1);
+  F hz[4][4];
+  for (int j = 0; j < 4; j++)
+    for (int i = 0; i < 4; i++) hz[j][i] = hf_at<F>(P, c0 + i, r0 + j);
+  const K x0 = cvt<K>(from_int(c0, F())) * PK.hf_dx - PK.hf_rx, y0 = cvt<K>(from_int(r0, F())) * PK.hf_dy - PK.hf_ry;
+  const V3<F> c = mk<F>(cvt<F>(ck.x - x0), cvt<F>(ck.y - y0), cz);
+  F best = F(S(1));
+  V3<F> bpa = c, bpb = c;
+  for (int j = 0; j < 3; j++)
+    for (int i = 0; i < 3; i++) {
+      const auto cell = inb & ((c0 + i) <= c1) & ((r0 + j) <= r1);
+      const S xa = S(i) * P.hf_dx, ya = S(j) * P.hf_dy;
+      for (int k = 0; k < 3; k++) {
+        // edges of cell (c, r): (c,r)-(c+1,r), (c,r)-(c,r+1), and the strip diagonal (c,r+1)-(c+1,r)
+        const V3<F> va = k == 2 ? mk<F>(F(xa), F(ya + P.hf_dy), hz[j + 1][i]) : mk<F>(F(xa), F(ya), hz[j][i]);
+        const V3<F> vb = k == 1 ? mk<F>(F(xa), F(ya + P.hf_dy), hz[j + 1][i]) : mk<F>(F(xa + P.hf_dx), F(ya), hz[j][i + 1]);
+        V3<F> ed = vb - va;
+        const F el = sqrt_(dot(ed, ed));
+        ed = rcp_(el) * ed;
+        const V3<F> mid = S(0.5) * (va + vb);
+        F s_, t_;
+        seg_seg_closest(c, az, H, mid, ed, S(0.5) * el, s_, t_);
+        const V3<F> pa = c + s_ * az, pb = mid + t_ * ed;
+        const V3<F> df = pa - pb;
+        const F dist = sqrt_(dot(df, df)) - rad;
+        const auto take = cell & (dist < S(0)) & (dist < best);
+        best = sel(take, dist, best); bpa = sel3(take, pa, bpa); bpb = sel3(take, pb, bpb);
+      }
+    }
+  const V3<F> df = bpa - bpb;
+  const F nn = sqrt_(dot(df, df));
+  const auto ok = (best < S(0)) & (nn > S(1e-12));
+  n_out = sel3(ok, rcp_(max_(nn, F(S(1e-30)))) * df, mk<F>(zero, zero, F(S(1))));
+  arm_out = sel3(ok, (bpa - c) - (rad + S(0.5) * best) * n_out, mk<F>(zero, zero, zero));
+  return sel(ok, best, F(S(1)));
+}
+
 // ------------------------------------------------------------------ row-distributed dense algebra (lane i holds row i)
 // In-place Cholesky of an N x N SPD matrix whose row i lives in A[0..N) of lane i (full rows, both triangles).  Afterwards the
 // lower part of the rows holds L (A[j], j < i) and il[j] = 1 / L_jj is replicated.  Pivots are floored relative to the original
@@ -606,8 +751,8 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
 // Between its uses the environment's state lives in slabs (LDS on the GPU), not in registers:
 //   kd (K, replicated): pose x, q; unconstrained acceleration l0, a0; bar axes ez       fd (F, replicated): v, w, ctrl, act
 //   td (F, per lane):   tendon-role results u, ra x u, rb x u, damping                  rd (K, per lane, per block): tendon-role constants
-constexpr int KX = 0, KQ = 9, KL0 = 21, KA0 = 30, KEZ = 39, KTAX = 48, K_SLAB = 51;
-constexpr int FV = 0, FW = 9, FCTRL = 18, FACT = 24, FDL = 30, FDA = 39, FEZ = 48, FFCL = 57, FFCA = 66, F_SLAB = 75;  // FDL / FDA: d = a - a0
+constexpr int KX = 0, KQ = 9, KL0 = 21, KA0 = 30, KEZ = 39, KTAX = 48, KACT = 51, K_SLAB = 57;
+constexpr int FV = 0, FW = 9, FCTRL = 18, FDL = 30, FDA = 39, FEZ = 48, FFCL = 57, FFCA = 66, F_SLAB = 75;  // FDL / FDA: d = a - a0
 constexpr int TU = 0, TMA = 3, TMB = 6, TDAMP = 9, T_SLAB = 10;
 constexpr int CN = 0, CRA = 3, CRB = 6, CC0 = 9, CDN = 10, CACT = 11, CJL0 = 12, CJA0 = 15, CDLA = 18, CDAA = 21, CDLB = 24, CDAB = 27, C_SLAB = 30;  // cd (F, per lane): my contact slot
 constexpr int AMB = 0, AMA = 3, AZB = 6, AZA = 9, A_SLAB = 12;  // ad (K, per lane): my slot's axial levers z x r and axes z of its two bars
@@ -626,6 +771,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   const V3<K> kz3 = mk<K>(kzero, kzero, kzero);
   const S im = S(1) / P.mass;
   const SK imk = SK(1) / PK.mass;
+  typename LaneTraits<F>::B any1 = typename LaneTraits<F>::B(false);  // MODEL 1: my page-1 slot (a cap's second terrain contact) is active
   RContact<F> c;
   V3<F> jl0, ja0;  // my slot's residual at the unconstrained acceleration: J (a0 + B v) + c0 n
   F dropped;
@@ -676,7 +822,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       const K passive = -tk * (L - tL0) - tb * Ld;
       K f, damp;
       if (MODEL) {  // dyntype filter, no bias, no force limit (uneven xml:39)
-        f = sel(Ro.actuated, PK.gain * cvt<K>(M.fd.ld(FACT + ti)), kzero) + passive;
+        f = sel(Ro.actuated, PK.gain * M.kd.ld(KACT + ti), kzero) + passive;
         damp = tb;
       } else {
         const K cc = clamp_(cvt<K>(M.fd.ld(FCTRL + ti)), K(PK.ctrl_lo), K(PK.ctrl_hi));
@@ -713,11 +859,42 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     {
       // caps on the floor: the distance is a small difference of pose quantities -> K
       const V3<K> kzc = ld3(M.kd, KEZ + 3 * jb), kxc = ld3(M.kd, KX + 3 * jb);
-      const K kdist = kxc.z + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc.z - PK.cap_r;
-      const F dist = cvt<F>(kdist);
       const V3<F> arm = (Ro.cap_sign * P.bar_half) * cvt3<F>(kzc);
-      F cc, dn;
+      F dist, cc, dn;
+      V3<F> fn = mk<F>(zero, zero, F(S(1))), frB;  // normal and arm of my floor contact (cap, or MODEL 1: rod)
+      auto fhit = Ro.is_cap;
+      if (MODEL) {
+        // heightfield floor (uneven xml:48,56): caps get their two deepest triangles (page 0 / page 1), a bar's r-cylinder one edge
+        const V3<K> org = mk<K>(K(PK.hf_x0), K(PK.hf_y0), K(PK.hf_z0));
+        F d2[2]; V3<F> n2[2];
+        V3<F> rn, rarm;
+        hfield_cap<K, F>(PK, P, (kxc + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc) - org, d2, n2);
+        const F rd = hfield_rod<K, F>(PK, P, kxc - org, cvt3<F>(kzc), rn, rarm);
+        const auto hit0 = sel(Ro.is_cap, d2[0] < S(0), sel(Ro.is_rod, rd < S(0), false));
+        dist = sel(hit0, sel(Ro.is_cap, d2[0], rd), zero);
+        fn = sel3(Ro.is_cap, n2[0], rn);
+        frB = sel3(Ro.is_cap, arm - (P.cap_r + S(0.5) * dist) * n2[0], rarm);
+        fhit = hit0;
+        // page 1: the cap's second terrain contact
+        const auto hit1 = Ro.is_cap & (d2[1] < S(0));
+        const F dist1 = sel(hit1, d2[1], zero);
+        F cc1, dn1;
+        contact_params(P, dist1, S(1), cc1, dn1);
+        const V3<F> rB1 = arm - (P.cap_r + S(0.5) * dist1) * n2[1];
+        st3(M.cd, C_SLAB + CN, n2[1]); st3(M.cd, C_SLAB + CRA, z3); st3(M.cd, C_SLAB + CRB, rB1);
+        M.cd.st(C_SLAB + CC0, cc1); M.cd.st(C_SLAB + CDN, dn1); M.cd.st(C_SLAB + CACT, sel(hit1, F(S(1)), zero));
+        st3(M.ad, A_SLAB + AMB, cross(kzc, cvt3<K>(rB1 - arm))); st3(M.ad, A_SLAB + AZB, kzc);
+        const V3<F> ylB1 = cvt3<F>(ld3(M.kd, KL0 + 3 * jb)) + P.B * ld3(M.fd, FV + 3 * jb), yaB1 = cvt3<F>(ld3(M.kd, KA0 + 3 * jb)) + P.B * ld3(M.fd, FW + 3 * jb);
+        st3(M.cd, C_SLAB + CJL0, (ylB1 + cross(yaB1, rB1)) + cc1 * n2[1]); st3(M.cd, C_SLAB + CJA0, yaB1);
+        any1 = hit1;
+      } else {
+        const K kdist = kxc.z + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc.z - PK.cap_r;
+        dist = cvt<F>(kdist);
+        frB = mk<F>(arm.x, arm.y, arm.z - (P.cap_r + S(0.5) * dist));
+        fhit = Ro.is_cap & (dist < S(0));
+      }
       contact_params(P, dist, S(1), cc, dn);
+      const auto is_floor = MODEL ? (Ro.is_cap | Ro.is_rod) : Ro.is_cap;
       // bar pairs (every lane runs the routine; only pair lanes keep the outcome)
       const V3<F> pxA = cvt3<F>(ld3(M.kd, KX + 3 * ja_)), pzA = ld3(M.fd, FEZ + 3 * ja_), pxB = cvt3<F>(kxc), pzB = cvt3<F>(kzc);
       RContact<F> p0, p1;
@@ -725,12 +902,12 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       bar_pair_contacts(P, pxA, pzA, pxB, pzB, Ro.is_pair, p0, p1, dropped);
       TGR_SCHED();
       const auto s0 = Ro.sub == 0;
-      c.n = sel3(Ro.is_cap, mk<F>(zero, zero, F(S(1))), sel3(s0, p0.n, p1.n));
-      c.rA = sel3(Ro.is_cap, z3, sel3(s0, p0.rA, p1.rA));
-      c.rB = sel3(Ro.is_cap, mk<F>(arm.x, arm.y, arm.z - (P.cap_r + S(0.5) * dist)), sel3(s0, p0.rB, p1.rB));
-      c.c0 = sel(Ro.is_cap, cc, sel(s0, p0.c0, p1.c0));
-      c.Dn = sel(Ro.is_cap, dn, sel(s0, p0.Dn, p1.Dn));
-      c.active = sel(Ro.is_cap, dist < S(0), sel(Ro.is_pair, sel(s0, p0.active, p1.active), false));
+      c.n = sel3(is_floor, fn, sel3(s0, p0.n, p1.n));
+      c.rA = sel3(is_floor, z3, sel3(s0, p0.rA, p1.rA));
+      c.rB = sel3(is_floor, frB, sel3(s0, p0.rB, p1.rB));
+      c.c0 = sel(is_floor, cc, sel(s0, p0.c0, p1.c0));
+      c.Dn = sel(is_floor, dn, sel(s0, p0.Dn, p1.Dn));
+      c.active = sel(is_floor, fhit, sel(Ro.is_pair, sel(s0, p0.active, p1.active), false));
       dropped = sel(Ro.is_pair & s0, dropped, zero);
       // The torque of my contact force about the OWN AXIS of each of its bars is the one place where fp32 is not enough (1e-6 N m inside
       // 10 N m cross products; the bar's inertia about that axis is 0.0038 kg m^2):  z . (r x f + t) = f . (z x r) + t . z, with the
@@ -750,7 +927,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     }
   }
   if (LAST) lag.overflow = rowsum(dropped);
-  const auto any_contact = rowsum(sel(c.active, F(S(1)), zero)) > S(0);
+  const auto any_contact = rowsum(sel(c.active | any1, F(S(1)), zero)) > S(0);
   // ---- Newton on d = a - a0 (replicated).  Stopping rule: sqrt(g^T M^-1 g) < tol, in sqrt(kg) m/s^2.  mujoco's rule -- the plain norm
   // of g over (mean inertia x nv) -- lets a torque residual about a bar's own axis (inertia 0.0038 kg m^2) pass that still spins the bar
   // up by 1e-2 rad/s^2; weighting by M^-1 bounds the acceleration error itself (H >= M), which is what the tolerance on qvel is about.
@@ -789,21 +966,37 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     const V3<F> jl = ld3(M.cd, CJL0) + ((ld3(M.cd, CDLB) + cross(ld3(M.cd, CDAB), cs.rB)) - (ld3(M.cd, CDLA) + cross(ld3(M.cd, CDAA), cs.rA)));
     const V3<F> ja = ld3(M.cd, CJA0) + (ld3(M.cd, CDAB) - ld3(M.cd, CDAA));
     const RCone<F> o = cone_eval(P, cs, jl, ja);
+    // MODEL 1, page 1: a cap's second terrain contact (same bar, no body A)
+    RContact<F> cs1;
+    V3<F> jl1 = z3, ja1 = z3;
+    RCone<F> o1;
+    if (MODEL) {
+      cs1.n = ld3(M.cd, C_SLAB + CN); cs1.rA = z3; cs1.rB = ld3(M.cd, C_SLAB + CRB);
+      cs1.c0 = M.cd.ld(C_SLAB + CC0); cs1.Dn = M.cd.ld(C_SLAB + CDN); cs1.active = M.cd.ld(C_SLAB + CACT) != S(0);
+      jl1 = ld3(M.cd, C_SLAB + CJL0) + (ld3(M.cd, CDLB) + cross(ld3(M.cd, CDAB), cs1.rB));
+      ja1 = ld3(M.cd, C_SLAB + CJA0) + ld3(M.cd, CDAB);
+      o1 = cone_eval(P, cs1, jl1, ja1);
+    }
     TGR_PHASE(4);
     // ---- constraint wrench per bar, gradient (dof role: component r of each bar's residual)
-    const V3<F> tB = cross(cs.rB, o.fl) + o.fa, tA = cross(cs.rA, o.fl) + o.fa;
+    V3<F> fB = o.fl, tB = cross(cs.rB, o.fl) + o.fa;
+    const V3<F> tA = cross(cs.rA, o.fl) + o.fa;
     K tauB, tauA;
     {
       const V3<K> kfl = cvt3<K>(o.fl), kfa = cvt3<K>(o.fa);
       tauB = dot(kfl, ld3(M.ad, AMB)) + dot(kfa, ld3(M.ad, AZB));
       tauA = dot(kfl, ld3(M.ad, AMA)) + dot(kfa, ld3(M.ad, AZA));
     }
+    if (MODEL) {
+      fB = fB + o1.fl; tB = tB + cross(cs1.rB, o1.fl) + o1.fa;
+      tauB = tauB + dot(cvt3<K>(o1.fl), ld3(M.ad, A_SLAB + AMB)) + dot(cvt3<K>(o1.fa), ld3(M.ad, A_SLAB + AZB));
+    }
     K gn = kzero;  // g^T M^-1 g
     cfrc_max = zero;
     F gd[3];
     for (int b = 0; b < 3; b++) {
       const auto onb = Ro.sB == b, ona = Ro.sA == b;
-      const V3<F> fcl = rowsum3(sel3(onb, o.fl, z3) - sel3(ona, o.fl, z3));
+      const V3<F> fcl = rowsum3(sel3(onb, fB, z3) - sel3(ona, o.fl, z3));
       const V3<F> fca = rowsum3(sel3(onb, tB, z3) - sel3(ona, tA, z3));
       const K tax = rowsum(sel(onb, tauB, kzero) - sel(ona, tauA, kzero));
       st3(M.fd, FFCL + 3 * b, fcl); st3(M.fd, FFCA + 3 * b, fca); M.kd.st(KTAX + b, tax);
@@ -836,6 +1029,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     }
     for (int i = 0; i < 6; i++) { H.O10[i] = zero; H.O20[i] = zero; H.O21[i] = zero; }
     static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<0, decltype(cc)::value>(H, dc, cs, o); });
+    if (MODEL) static_for<6>([&](auto cc) { hess_add_slot<1, decltype(cc)::value>(H, dc, cs1, o1); });
     // which bar pairs does any environment of the wavefront couple?  (uniform: lets the factorisation skip zero blocks)
     const bool cp0 = any_slot<6>(cs.active) || any_slot<7>(cs.active), cp1 = any_slot<8>(cs.active) || any_slot<9>(cs.active),
                cp2 = any_slot<10>(cs.active) || any_slot<11>(cs.active);
@@ -859,6 +1053,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     const V3<F> ql = (plB + cross(paB, cs.rB)) - (plA + cross(paA, cs.rA));
     const V3<F> qa = paB - paA;
     const RLSlot<F> ls = ls_make(cs, jl, ja, ql, qa);
+    RLSlot<F> ls1;
+    if (MODEL) ls1 = ls_make(cs1, jl1, ja1, plB + cross(paB, cs1.rB), paB);
     conv = conv | !(abs_(d0) >= P.tol * P.tol);  // Newton decrement g^T H^-1 g (<= g^T M^-1 g) below tolerance
     conv = conv | !(d0 < S(0));                  // no descent left at working precision
     F alpha = sel(conv, zero, F(S(1))), lo = zero, hi = F(S(-1));
@@ -867,6 +1063,11 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     for (int k = 0;; k++) {
       F s1, s2;
       ls_slot(P, ls, alpha, s1, s2);
+      if (MODEL) {
+        F t1, t2;
+        ls_slot(P, ls1, alpha, t1, t2);
+        s1 = s1 + t1; s2 = s2 + t2;
+      }
       n_ls++;
       const F d1 = g1 + alpha * g2 + rowsum(s1), d2 = g2 + rowsum(s2);
       const auto small = abs_(d1) <= gtol;
@@ -986,8 +1187,9 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   }
   if (MODEL) {
     for (int a = 0; a < 6; a++) {
-      const F ac = M.fd.ld(FACT + a);
-      M.fd.st(FACT + a, ac + P.h * (clamp_(M.fd.ld(FCTRL + a), F(P.ctrl_lo), F(P.ctrl_hi)) - ac) * P.act_itau);
+      // (in K: the actuator gain is 15000 N per unit of activation, and twenty fp32 roundings of the activation are 1e-3 N)
+      const K ac = M.kd.ld(KACT + a);
+      M.kd.st(KACT + a, ac + PK.h * (cvt<K>(clamp_(M.fd.ld(FCTRL + a), F(P.ctrl_lo), F(P.ctrl_hi))) - ac) * PK.act_itau);
     }
   }
 }

@@ -759,33 +759,37 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
 // 256-thread blocks = 4 independent wavefronts x 4 environments; the 16 lanes of a row hold the environment's state replicated and
 // split the work by role.  No LDS in the physics (the observation tile is the only shared memory), no barrier inside a sub-step.
 // T: type of the state arrays / outputs; TK: type of pose, kinematics and tendon geometry inside the kernel (double in production).
-constexpr int ROW_ENVS = 16;  // environments per 256-thread block
+// environments per block (16 lanes each): 16 (256 threads), except the fp64 instantiation of the uneven-ground model, whose two pages of
+// contact slots would not fit the LDS -- 8 there (128 threads)
+template <typename T, int MODEL> constexpr int row_envs() { return (MODEL && sizeof(T) == 8) ? 8 : 16; }
 // wavefronts per SIMD the row kernels are compiled for (register budget 512 / waves): two for fp32 handles -- the donor rows of a
 // 4096-env random-action rollout bring the grid to ~2300 wavefronts on 1024 SIMDs -- one for the fp64 parity instantiation
 #ifndef TGR_ROW_WAVES
-#define TGR_ROW_WAVES(T) (sizeof(T) == 4 ? 2 : 1)
+#define TGR_ROW_WAVES(T, MODEL) ((sizeof(T) == 4 && !(MODEL)) ? 2 : 1)
 #endif
 
 template <typename T, typename TK> struct RowArgs { row::RParams<T> P; row::RParams<TK> PK; };
 
 // the row's state slabs in shared memory (tgr_row.h RMem): written and read by the 16 lanes of the row alone, so no barrier guards them
-template <typename T, typename TK> struct RowShared {
-  TK kd[ROW_ENVS * row::K_SLAB];
+template <typename T, typename TK, int MODEL> struct RowShared {
+  static constexpr int NE = row_envs<T, MODEL>(), PAGES = row::n_pages<MODEL>();
+  TK kd[NE * row::K_SLAB];
   TK rd[row::R_SLAB * 16];
-  TK ad[ROW_ENVS * row::A_SLAB * 16];
-  T fd[ROW_ENVS * row::F_SLAB];
-  T td[ROW_ENVS * row::T_SLAB * 16];
-  T cd[ROW_ENVS * row::C_SLAB * 16];
-  T tile[ROW_ENVS * 49];
+  TK ad[NE * row::A_SLAB * PAGES * 16];
+  T fd[NE * row::F_SLAB];
+  T td[NE * row::T_SLAB * 16];
+  T cd[NE * row::C_SLAB * PAGES * 16];
+  T tile[NE * 49];
 };
-template <typename T, typename TK> TGR_DEV row::RMem<TK, T> row_mem(RowShared<T, TK>& sh, int slot, int r) {
+template <typename T, typename TK, int MODEL> TGR_DEV row::RMem<TK, T> row_mem(RowShared<T, TK, MODEL>& sh, int slot, int r) {
+  constexpr int PAGES = row::n_pages<MODEL>();
   row::RMem<TK, T> M;
   M.kd = row::Slab<TK>{sh.kd + slot * row::K_SLAB, 1, 0};
   M.fd = row::Slab<T>{sh.fd + slot * row::F_SLAB, 1, 0};
   M.td = row::Slab<T>{sh.td + slot * row::T_SLAB * 16, 16, r};
   M.rd = row::Slab<TK>{sh.rd, 16, r};
-  M.ad = row::Slab<TK>{sh.ad + slot * row::A_SLAB * 16, 16, r};
-  M.cd = row::Slab<T>{sh.cd + slot * row::C_SLAB * 16, 16, r};
+  M.ad = row::Slab<TK>{sh.ad + slot * row::A_SLAB * PAGES * 16, 16, r};
+  M.cd = row::Slab<T>{sh.cd + slot * row::C_SLAB * PAGES * 16, 16, r};
   return M;
 }
 // state of the block kernels' layout -> the row's slabs
@@ -799,7 +803,7 @@ template <typename T, typename TK> TGR_DEV void row_import(const Sim<T>& S, cons
     M.fd.st(row::FW + 3 * b, S.w[b].x); M.fd.st(row::FW + 3 * b + 1, S.w[b].y); M.fd.st(row::FW + 3 * b + 2, S.w[b].z);
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, S.ctrl[i]); M.fd.st(row::FACT + i, S.act[i]); }
+  for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, S.ctrl[i]); M.kd.st(row::KACT + i, TK(S.act[i])); }
 #pragma unroll
   for (int i = 0; i < 18; i++) M.fd.st(row::FDL + i, T(0));
 }
@@ -821,7 +825,7 @@ template <typename T, typename TK> TGR_DEV void row_load(const T* st, int m, int
     row::st3(M.fd, row::FW + 3 * b, row::cvt3<T>(row::rot_apply(R, wb)));
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, st[(F_CTRL + i) * m + e]); M.fd.st(row::FACT + i, st[(F_ACT + i) * m + e]); }
+  for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, st[(F_CTRL + i) * m + e]); M.kd.st(row::KACT + i, TK(st[(F_ACT + i) * m + e])); }
 #pragma unroll
   for (int i = 0; i < 18; i++) M.fd.st(row::FDL + i, T(0));
 }
@@ -839,7 +843,7 @@ TGR_DEV void row_export(const row::RMem<TK, T>& M, const row::RLag<TK, T>& rl, S
     for (int i = 0; i < 4; i++) { S.q[b][i] = T(M.kd.ld(row::KQ + 4 * b + i)); lag.q[b][i] = T(rl.q[b][i]); }
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) { S.ctrl[i] = M.fd.ld(row::FCTRL + i); S.act[i] = M.fd.ld(row::FACT + i); }
+  for (int i = 0; i < 6; i++) { S.ctrl[i] = M.fd.ld(row::FCTRL + i); S.act[i] = T(M.kd.ld(row::KACT + i)); }
 #pragma unroll
   for (int i = 0; i < 9; i++) lag.tenL[i] = rl.tenL[i];
   lag.cfrc_absmax = rl.cfrc_absmax; lag.cfrc_clip_sq = rl.cfrc_clip_sq; lag.bar_contact = rl.bar_contact;
@@ -851,8 +855,9 @@ template <typename T, typename TK> TGR_DEV void row_lag_init(row::RLag<TK, T>& r
   for (int i = 0; i < 9; i++) rl.tenL[i] = T(0);
 }
 
-template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, TGR_ROW_WAVES(T)) void step_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
-  __shared__ RowShared<T, TK> sh;
+template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 * row_envs<T, MODEL>()), (TGR_ROW_WAVES(T, MODEL))) void step_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
+  constexpr int ROW_ENVS = row_envs<T, MODEL>();
+  __shared__ RowShared<T, TK, MODEL> sh;
   const int r = (int)(threadIdx.x & 15u);
   const int slot = (int)(threadIdx.x >> 4);  // environment of this row within the block
   const int gid = blockIdx.x * ROW_ENVS + slot;
@@ -868,7 +873,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, 
   const int D = E.obs_dim;
   const int Dp = (D & 1) ? D : D + 1;
   if (__any(active)) {  // (a wavefront of idle donor rows has nothing to do; the block still meets at the tile barrier below)
-    const row::RMem<TK, T> M = row_mem<T, TK>(sh, slot, r);
+    const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
     int episode = k.ist[I_EPISODE * m + e];
     if (donor_run && phase == PH_INIT) {
       Sim<T> S0;
@@ -916,8 +921,9 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, 
 }
 
 // reset_model() in one go, row layout: one row per entry of list[] (tgr_reset, and live envs that found no ready donor)
-template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, TGR_ROW_WAVES(T)) void settle_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
-  __shared__ RowShared<T, TK> sh;
+template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 * row_envs<T, MODEL>()), (TGR_ROW_WAVES(T, MODEL))) void settle_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
+  constexpr int ROW_ENVS = row_envs<T, MODEL>();
+  __shared__ RowShared<T, TK, MODEL> sh;
   const int r = (int)(threadIdx.x & 15u);
   const int slot = (int)(threadIdx.x >> 4);
   const int count = *k.list_count;
@@ -932,7 +938,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__(256, 
   const int episode = k.ist[I_EPISODE * m + e];
   Sim<T> S;
   init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
-  const row::RMem<TK, T> M = row_mem<T, TK>(sh, slot, r);
+  const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
   row_import<T, TK>(S, M);
   RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
   ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
@@ -1375,7 +1381,8 @@ template <typename T> static void params_to_row(const Params<T>& P, const tgr_co
   R.hf_rx = P.hf_rx; R.hf_ry = P.hf_ry; R.hf_ez = P.hf_ez; R.hf_x0 = P.hf_x0; R.hf_y0 = P.hf_y0; R.hf_z0 = P.hf_z0; R.hf_dx = P.hf_dx; R.hf_dy = P.hf_dy;
   R.hf_nrow = P.hf_nrow; R.hf_ncol = P.hf_ncol; R.hf = P.hf;
   const bool f32 = c.precision != TGR_PRECISION_F64;
-  R.tol = T(c.solver_tolerance > 0 ? c.solver_tolerance : (f32 ? 1e-3 : 1e-8));
+  // (uneven-ground model: 5 cm caps on tilted facets put more contact torque about the bars' own axes -- a tighter default keeps qvel inside 1e-4)
+  R.tol = T(c.solver_tolerance > 0 ? c.solver_tolerance : (f32 ? (c.model_kind ? 3e-4 : 1e-3) : 1e-8));
   R.max_iter = c.solver_iterations > 0 ? c.solver_iterations : (f32 ? 8 : 40);
   R.ls_iter = f32 ? 6 : 50;
 }
@@ -1385,11 +1392,8 @@ template <typename T> static void fill_row_args(const tgr_handle* h, const KArgs
   fill_args<double>(h, kd);
   params_to_row<double>(kd.P, h->cfg, ra.PK);
 }
-// which kernels step this handle: the row kernels wherever they exist (flat-floor model), the block kernels otherwise
-static bool use_row_kernels(const tgr_handle* h) {
-  if (h->cfg.kernel_layout == TGR_KERNEL_BLOCK) return false;
-  return h->cfg.model_kind == 0;
-}
+// which kernels step this handle: the row kernels unless the block kernels (the cross-check layout) are asked for
+static bool use_row_kernels(const tgr_handle* h) { return h->cfg.kernel_layout != TGR_KERNEL_BLOCK; }
 
 extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_handle** out) {
   if (!cfg || !out || n_envs <= 0) { g_err = "tgr_create: bad arguments"; return TGR_ERR_INVALID; }
@@ -1483,6 +1487,17 @@ extern "C" int tgr_stats(tgr_handle* h, uint64_t out[8]) {
   return TGR_OK;
 }
 
+// settle_kernel_row over (at most) cnt list entries
+template <typename T> static void launch_settle_row(const tgr_handle* h, int cnt, hipStream_t s, const KArgs<T>& k, const RowArgs<T, double>& ra) {
+  if (h->cfg.model_kind) {
+    constexpr int NE = row_envs<T, 1>();
+    hipLaunchKernelGGL((settle_kernel_row<T, double, 1>), dim3((cnt + NE - 1) / NE), dim3(16 * NE), 0, s, k, ra);
+  } else {
+    constexpr int NE = row_envs<T, 0>();
+    hipLaunchKernelGGL((settle_kernel_row<T, double, 0>), dim3((cnt + NE - 1) / NE), dim3(16 * NE), 0, s, k, ra);
+  }
+}
+
 template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, void* obs, hipStream_t s) {
   if (h->cfg.model_kind == 1 && !h->hf) { h->err = "tgr_reset: the uneven-ground model needs tgr_set_hfield first"; return TGR_ERR_INVALID; }
   std::vector<int> idx;
@@ -1504,7 +1519,7 @@ template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, 
   if (use_row_kernels(h)) {
     RowArgs<T, double> ra;
     fill_row_args<T>(h, k, ra);
-    hipLaunchKernelGGL((settle_kernel_row<T, double, 0>), dim3((cnt + ROW_ENVS - 1) / ROW_ENVS), dim3(256), 0, s, k, ra);
+    launch_settle_row<T>(h, cnt, s, k, ra);
   } else {
 #ifndef TGR_FAST_BUILD
     int blocks = (cnt + LW - 1) / LW;
@@ -1547,7 +1562,13 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
   RowArgs<T, double> ra;
   if (rowk) {
     fill_row_args<T>(h, k, ra);
-    hipLaunchKernelGGL((step_kernel_row<T, double, 0>), dim3((h->m + ROW_ENVS - 1) / ROW_ENVS), dim3(256), 0, s, k, ra);
+    if (h->cfg.model_kind) {
+      constexpr int NE = row_envs<T, 1>();
+      hipLaunchKernelGGL((step_kernel_row<T, double, 1>), dim3((h->m + NE - 1) / NE), dim3(16 * NE), 0, s, k, ra);
+    } else {
+      constexpr int NE = row_envs<T, 0>();
+      hipLaunchKernelGGL((step_kernel_row<T, double, 0>), dim3((h->m + NE - 1) / NE), dim3(16 * NE), 0, s, k, ra);
+    }
   } else {
 #ifndef TGR_FAST_BUILD
     int blocks = (h->m + LW - 1) / LW;
@@ -1563,7 +1584,7 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
     HIP_TRY(h, hipGetLastError());
     // envs that found no ready donor are settled here and now (grid sized for the worst case, exits on an empty list)
     if (rowk) {
-      hipLaunchKernelGGL((settle_kernel_row<T, double, 0>), dim3((h->n + ROW_ENVS - 1) / ROW_ENVS), dim3(256), 0, s, k, ra);
+      launch_settle_row<T>(h, h->n, s, k, ra);
     } else {
 #ifndef TGR_FAST_BUILD
       int sblocks = (h->n + LW - 1) / LW;

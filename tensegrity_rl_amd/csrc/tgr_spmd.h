@@ -86,6 +86,8 @@ template <int K> TGR_RDEV bool any_slot(bool flag) {
   return (__ballot(flag) & (0x0001000100010001ull << K)) != 0ull;
 }
 template <typename To, typename From> TGR_RDEV To cvt(From x) { return (To)x; }
+TGR_RDEV float gather_f(const float* base, int idx) { return base[idx]; }
+TGR_RDEV int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 #else
 // ------------------------------------------------------------------ host emulation: a lane value is the 16 scalars of a row
 template <typename T> struct Ln {
@@ -162,6 +164,8 @@ template <typename T> inline Ln<T> rowsum(const Ln<T>& x) {  // same butterfly a
 }
 template <typename T> inline Ln<T> rowmax(const Ln<T>& x) { T m = x.v[0]; for (int i = 1; i < ROW; i++) m = x.v[i] > m ? x.v[i] : m; return Ln<T>(m); }
 template <int K> inline bool any_slot(const Ln<bool>& flag) { return flag.v[K]; }
+inline Ln<float> gather_f(const float* base, const Ln<int>& idx) { Ln<float> r; for (int i = 0; i < ROW; i++) r.v[i] = base[idx.v[i]]; return r; }
+inline Ln<int> clampi(const Ln<int>& x, int lo, int hi) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = x.v[i] < lo ? lo : (x.v[i] > hi ? hi : x.v[i]); return r; }
 template <typename To, typename T> inline To cvt(const Ln<T>& x) { To r; for (int i = 0; i < ROW; i++) r.v[i] = (decltype(r.v[0] + 0))x.v[i]; return r; }
 #endif
 

@@ -53,8 +53,8 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
   int bad = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : bad)
   for (int e = 0; e < n; e++) {
-    K kd[K_SLAB], rd[R_SLAB], ad[A_SLAB];
-    F fd[F_SLAB], td[T_SLAB], cd[C_SLAB];
+    K kd[K_SLAB], rd[R_SLAB], ad[A_SLAB * n_pages<MODEL>()];
+    F fd[F_SLAB], td[T_SLAB], cd[C_SLAB * n_pages<MODEL>()];
     RMem<K, F> M;
     M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0}; M.cd = Slab<F>{cd, 1, 0};
     store_role_consts<K, F, TK, MODEL>(PK, M.rd);
@@ -71,7 +71,7 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
       for (int i = 0; i < 3; i++) fd[FV + 3 * b + i] = F(T(v[i]));
       st3(M.fd, FW + 3 * b, cvt3<F>(rot_apply(R, mk<K>(K(TK(v[3])), K(TK(v[4])), K(TK(v[5]))))));
     }
-    for (int i = 0; i < 6; i++) { fd[FCTRL + i] = F(T(ctrl[6 * e + i])); fd[FACT + i] = F(T(act[6 * e + i])); }
+    for (int i = 0; i < 6; i++) { fd[FCTRL + i] = F(T(ctrl[6 * e + i])); kd[KACT + i] = K(TK(act[6 * e + i])); }
     for (int i = 0; i < 18; i++) fd[FDL + i] = F(T(0));
     lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = F(T(0)); lag.n_own = F(T(0)); lag.cfrc_absmax = F(T(0)); lag.cfrc_clip_sq = F(T(0)); lag.bar_contact = F(T(0)); lag.overflow = F(T(0));
     for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, M, lag);
@@ -89,7 +89,7 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
       for (int i = 0; i < 3; i++) v[i] = fd[FV + 3 * b + i].v[0];
       v[3] = wb.x.v[0]; v[4] = wb.y.v[0]; v[5] = wb.z.v[0];
     }
-    for (int i = 0; i < 6; i++) act[6 * e + i] = fd[FACT + i].v[0];
+    for (int i = 0; i < 6; i++) act[6 * e + i] = kd[KACT + i].v[0];
     double* o = out + 32 * e;
     for (int t = 0; t < 9; t++) { o[t] = lag.tenL[t].v[0]; bad += check_rep(lag.tenL[t], "tenL", e); }
     for (int b = 0; b < 3; b++) { o[9 + 3 * b] = lag.x[b].x.v[0]; o[10 + 3 * b] = lag.x[b].y.v[0]; o[11 + 3 * b] = lag.x[b].z.v[0]; }
@@ -114,5 +114,7 @@ extern "C" int tgr_row_emul(int precision, int model, const double* params, cons
     if (precision == 2) return run<double, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
     return run<float, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
   }
-  return -1;
+  if (precision == 1) return run<double, double, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
+  if (precision == 2) return run<double, float, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
+  return run<float, float, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
 }

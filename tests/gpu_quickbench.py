@@ -15,7 +15,7 @@ for a in sys.argv[5:]:
         try:
             kw[k_] = float(v_)
         except ValueError:
-            kw[k_] = v_
+            kw[k_] = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', v_)) if v_.endswith('.npy') else v_
 env = TensegrityVecEnv(n, kind, auto_reset=bool(auto), **kw)
 t0 = time.time(); env.reset_tensors(); torch.cuda.synchronize(); t_reset = time.time() - t0
 g = torch.Generator(device="cuda"); g.manual_seed(0)

@@ -17,8 +17,8 @@ def terrain(golden_dir):
     return np.load(os.path.join(golden_dir, "terrain_100.npy"))
 
 
-@pytest.mark.parametrize("kind", ["tensegrity_env", "tr_env"])
-def test_uneven_fp64_matches_oracle(oracle, golden_dir, kind):
+@pytest.mark.parametrize("kind,layout", [("tensegrity_env", "row"), ("tr_env", "row"), ("tr_env", "block")])
+def test_uneven_fp64_matches_oracle(oracle, golden_dir, kind, layout):
     from tensegrity_rl_amd import TensegrityVecEnv
     from tensegrity_rl_amd.vec_env import heights_from_image
     O = oracle
@@ -28,7 +28,7 @@ def test_uneven_fp64_matches_oracle(oracle, golden_dir, kind):
     ob = O.OracleBatch(O.make_cfg(kind, "straight", heights=h, model_kind=1), n, seed=21)
     ob.reset()                                    # drops the robots ~0.8 m onto the terrain and settles them (reset_model)
     env = TensegrityVecEnv(n, kind + "-v0", desired_action="straight", precision="f64", auto_reset=False, seed=21,
-                           xml_file="3prism_jonathan_steady_side_uneven_ground.xml", terrain=img)
+                           xml_file="3prism_jonathan_steady_side_uneven_ground.xml", terrain=img, kernel_layout=layout)
     assert env.cfg.model_kind == 1 and env.cfg.cap_radius == 0.05
     rng = np.random.default_rng(2)
     ncon = nrod = 0
@@ -82,12 +82,15 @@ def test_uneven_full_size_rollout_fp32(golden_dir):
 
 
 def test_uneven_fp32_close_to_oracle(oracle, golden_dir):
-    """the fp32 instantiation of the MODEL = 1 kernels on identical (state, action): same tolerance statement as the flat model"""
+    """the fp32 handle (row kernels, MODEL = 1: pose / kinematics / tendons / activations in fp64, stopping rule 3e-4) on identical
+    (state, action): BASELINE.json's 1e-4 on qpos and qvel.  The bar is 98 % of env-steps rather than the flat model's 99 %: rounding the
+    state to fp32 between env-steps alone flips a facet choice in ~1 % of them (an fp64 run from the rounded state has the same outliers,
+    tests/test_row_emulation.py)."""
     from tensegrity_rl_amd import TensegrityVecEnv
     from tensegrity_rl_amd.vec_env import heights_from_image
     O = oracle
     img = terrain(golden_dir)
-    n = 128
+    n = 256
     ob = O.OracleBatch(O.make_cfg("tr_env", "straight", heights=heights_from_image(img), model_kind=1), n, seed=4)
     ob.reset()
     env = TensegrityVecEnv(n, "tr_env-v0", precision="f32", auto_reset=False, seed=4, model="uneven", terrain=img)
@@ -103,8 +106,8 @@ def test_uneven_fp32_close_to_oracle(oracle, golden_dir):
         eq.append(rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3)); ev.append(rel_env(st["qvel"] - v2, v2, 1e-2))
     eq, ev = np.concatenate(eq), np.concatenate(ev)
     print("uneven fp32: qpos median %.1e frac<1e-4 %.3f ; qvel median %.1e frac<1e-4 %.3f" % (np.median(eq), (eq < 1e-4).mean(), np.median(ev), (ev < 1e-4).mean()))
-    assert np.median(eq) < 1e-5 and (eq < 1e-4).mean() > 0.85
-    assert np.median(ev) < 1e-3
+    assert (eq < 1e-4).mean() >= 0.98 and (ev < 1e-4).mean() >= 0.98
+    assert np.median(eq) < 1e-6 and np.median(ev) < 2e-5
     env.close(); ob.close()
 
 
