@@ -14,7 +14,10 @@ DEPS = [SRC, os.path.join(HERE, "csrc", "tgr_device.h"), os.path.join(HERE, "csr
         os.path.join(os.path.dirname(HERE), "include", "tensegrity.h")]
 LIB = os.path.join(HERE, "libtensegrity.so")
 STAMP = LIB + ".srchash"
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+# -fno-slp-vectorize: the SLP vectoriser pairs the row kernels' fp32 arithmetic into v_pk_* instructions, which take as long as two scalar
+# ones on this hardware would if the pairs did not have to be assembled first -- 690 of the 4400 instructions of the Newton loop were
+# register moves doing that, and 135 VGPRs spilled (37 without it); measured +7 % env-steps/s
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize"]
 
 
 def lib_path():

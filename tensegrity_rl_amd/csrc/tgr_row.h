@@ -950,7 +950,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     st3(M.cd, CJL0, jl0); st3(M.cd, CJA0, ja0);
   }
   auto conv = !any_contact;
-  F cfrc_max = zero, bar_force = zero;
+  F bar_force = zero;
   int n_it = 0, n_ls = 0;
   TGR_FENCE();
   for (int it = 0;; it++) {
@@ -991,8 +991,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       fB = fB + o1.fl; tB = tB + cross(cs1.rB, o1.fl) + o1.fa;
       tauB = tauB + dot(cvt3<K>(o1.fl), ld3(M.ad, A_SLAB + AMB)) + dot(cvt3<K>(o1.fa), ld3(M.ad, A_SLAB + AZB));
     }
+    TGR_CENSUS(12);
     K gn = kzero;  // g^T M^-1 g
-    cfrc_max = zero;
     F gd[3];
     for (int b = 0; b < 3; b++) {
       const auto onb = Ro.sB == b, ona = Ro.sA == b;
@@ -1009,10 +1009,12 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       gn = gn + cvt<K>(im * dot(gl, gl) + (dot(ga, ga) - gz * gz) * (S(1) / P.Ixx)) + gax * gax * (SK(1) / PK.Izz);
       ga = ga + (cvt<F>(gax) - gz) * ezb;  // the direction is solved for the same axial residual the test looks at
       gd[b] = sel(Ro.is_dof, sel(Ro.is_ang, pick_comp(Ro.k, ga), pick_comp(Ro.k, gl)), zero);
-      cfrc_max = max_(cfrc_max, max_(max_(max_(abs_(fcl.x), abs_(fcl.y)), abs_(fcl.z)), max_(max_(abs_(fca.x), abs_(fca.y)), abs_(fca.z))));
     }
     if (LAST) bar_force = rowsum(sel(Ro.is_pair, sqrt_(dot(o.fl, o.fl)), zero));
     conv = conv | !(gn >= PK.tol * PK.tol);
+#ifdef TGR_ROW_TRACE
+    std::fprintf(stderr, "it %d gn %.3e conv %d\n", it, (double)gn.v[0], (int)conv.v[0]);
+#endif
     if (!any_lane(!conv) || it >= P.max_iter) break;
     n_it++;
     lag.n_own = lag.n_own + sel(conv, zero, F(S(1)));
@@ -1057,6 +1059,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     if (MODEL) ls1 = ls_make(cs1, jl1, ja1, plB + cross(paB, cs1.rB), paB);
     conv = conv | !(abs_(d0) >= P.tol * P.tol);  // Newton decrement g^T H^-1 g (<= g^T M^-1 g) below tolerance
     conv = conv | !(d0 < S(0));                  // no descent left at working precision
+    if (!any_lane(!conv)) break;                 // (the iterate stays where the wrench above was taken)
+    TGR_CENSUS(10);
     F alpha = sel(conv, zero, F(S(1))), lo = zero, hi = F(S(-1));
     auto ls_done = conv;
     const F gtol = P.ls_tol * abs_(d0);
@@ -1083,6 +1087,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       alpha = sel(go, na, alpha);
       if (!any_lane(!ls_done) || k + 1 >= P.ls_iter) break;
     }
+    TGR_CENSUS(11);
     for (int b = 0; b < 3; b++) {
       st3(M.fd, FDL + 3 * b, ld3(M.fd, FDL + 3 * b) + alpha * pl[b]);
       st3(M.fd, FDA + 3 * b, ld3(M.fd, FDA + 3 * b) + alpha * pa[b]);
@@ -1096,15 +1101,16 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   lag.n_it += n_it; lag.n_ls += n_ls;
   lag.n_unconv = lag.n_unconv + sel(conv, zero, F(S(1)));
   if (LAST) {
-    lag.cfrc_absmax = cfrc_max;
-    F sq = zero;
+    F sq = zero, cfrc_max = zero;
     for (int b = 0; b < 3; b++) {
       const V3<F> fl = ld3(M.fd, FFCL + 3 * b), fa = ld3(M.fd, FFCA + 3 * b);
+      cfrc_max = max_(cfrc_max, max_(max_(max_(abs_(fl.x), abs_(fl.y)), abs_(fl.z)), max_(max_(abs_(fa.x), abs_(fa.y)), abs_(fa.z))));
       const V3<F> a = mk<F>(clamp_(fl.x, F(P.cf_lo), F(P.cf_hi)), clamp_(fl.y, F(P.cf_lo), F(P.cf_hi)), clamp_(fl.z, F(P.cf_lo), F(P.cf_hi)));
       const V3<F> t = mk<F>(clamp_(fa.x, F(P.cf_lo), F(P.cf_hi)), clamp_(fa.y, F(P.cf_lo), F(P.cf_hi)), clamp_(fa.z, F(P.cf_lo), F(P.cf_hi)));
       sq = sq + dot(a, a) + dot(t, t);
     }
     lag.cfrc_clip_sq = sq;
+    lag.cfrc_absmax = cfrc_max;
     lag.bar_contact = bar_force;
     for (int b = 0; b < 3; b++) {  // qacc of the last forward pass (what mujoco keeps as qacc_warmstart)
       lag.al[b] = cvt3<F>(ld3(M.kd, KL0 + 3 * b)) + ld3(M.fd, FDL + 3 * b);
@@ -1133,6 +1139,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     const V3<F> was = inv_inertia(P, ld3(M.fd, FEZ + 3 * Ro.ba), mas), wbs = inv_inertia(P, ld3(M.fd, FEZ + 3 * Ro.bb), mbs);
     F zt = dot(us, flB - flA) + dot(mbs, faB) - dot(mas, faA);
     TGR_SCHED();
+    TGR_CENSUS(13);
     F Sr[9], il9[9];
     static_for<9>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
@@ -1147,11 +1154,13 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       Sr[s] = sel(Ro.is_ten, v, zero);
     });
     TGR_SCHED();
+    TGR_CENSUS(14);
     rchol<9>(Sr, il9);
     TGR_SCHED();
     F zr[9], zd;
     rfwd<9>(Sr, il9, zt, zr);
     rbwd<9>(Sr, il9, zr, zd, zr);
+    TGR_CENSUS(15);
     for (int b = 0; b < 3; b++) {
       const auto ona = Ro.ba == b, onb = Ro.bb == b;
       const F ca = sel(ona, zd, zero) - sel(onb, zd, zero);

@@ -759,9 +759,16 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
 // 256-thread blocks = 4 independent wavefronts x 4 environments; the 16 lanes of a row hold the environment's state replicated and
 // split the work by role.  No LDS in the physics (the observation tile is the only shared memory), no barrier inside a sub-step.
 // T: type of the state arrays / outputs; TK: type of pose, kinematics and tendon geometry inside the kernel (double in production).
-// environments per block (16 lanes each): 16 (256 threads), except the fp64 instantiation of the uneven-ground model, whose two pages of
-// contact slots would not fit the LDS -- 8 there (128 threads)
-template <typename T, int MODEL> constexpr int row_envs() { return (MODEL && sizeof(T) == 8) ? 8 : 16; }
+// environments per block (16 lanes each).  One wavefront per block: the blocks of a launch finish at very different times (Newton
+// iterations) and a 4096-env rollout with its donor rows is just over one round of the 2048 wave slots of the chip -- with 4-wave blocks
+// the last 64 blocks waited for whole blocks to drain and the launch took two wave life times; single waves slot in as soon as any
+// wave retires.  (20 KB of LDS per wave for the fp32 flat-floor kernels: 8 blocks per CU = 2 waves per SIMD.)
+#ifndef TGR_ROW_ENVS
+#define TGR_ROW_ENVS 4
+#endif
+template <typename T, int MODEL> constexpr int row_envs() { return TGR_ROW_ENVS; }
+// the flat-floor model keeps no activations: its K slab ends before KACT
+template <int MODEL> constexpr int k_slab() { return MODEL ? row::K_SLAB : row::KACT; }
 // wavefronts per SIMD the row kernels are compiled for (register budget 512 / waves): two for fp32 handles -- the donor rows of a
 // 4096-env random-action rollout bring the grid to ~2300 wavefronts on 1024 SIMDs -- one for the fp64 parity instantiation
 #ifndef TGR_ROW_WAVES
@@ -773,18 +780,17 @@ template <typename T, typename TK> struct RowArgs { row::RParams<T> P; row::RPar
 // the row's state slabs in shared memory (tgr_row.h RMem): written and read by the 16 lanes of the row alone, so no barrier guards them
 template <typename T, typename TK, int MODEL> struct RowShared {
   static constexpr int NE = row_envs<T, MODEL>(), PAGES = row::n_pages<MODEL>();
-  TK kd[NE * row::K_SLAB];
+  TK kd[NE * k_slab<MODEL>()];
   TK rd[row::R_SLAB * 16];
   TK ad[NE * row::A_SLAB * PAGES * 16];
   T fd[NE * row::F_SLAB];
   T td[NE * row::T_SLAB * 16];
-  T cd[NE * row::C_SLAB * PAGES * 16];
-  T tile[NE * 49];
+  T cd[NE * row::C_SLAB * PAGES * 16];  // (after the last sub-step: the row's observation line, <= 49 values)
 };
 template <typename T, typename TK, int MODEL> TGR_DEV row::RMem<TK, T> row_mem(RowShared<T, TK, MODEL>& sh, int slot, int r) {
   constexpr int PAGES = row::n_pages<MODEL>();
   row::RMem<TK, T> M;
-  M.kd = row::Slab<TK>{sh.kd + slot * row::K_SLAB, 1, 0};
+  M.kd = row::Slab<TK>{sh.kd + slot * k_slab<MODEL>(), 1, 0};
   M.fd = row::Slab<T>{sh.fd + slot * row::F_SLAB, 1, 0};
   M.td = row::Slab<T>{sh.td + slot * row::T_SLAB * 16, 16, r};
   M.rd = row::Slab<TK>{sh.rd, 16, r};
@@ -793,7 +799,7 @@ template <typename T, typename TK, int MODEL> TGR_DEV row::RMem<TK, T> row_mem(R
   return M;
 }
 // state of the block kernels' layout -> the row's slabs
-template <typename T, typename TK> TGR_DEV void row_import(const Sim<T>& S, const row::RMem<TK, T>& M) {
+template <typename T, typename TK, int MODEL> TGR_DEV void row_import(const Sim<T>& S, const row::RMem<TK, T>& M) {
 #pragma unroll
   for (int b = 0; b < 3; b++) {
     M.kd.st(row::KX + 3 * b, TK(S.x[b].x)); M.kd.st(row::KX + 3 * b + 1, TK(S.x[b].y)); M.kd.st(row::KX + 3 * b + 2, TK(S.x[b].z));
@@ -803,11 +809,11 @@ template <typename T, typename TK> TGR_DEV void row_import(const Sim<T>& S, cons
     M.fd.st(row::FW + 3 * b, S.w[b].x); M.fd.st(row::FW + 3 * b + 1, S.w[b].y); M.fd.st(row::FW + 3 * b + 2, S.w[b].z);
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, S.ctrl[i]); M.kd.st(row::KACT + i, TK(S.act[i])); }
+  for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, S.ctrl[i]); if (MODEL) M.kd.st(row::KACT + i, TK(S.act[i])); }
 #pragma unroll
   for (int i = 0; i < 18; i++) M.fd.st(row::FDL + i, T(0));
 }
-template <typename T, typename TK> TGR_DEV void row_load(const T* st, int m, int e, const row::RMem<TK, T>& M) {
+template <typename T, typename TK, int MODEL> TGR_DEV void row_load(const T* st, int m, int e, const row::RMem<TK, T>& M) {
 #pragma unroll
   for (int b = 0; b < 3; b++) {
 #pragma unroll
@@ -825,12 +831,12 @@ template <typename T, typename TK> TGR_DEV void row_load(const T* st, int m, int
     row::st3(M.fd, row::FW + 3 * b, row::cvt3<T>(row::rot_apply(R, wb)));
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, st[(F_CTRL + i) * m + e]); M.kd.st(row::KACT + i, TK(st[(F_ACT + i) * m + e])); }
+  for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, st[(F_CTRL + i) * m + e]); if (MODEL) M.kd.st(row::KACT + i, TK(st[(F_ACT + i) * m + e])); }
 #pragma unroll
   for (int i = 0; i < 18; i++) M.fd.st(row::FDL + i, T(0));
 }
 // the env layer (finish_lane, settle_period_done, make_obs ...) works on the block kernels' structs
-template <typename T, typename TK>
+template <typename T, typename TK, int MODEL>
 TGR_DEV void row_export(const row::RMem<TK, T>& M, const row::RLag<TK, T>& rl, Sim<T>& S, Lag<T>& lag) {
 #pragma unroll
   for (int b = 0; b < 3; b++) {
@@ -843,7 +849,7 @@ TGR_DEV void row_export(const row::RMem<TK, T>& M, const row::RLag<TK, T>& rl, S
     for (int i = 0; i < 4; i++) { S.q[b][i] = T(M.kd.ld(row::KQ + 4 * b + i)); lag.q[b][i] = T(rl.q[b][i]); }
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) { S.ctrl[i] = M.fd.ld(row::FCTRL + i); S.act[i] = T(M.kd.ld(row::KACT + i)); }
+  for (int i = 0; i < 6; i++) { S.ctrl[i] = M.fd.ld(row::FCTRL + i); S.act[i] = MODEL ? T(M.kd.ld(row::KACT + i)) : T(0); }
 #pragma unroll
   for (int i = 0; i < 9; i++) lag.tenL[i] = rl.tenL[i];
   lag.cfrc_absmax = rl.cfrc_absmax; lag.cfrc_clip_sq = rl.cfrc_clip_sq; lag.bar_contact = rl.bar_contact;
@@ -855,8 +861,14 @@ template <typename T, typename TK> TGR_DEV void row_lag_init(row::RLag<TK, T>& r
   for (int i = 0; i < 9; i++) rl.tenL[i] = T(0);
 }
 
+#ifdef TGR_WAVE_TIMES  // development aid: start / end time, iterations of every wavefront of the last step launch
+__device__ unsigned long long g_wave_times[4 * 16384];
+#endif
 template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 * row_envs<T, MODEL>()), (TGR_ROW_WAVES(T, MODEL))) void step_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
   constexpr int ROW_ENVS = row_envs<T, MODEL>();
+#ifdef TGR_WAVE_TIMES
+  const unsigned long long wt0 = wall_clock64();
+#endif
   __shared__ RowShared<T, TK, MODEL> sh;
   const int r = (int)(threadIdx.x & 15u);
   const int slot = (int)(threadIdx.x >> 4);  // environment of this row within the block
@@ -871,18 +883,17 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   const bool active = live || donor_run;
   const int total = settle_total(E);
   const int D = E.obs_dim;
-  const int Dp = (D & 1) ? D : D + 1;
-  if (__any(active)) {  // (a wavefront of idle donor rows has nothing to do; the block still meets at the tile barrier below)
+  if (__any(active)) {  // (a wavefront of idle donor rows has nothing to do)
     const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
     int episode = k.ist[I_EPISODE * m + e];
     if (donor_run && phase == PH_INIT) {
       Sim<T> S0;
       init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S0);
-      row_import<T, TK>(S0, M);
+      row_import<T, TK, MODEL>(S0, M);
       phase = total;
       if (valid && r == 0) { k.ist[I_SRC * m + e] = e; k.ist[I_SRCEP * m + e] = episode; k.ist[I_EPISODE * m + e] = episode + 1; }
     } else {
-      row_load<T, TK>(k.st, m, e, M);
+      row_load<T, TK, MODEL>(k.st, m, e, M);
     }
     if (live) {
 #pragma unroll
@@ -900,7 +911,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
     row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, M, rl);
     Sim<T> S;
     Lag<T> lag;
-    row_export<T, TK>(M, rl, S, lag);
+    row_export<T, TK, MODEL>(M, rl, S, lag);
     const bool w0 = r == 0;  // one lane of the row owns the env's global stores
     if ((threadIdx.x & 63u) == 0) {
       atomicAdd(&k.counters[3], (unsigned long long)lag.n_it);
@@ -912,11 +923,18 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
       const int nact = __popcll(__ballot(active && w0));
       if ((threadIdx.x & 63u) == 0) atomicAdd(&k.counters[7], (unsigned long long)(nact * E.frame_skip));
     }
-    finish_lane(k, S, lag, e, valid, live, active, w0, phase, total, sh.tile + slot * Dp);
+    T* const orow = sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16);  // the contact slots are dead now
+    finish_lane(k, S, lag, e, valid, live, active, w0, phase, total, orow);
+#ifdef TGR_WAVE_TIMES
+    if ((threadIdx.x & 63u) == 0) {
+      const int wv = blockIdx.x * (ROW_ENVS / 4) + (threadIdx.x >> 6);
+      if (wv < 16384) { g_wave_times[4 * wv] = wt0; g_wave_times[4 * wv + 1] = wall_clock64(); g_wave_times[4 * wv + 2] = (unsigned long long)lag.n_it; g_wave_times[4 * wv + 3] = __popcll(__ballot(active && w0)); }
+    }
+#endif
     // the observation of a live env leaves through the row's tile line: lane 0 wrote it, the 16 lanes store it (LDS operations of one
     // wavefront complete in order, so no barrier is needed)
     if (live)
-      for (int c = r; c < D; c += 16) k.obs[(size_t)e * D + c] = sh.tile[slot * Dp + c];
+      for (int c = r; c < D; c += 16) k.obs[(size_t)e * D + c] = orow[c];
   }
 }
 
@@ -939,7 +957,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   Sim<T> S;
   init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
   const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
-  row_import<T, TK>(S, M);
+  row_import<T, TK, MODEL>(S, M);
   RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
   ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
   int step_num = 0;
@@ -957,7 +975,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
 #pragma unroll 1
     for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, M, rl);
     row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, M, rl);
-    row_export<T, TK>(M, rl, S, lag);
+    row_export<T, TK, MODEL>(M, rl, S, lag);
     // the heading deque lives in global memory: one lane of the row pushes (the others would push the same value again)
     if (w0) settle_period_done(P, E, lag, st, ring, step_num, reset_psi, ms, xy_prev, lane_key(E, n, e), (unsigned long long)(unsigned)episode);
   }
@@ -974,7 +992,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   atomicAdd(&k.counters[1], 1ull);
   if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
   const int D = E.obs_dim;
-  T* orow = sh.tile + slot * ((D & 1) ? D : D + 1);
+  T* orow = sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16);
   make_obs(P, E, S, lag, wb, ms, orow);
   if (E.use_obs_noise) apply_obs_noise(E, lane_key(E, n, e), (unsigned)episode, 0, orow);
   T* op = e < n ? (k.obs_reset ? k.obs_reset + (size_t)e * D : nullptr) : k.dobs + (size_t)(e - n) * D;
@@ -1426,6 +1444,12 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   return TGR_OK;
 }
 
+#ifdef TGR_WAVE_TIMES
+extern "C" int tgr_debug_wave_times(unsigned long long* out, int n_waves) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(tgr::g_wave_times), sizeof(unsigned long long) * 4 * n_waves);
+  return 0;
+}
+#endif
 extern "C" int tgr_set_hfield(tgr_handle* h, const float* heights, int nrow, int ncol) {
   if (!h) return TGR_ERR_INVALID;
   if (!heights || nrow < 2 || ncol < 2) { h->err = "tgr_set_hfield: need a [nrow >= 2][ncol >= 2] array"; return TGR_ERR_INVALID; }

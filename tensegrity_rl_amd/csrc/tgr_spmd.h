@@ -36,6 +36,7 @@ constexpr int ROW = 16;
 // nothing is scheduled across a phase mark: the machine scheduler otherwise hoists the next phase's loads over this phase's arithmetic
 // and the register allocator pays for it
 #define TGR_PHASE(i) __builtin_amdgcn_sched_barrier(0)
+#define TGR_CENSUS(i) ((void)0)
 #define TGR_SCHED() __builtin_amdgcn_sched_barrier(0)
 // the compiler must not connect this value with an earlier copy of it (so it is recomputed here instead of kept alive since there)
 #define TGR_LAUNDER(x) asm volatile("" : "+v"(x))
@@ -101,8 +102,10 @@ struct OpCount { long long n[2][16]; int phase; };
 inline OpCount& opcount() { static thread_local OpCount c = {}; return c; }
 template <typename T> inline void op_tick() { OpCount& c = opcount(); c.n[sizeof(T) == 8 ? 1 : 0][c.phase]++; }
 #define TGR_PHASE(i) (::tgr::row::opcount().phase = (i))
+#define TGR_CENSUS(i) (::tgr::row::opcount().phase = (i))
 #else
 template <typename T> inline void op_tick() {}
+#define TGR_CENSUS(i) ((void)0)
 #define TGR_PHASE(i) ((void)0)
 #endif
 template <typename F> struct LaneTraits;
