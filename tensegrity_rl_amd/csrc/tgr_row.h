@@ -757,7 +757,15 @@ constexpr int TU = 0, TMA = 3, TMB = 6, TDAMP = 9, T_SLAB = 10;
 constexpr int CN = 0, CRA = 3, CRB = 6, CC0 = 9, CDN = 10, CACT = 11, CJL0 = 12, CJA0 = 15, CDLA = 18, CDAA = 21, CDLB = 24, CDAB = 27, C_SLAB = 30;  // cd (F, per lane): my contact slot
 constexpr int AMB = 0, AMA = 3, AZB = 6, AZA = 9, A_SLAB = 12;  // ad (K, per lane): my slot's axial levers z x r and axes z of its two bars
 constexpr int RSA = 0, RSB = 3, RTK = 6, RTB = 7, RTL0 = 8, R_SLAB = 9;
-template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; };
+// hd (F, replicated): the solver's history -- the iterate d the sub-step before last ended on (18) and whether the last two sub-steps
+// had contacts (2).  On the GPU it lives in columns 9 and 10 of the tendon slab (lanes 9.. own no tendon): hidx() is its addressing.
+constexpr int HD = 0, HPC = 18, HPPC = 19, H_SLAB = 20;
+#ifdef TGR_ROW_EMUL
+constexpr int hidx(int i) { return i; }
+#else
+constexpr int hidx(int i) { return (i % 10) * 16 + i / 10; }
+#endif
+template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; Slab<F> hd; };
 
 // `LAST`: what only the last sub-step of a control period records (lagged kinematics, tendon lengths, contact wrench).
 // K / PK: lane and scalar type of the pose, the kinematics, the tendon geometry and the smooth forces; F / P: of the rest.
@@ -837,8 +845,13 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       f = sel(Ro.is_ten, f, kzero);
       TGR_SCHED();
       const V3<K> ma = cross(ra, u), mb = cross(rb, u);
-      st3(M.td, TU, cvt3<F>(u)); st3(M.td, TMA, cvt3<F>(ma)); st3(M.td, TMB, cvt3<F>(mb));
-      M.td.st(TDAMP, cvt<F>(sel(Ro.is_ten, damp, kzero)));
+#ifndef TGR_ROW_EMUL
+      if (lane_id() < 9)  // (the other lanes' columns of this slab hold the solver's history, hd)
+#endif
+      {
+        st3(M.td, TU, cvt3<F>(u)); st3(M.td, TMA, cvt3<F>(ma)); st3(M.td, TMB, cvt3<F>(mb));
+        M.td.st(TDAMP, cvt<F>(damp));
+      }
       for (int b = 0; b < 3; b++) {
         const auto onb = ib == b, ona = ia == b;
         const K fb = sel(onb, f, kzero), fa_ = sel(ona, f, kzero);
@@ -938,9 +951,21 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   {
     const Roles<F> Ro = lane_roles<F, MODEL>();
     V3<F> dl[3], da[3];
+    const F pc = M.hd.ld(hidx(HPC)), ppc = M.hd.ld(hidx(HPPC));
+    #ifndef TGR_WX
+#define TGR_WX 0.75
+#endif
+    const F wx = S(TGR_WX) * pc * ppc;
+    M.hd.st(hidx(HPPC), pc); M.hd.st(hidx(HPC), sel(any_contact, F(S(1)), zero));
     for (int b = 0; b < 3; b++) {
-      dl[b] = P.warm_start ? sel3(any_contact, ld3(M.fd, FDL + 3 * b), z3) : z3;
-      da[b] = P.warm_start ? sel3(any_contact, ld3(M.fd, FDA + 3 * b), z3) : z3;
+      // ... extrapolated by 3/4 of its last change when the two sub-steps before this one both had contacts (-9 % iterations)
+      const V3<F> cl = ld3(M.fd, FDL + 3 * b), ca = ld3(M.fd, FDA + 3 * b);
+      const V3<F> ql_ = mk<F>(M.hd.ld(hidx(HD + 3 * b)), M.hd.ld(hidx(HD + 3 * b + 1)), M.hd.ld(hidx(HD + 3 * b + 2)));
+      const V3<F> qa_ = mk<F>(M.hd.ld(hidx(HD + 9 + 3 * b)), M.hd.ld(hidx(HD + 9 + 3 * b + 1)), M.hd.ld(hidx(HD + 9 + 3 * b + 2)));
+      M.hd.st(hidx(HD + 3 * b), cl.x); M.hd.st(hidx(HD + 3 * b + 1), cl.y); M.hd.st(hidx(HD + 3 * b + 2), cl.z);
+      M.hd.st(hidx(HD + 9 + 3 * b), ca.x); M.hd.st(hidx(HD + 9 + 3 * b + 1), ca.y); M.hd.st(hidx(HD + 9 + 3 * b + 2), ca.z);
+      dl[b] = P.warm_start ? sel3(any_contact, cl + wx * (cl - ql_), z3) : z3;
+      da[b] = P.warm_start ? sel3(any_contact, ca + wx * (ca - qa_), z3) : z3;
       st3(M.fd, FDL + 3 * b, dl[b]); st3(M.fd, FDA + 3 * b, da[b]);
     }
     st3(M.cd, CDLA, pick_bar0(Ro.sA, dl)); st3(M.cd, CDAA, pick_bar0(Ro.sA, da));
@@ -996,15 +1021,18 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     F gd[3];
     for (int b = 0; b < 3; b++) {
       const auto onb = Ro.sB == b, ona = Ro.sA == b;
+      // (the slab reads of this bar go out before its row sums, whose DPP chains cover their latency)
+      const V3<F> dl = ld3(M.fd, FDL + 3 * b), da = ld3(M.fd, FDA + 3 * b), ezb = ld3(M.fd, FEZ + 3 * b);
+      const V3<K> kez = ld3(M.kd, KEZ + 3 * b);
+      TGR_SCHED();
       const V3<F> fcl = rowsum3(sel3(onb, fB, z3) - sel3(ona, o.fl, z3));
       const V3<F> fca = rowsum3(sel3(onb, tB, z3) - sel3(ona, tA, z3));
       const K tax = rowsum(sel(onb, tauB, kzero) - sel(ona, tauA, kzero));
       st3(M.fd, FFCL + 3 * b, fcl); st3(M.fd, FFCA + 3 * b, fca); M.kd.st(KTAX + b, tax);
-      const V3<F> dl = ld3(M.fd, FDL + 3 * b), da = ld3(M.fd, FDA + 3 * b), ezb = ld3(M.fd, FEZ + 3 * b);
       const V3<F> gl = P.mass * dl - fcl;
       V3<F> ga = inertia_mul(P, ezb, da) - fca;
       // M-norm of the residual: force and transverse torque in F, the axial torque from K
-      const K gax = PK.Izz * dot(ld3(M.kd, KEZ + 3 * b), cvt3<K>(da)) - tax;
+      const K gax = PK.Izz * dot(kez, cvt3<K>(da)) - tax;
       const F gz = dot(ezb, ga);
       gn = gn + cvt<K>(im * dot(gl, gl) + (dot(ga, ga) - gz * gz) * (S(1) / P.Ixx)) + gax * gax * (SK(1) / PK.Izz);
       ga = ga + (cvt<F>(gax) - gz) * ezb;  // the direction is solved for the same axial residual the test looks at
@@ -1134,8 +1162,9 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     TGR_SCHED();
     accel(Ro.bb, flB, faB);
     TGR_SCHED();
-    const F sc = sqrt_(P.h * M.td.ld(TDAMP));
-    const V3<F> us = sc * ld3(M.td, TU), mas = sc * ld3(M.td, TMA), mbs = sc * ld3(M.td, TMB);
+    // (lanes 9.. own no tendon: what they read here is the solver's history or never written -- zero, not garbage, enters the row sums)
+    const F sc = sqrt_(P.h * sel(Ro.is_ten, M.td.ld(TDAMP), zero));
+    const V3<F> us = sc * sel3(Ro.is_ten, ld3(M.td, TU), z3), mas = sc * sel3(Ro.is_ten, ld3(M.td, TMA), z3), mbs = sc * sel3(Ro.is_ten, ld3(M.td, TMB), z3);
     const V3<F> was = inv_inertia(P, ld3(M.fd, FEZ + 3 * Ro.ba), mas), wbs = inv_inertia(P, ld3(M.fd, FEZ + 3 * Ro.bb), mbs);
     F zt = dot(us, flB - flA) + dot(mbs, faB) - dot(mas, faA);
     TGR_SCHED();

@@ -793,6 +793,7 @@ template <typename T, typename TK, int MODEL> TGR_DEV row::RMem<TK, T> row_mem(R
   M.kd = row::Slab<TK>{sh.kd + slot * k_slab<MODEL>(), 1, 0};
   M.fd = row::Slab<T>{sh.fd + slot * row::F_SLAB, 1, 0};
   M.td = row::Slab<T>{sh.td + slot * row::T_SLAB * 16, 16, r};
+  M.hd = row::Slab<T>{sh.td + slot * row::T_SLAB * 16 + 9, 1, 0};  // columns 9, 10 of the tendon slab (tgr_row.h hidx)
   M.rd = row::Slab<TK>{sh.rd, 16, r};
   M.ad = row::Slab<TK>{sh.ad + slot * row::A_SLAB * PAGES * 16, 16, r};
   M.cd = row::Slab<T>{sh.cd + slot * row::C_SLAB * PAGES * 16, 16, r};
@@ -812,6 +813,8 @@ template <typename T, typename TK, int MODEL> TGR_DEV void row_import(const Sim<
   for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, S.ctrl[i]); if (MODEL) M.kd.st(row::KACT + i, TK(S.act[i])); }
 #pragma unroll
   for (int i = 0; i < 18; i++) M.fd.st(row::FDL + i, T(0));
+#pragma unroll
+  for (int i = 0; i < row::H_SLAB; i++) M.hd.st(row::hidx(i), T(0));
 }
 template <typename T, typename TK, int MODEL> TGR_DEV void row_load(const T* st, int m, int e, const row::RMem<TK, T>& M) {
 #pragma unroll
@@ -834,6 +837,8 @@ template <typename T, typename TK, int MODEL> TGR_DEV void row_load(const T* st,
   for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, st[(F_CTRL + i) * m + e]); if (MODEL) M.kd.st(row::KACT + i, TK(st[(F_ACT + i) * m + e])); }
 #pragma unroll
   for (int i = 0; i < 18; i++) M.fd.st(row::FDL + i, T(0));
+#pragma unroll
+  for (int i = 0; i < row::H_SLAB; i++) M.hd.st(row::hidx(i), T(0));
 }
 // the env layer (finish_lane, settle_period_done, make_obs ...) works on the block kernels' structs
 template <typename T, typename TK, int MODEL>

@@ -54,9 +54,10 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : bad)
   for (int e = 0; e < n; e++) {
     K kd[K_SLAB], rd[R_SLAB], ad[A_SLAB * n_pages<MODEL>()];
+    F hd[H_SLAB];
     F fd[F_SLAB], td[T_SLAB], cd[C_SLAB * n_pages<MODEL>()];
     RMem<K, F> M;
-    M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0}; M.cd = Slab<F>{cd, 1, 0};
+    M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0}; M.cd = Slab<F>{cd, 1, 0}; M.hd = Slab<F>{hd, 1, 0};
     store_role_consts<K, F, TK, MODEL>(PK, M.rd);
     RLag<K, F> lag;
     for (int b = 0; b < 3; b++) {
@@ -73,6 +74,7 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
     }
     for (int i = 0; i < 6; i++) { fd[FCTRL + i] = F(T(ctrl[6 * e + i])); kd[KACT + i] = K(TK(act[6 * e + i])); }
     for (int i = 0; i < 18; i++) fd[FDL + i] = F(T(0));
+    for (int i = 0; i < H_SLAB; i++) hd[i] = F(T(0));
     lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = F(T(0)); lag.n_own = F(T(0)); lag.cfrc_absmax = F(T(0)); lag.cfrc_clip_sq = F(T(0)); lag.bar_contact = F(T(0)); lag.overflow = F(T(0));
     for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, M, lag);
     substep<K, F, TK, T, MODEL, true>(PK, P, M, lag);
