@@ -127,10 +127,10 @@ typedef struct tgr_config {
    * qvel = s * N(0, 1)^18.  The reference draws from self.np_random; here philox keyed (seed; lane key, episode), counters 16..26
    * (uniforms) and 32..40 (Box-Muller normals) */
   double reset_noise_scale;
-  /* which kernels step the handle.  TGR_KERNEL_ROW: one environment per 16-lane DPP row, 4 per wavefront, no LDS (tgr_row.h); pose,
-   * kinematics, tendon geometry and the Newton gradient in fp64 inside the kernel when the handle is fp32 ("mixed precision");
-   * solver_tolerance then bounds sqrt(g^T M^-1 g).  TGR_KERNEL_BLOCK: 64 environments x 4 wavefronts with per-lane LDS columns
-   * (tgr_device.h), all arithmetic in the handle's precision, mujoco's stopping rule.  AUTO = ROW wherever it exists (flat-floor model) */
+  /* which kernels step the handle.  TGR_KERNEL_ROW: one environment per 16-lane DPP row, 4 per wavefront, state parked in LDS slabs
+   * (tgr_row.h); pose, kinematics, tendon geometry and axial torques in fp64 inside the kernel when the handle is fp32 ("mixed
+   * precision"); solver_tolerance then bounds sqrt(g^T M^-1 g).  TGR_KERNEL_BLOCK: 64 environments x 4 wavefronts with per-lane LDS
+   * columns (tgr_device.h), all arithmetic in the handle's precision, mujoco's stopping rule: kept as a cross-check.  AUTO = ROW */
   int32_t kernel_layout;
 } tgr_config;
 
