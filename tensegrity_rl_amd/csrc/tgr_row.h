@@ -59,8 +59,8 @@ template <int MODEL> constexpr int n_slots(int page) { return MODEL ? (page == 0
 // length must be good to ~1e-9 m for the stated 1e-4 relative bound on velocities of a few cm/s); F: everything else
 // what the reference reads after mj_step: quantities of the forward pass of the LAST sub-step (one sub-step old)
 template <typename K, typename F> struct RLag {
-  V3<K> x[3], z[3];
-  K q[3][4];
+  V3<F> x[3], z[3];  // pose at the start of the last sub-step (what the observation is built from), already in the output type
+  F q[3][4];
   F tenL[9];
   F cfrc_absmax, cfrc_clip_sq, bar_contact;
   V3<F> al[3], aa[3];  // qacc of the last forward pass (angular part in the world frame)
@@ -787,7 +787,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     TGR_PHASE(0);
     const Roles<F> Ro = lane_roles<F, MODEL>();
     // ---- kinematics (replicated): normalised orientation and bar axis of every bar, back into the slabs
-    for (int b = 0; b < 3; b++) {
+    static_for<3>([&](auto bc) {  // (unrolled: lag.x[b] with a run-time b would put the lagged pose into scratch memory)
+      constexpr int b = decltype(bc)::value;
       K q[4] = {M.kd.ld(KQ + 4 * b), M.kd.ld(KQ + 4 * b + 1), M.kd.ld(KQ + 4 * b + 2), M.kd.ld(KQ + 4 * b + 3)};
       normalize_quat(q);
       for (int i = 0; i < 4; i++) M.kd.st(KQ + 4 * b + i, q[i]);
@@ -795,10 +796,10 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       st3(M.kd, KEZ + 3 * b, kz);
       st3(M.fd, FEZ + 3 * b, cvt3<F>(kz));
       if (LAST) {
-        lag.x[b] = ld3(M.kd, KX + 3 * b); lag.z[b] = kz;
-        for (int i = 0; i < 4; i++) lag.q[b][i] = q[i];
+        lag.x[b] = cvt3<F>(ld3(M.kd, KX + 3 * b)); lag.z[b] = cvt3<F>(kz);
+        for (int i = 0; i < 4; i++) lag.q[b][i] = cvt<F>(q[i]);
       }
-    }
+    });
     TGR_PHASE(1);
     // ---- tendons (tendon role): geometry, force, Jacobian pieces; smooth wrench per bar (replicated).  Each lane reads the pose of
     // ITS two bars straight from the slab (a lane-dependent LDS address), so no lane ever holds all three bars

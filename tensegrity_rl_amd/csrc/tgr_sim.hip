@@ -229,8 +229,12 @@ TGR_DEV void make_obs(const Params<T>& P, const EnvCfg<T>& E, const Sim<T>& S, c
 // tr_env.py:549-646, use_obs_noise: what step()/reset() return is observation_with_noise.  o: this lane's observation row
 // (noise-free, in LDS).  45 standard normals in the reference's order -- cap positions (18), tendon lengths (9), cap velocities
 // (18) -- from philox keyed (seed; key, episode, 0x80000000 + 16 * k + j), k = index of the observation within the episode.
-template <typename T> TGR_DEV void apply_obs_noise(const EnvCfg<T>& E, unsigned long long key, unsigned episode, int kobs, T* o) {
-  T z[48];
+// ZEXT: the 48 normal draws are kept at zext (the row kernels hand in idle LDS: as a local array indexed by the loop counter they would
+// live in scratch memory)
+template <typename T, bool ZEXT = false>
+TGR_DEV void apply_obs_noise(const EnvCfg<T>& E, unsigned long long key, unsigned episode, int kobs, T* o, T* zext = nullptr) {
+  T zl[ZEXT ? 1 : 48];
+  T* const z = ZEXT ? zext : zl;
   const unsigned k0 = (unsigned)E.seed, k1 = (unsigned)(E.seed >> 32);
 #pragma unroll 1
   for (int j = 0; j < 12; j++) {
@@ -427,11 +431,14 @@ template <typename T> TGR_DEV unsigned long long lane_key(const EnvCfg<T>& E, in
 }
 
 // start pose of an episode: yaw-randomised table pose, zero velocity, random tendon targets
-template <typename T> TGR_DEV void init_episode(const EnvCfg<T>& E, unsigned long long key, unsigned long long episode, Sim<T>& S) {
+// tmp: 39 doubles of work space for the perturbed pose (indexed by run-time loop counters: as a local array it would live in scratch
+// memory -- the row kernels hand in a piece of LDS that is idle at that point)
+template <typename T> TGR_DEV void init_episode(const EnvCfg<T>& E, unsigned long long key, unsigned long long episode, Sim<T>& S, double* tmp) {
   Draws dr = reset_draws(E, key, episode);
   double c = cos(dr.theta), s = sin(dr.theta), ch = cos(0.5 * dr.theta), sh = sin(0.5 * dr.theta);
   const double* q0 = E.env_kind == TGR_ENV_TR ? c_rolling[dr.pose] : (E.model_kind ? c_qpos0_uneven : c_qpos0);
-  double qn[21], vn[18];
+  double* const qn = tmp;
+  double* const vn = tmp + 21;
 #pragma unroll
   for (int i = 0; i < 21; i++) qn[i] = q0[i];
 #pragma unroll
@@ -566,9 +573,9 @@ TGR_DEV void store_reset_aux(const Params<T>& P, T* st, int* ist, int m, int e, 
 
 // ------------------------------------------------------------------ after the twenty sub-steps: bookkeeping of one env (shared by the
 // block kernels and the row kernels).  `w0`: this lane owns the env's global stores; orow: the env's row of the observation tile
-template <typename T>
+template <typename T, bool ZEXT = false>
 TGR_DEV void finish_lane(const KArgs<T>& k, Sim<T>& S, const Lag<T>& lag, int e, bool valid, bool live, bool active, bool w0, int phase,
-                         int total, T* orow) {
+                         int total, T* orow, T* zext = nullptr) {
   const Params<T>& P = k.P;
   const EnvCfg<T>& E = k.E;
   const int n = k.n, m = k.m;
@@ -619,7 +626,7 @@ TGR_DEV void finish_lane(const KArgs<T>& k, Sim<T>& S, const Lag<T>& lag, int e,
       if (phase == PH_READY) {
         store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
         make_obs(P, E, S, lag, wb, ms, orow);
-        if (E.use_obs_noise) apply_obs_noise(E, lane_key(E, n, e), (unsigned)k.ist[I_SRCEP * m + e], 0, orow);
+        if (E.use_obs_noise) apply_obs_noise<T, ZEXT>(E, lane_key(E, n, e), (unsigned)k.ist[I_SRCEP * m + e], 0, orow, zext);
         T* op = k.dobs + (size_t)(e - n) * D;
         for (int i = 0; i < D; i++) op[i] = orow[i];
       }
@@ -640,7 +647,7 @@ TGR_DEV void finish_lane(const KArgs<T>& k, Sim<T>& S, const Lag<T>& lag, int e,
         T* cp = k.obs_clean + (size_t)e * D;
         for (int i = 0; i < D; i++) cp[i] = orow[i];
       }
-      if (E.use_obs_noise) apply_obs_noise(E, lane_key(E, n, k.ist[I_SRC * m + e]), (unsigned)k.ist[I_SRCEP * m + e], elapsed, orow);
+      if (E.use_obs_noise) apply_obs_noise<T, ZEXT>(E, lane_key(E, n, k.ist[I_SRC * m + e]), (unsigned)k.ist[I_SRCEP * m + e], elapsed, orow, zext);
       k.st[(F_XYLAG + 0) * m + e] = out.xy[0]; k.st[(F_XYLAG + 1) * m + e] = out.xy[1];
       k.st[F_PSILAG * m + e] = out.psi_straight;
       k.st[F_EPRET * m + e] = ep_ret;
@@ -694,7 +701,8 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
   int episode = k.ist[I_EPISODE * m + e];
   const int total = settle_total(E);
   if (!live && phase == PH_INIT) {
-    init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
+    double ie_tmp[39];
+    init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S, ie_tmp);
     phase = total;
     if (valid) { k.ist[I_SRC * m + e] = e; k.ist[I_SRCEP * m + e] = episode; k.ist[I_EPISODE * m + e] = episode + 1; }
   } else {
@@ -893,7 +901,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
     int episode = k.ist[I_EPISODE * m + e];
     if (donor_run && phase == PH_INIT) {
       Sim<T> S0;
-      init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S0);
+      init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S0, (double*)(sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16)));
       row_import<T, TK, MODEL>(S0, M);
       phase = total;
       if (valid && r == 0) { k.ist[I_SRC * m + e] = e; k.ist[I_SRCEP * m + e] = episode; k.ist[I_EPISODE * m + e] = episode + 1; }
@@ -929,7 +937,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
       if ((threadIdx.x & 63u) == 0) atomicAdd(&k.counters[7], (unsigned long long)(nact * E.frame_skip));
     }
     T* const orow = sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16);  // the contact slots are dead now
-    finish_lane(k, S, lag, e, valid, live, active, w0, phase, total, orow);
+    finish_lane<T, true>(k, S, lag, e, valid, live, active, w0, phase, total, orow, orow + 64);  // (orow: <= 49 values of the row's 480)
 #ifdef TGR_WAVE_TIMES
     if ((threadIdx.x & 63u) == 0) {
       const int wv = blockIdx.x * (ROW_ENVS / 4) + (threadIdx.x >> 6);
@@ -960,7 +968,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   const Params<T>& P = k.P;
   const int episode = k.ist[I_EPISODE * m + e];
   Sim<T> S;
-  init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
+  init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S, (double*)(sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16)));
   const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
   row_import<T, TK, MODEL>(S, M);
   RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
@@ -999,7 +1007,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   const int D = E.obs_dim;
   T* orow = sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16);
   make_obs(P, E, S, lag, wb, ms, orow);
-  if (E.use_obs_noise) apply_obs_noise(E, lane_key(E, n, e), (unsigned)episode, 0, orow);
+  if (E.use_obs_noise) apply_obs_noise<T, true>(E, lane_key(E, n, e), (unsigned)episode, 0, orow, orow + 64);
   T* op = e < n ? (k.obs_reset ? k.obs_reset + (size_t)e * D : nullptr) : k.dobs + (size_t)(e - n) * D;
   if (op)
     for (int i = 0; i < D; i++) op[i] = orow[i];
@@ -1025,7 +1033,8 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
 
   int episode = k.ist[I_EPISODE * m + e];
   Sim<T> S;
-  init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S);
+  double ie_tmp[39];
+  init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S, ie_tmp);
   RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
   ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
   int step_num = 0;
