@@ -59,11 +59,9 @@ template <int MODEL> constexpr int n_slots(int page) { return MODEL ? (page == 0
 // length must be good to ~1e-9 m for the stated 1e-4 relative bound on velocities of a few cm/s); F: everything else
 // what the reference reads after mj_step: quantities of the forward pass of the LAST sub-step (one sub-step old)
 template <typename K, typename F> struct RLag {
-  V3<F> x[3], z[3];  // pose at the start of the last sub-step (what the observation is built from), already in the output type
-  F q[3][4];
-  F tenL[9];
+  // (the pose and the tendon lengths at the start of the last sub-step -- what the observation is built from -- are parked in the lp
+  // slab, the bar axes stay in kd: thirty values that would otherwise sit in registers through the whole last sub-step)
   F cfrc_absmax, cfrc_clip_sq, bar_contact;
-  V3<F> al[3], aa[3];  // qacc of the last forward pass (angular part in the world frame)
   F overflow;   // dropped bar-bar contacts in the last sub-step (a count, kept as a real)
   F n_unconv;   // sub-steps this environment left the solver at the iteration cap
   F n_own;      // Newton iterations this environment itself still needed (the wavefront runs until its slowest one is done)
@@ -760,12 +758,16 @@ constexpr int RSA = 0, RSB = 3, RTK = 6, RTB = 7, RTL0 = 8, R_SLAB = 9;
 // hd (F, replicated): the solver's history -- the iterate d the sub-step before last ended on (18) and whether the last two sub-steps
 // had contacts (2).  On the GPU it lives in columns 9 and 10 of the tendon slab (lanes 9.. own no tendon): hidx() is its addressing.
 constexpr int HD = 0, HPC = 18, HPPC = 19, H_SLAB = 20;
+// lp (F, replicated): the lagged pose of the last sub-step, x (9), q (12), and its tendon lengths (9) -- columns 11..13 of the tendon slab.
+constexpr int LPX = 0, LPQ = 9, LPT = 21, LP_SLAB = 30;
 #ifdef TGR_ROW_EMUL
 constexpr int hidx(int i) { return i; }
+constexpr int lidx(int i) { return i; }
 #else
 constexpr int hidx(int i) { return (i % 10) * 16 + i / 10; }
+constexpr int lidx(int i) { return (i % 10) * 16 + i / 10; }
 #endif
-template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; Slab<F> hd; };
+template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; Slab<F> hd; Slab<F> lp; };
 
 // `LAST`: what only the last sub-step of a control period records (lagged kinematics, tendon lengths, contact wrench).
 // K / PK: lane and scalar type of the pose, the kinematics, the tendon geometry and the smooth forces; F / P: of the rest.
@@ -796,8 +798,9 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       st3(M.kd, KEZ + 3 * b, kz);
       st3(M.fd, FEZ + 3 * b, cvt3<F>(kz));
       if (LAST) {
-        lag.x[b] = cvt3<F>(ld3(M.kd, KX + 3 * b)); lag.z[b] = cvt3<F>(kz);
-        for (int i = 0; i < 4; i++) lag.q[b][i] = cvt<F>(q[i]);
+        const V3<F> lx = cvt3<F>(ld3(M.kd, KX + 3 * b));
+        M.lp.st(lidx(LPX + 3 * b), lx.x); M.lp.st(lidx(LPX + 3 * b + 1), lx.y); M.lp.st(lidx(LPX + 3 * b + 2), lx.z);
+        for (int i = 0; i < 4; i++) M.lp.st(lidx(LPQ + 4 * b + i), cvt<F>(q[i]));
       }
     });
     TGR_PHASE(1);
@@ -819,7 +822,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       const K L2 = dot(dif, dif);
       const K iL = rsqrt_(max_(L2, K(SK(1e-30))));
       const K L = L2 * iL;
-      if (LAST) static_for<9>([&](auto tc) { constexpr int t = decltype(tc)::value; lag.tenL[t] = cvt<F>(bcast<t>(L)); });
+      if (LAST) static_for<9>([&](auto tc) { constexpr int t = decltype(tc)::value; M.lp.st(lidx(LPT + t), cvt<F>(bcast<t>(L))); });
       const V3<K> u = iL * dif;
       TGR_SCHED();
       const V3<K> va = cvt3<K>(ld3(M.fd, FV + 3 * ia)) + cross(cvt3<K>(ld3(M.fd, FW + 3 * ia)), ra);
@@ -1141,10 +1144,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     lag.cfrc_clip_sq = sq;
     lag.cfrc_absmax = cfrc_max;
     lag.bar_contact = bar_force;
-    for (int b = 0; b < 3; b++) {  // qacc of the last forward pass (what mujoco keeps as qacc_warmstart)
-      lag.al[b] = cvt3<F>(ld3(M.kd, KL0 + 3 * b)) + ld3(M.fd, FDL + 3 * b);
-      lag.aa[b] = cvt3<F>(ld3(M.kd, KA0 + 3 * b)) + ld3(M.fd, FDA + 3 * b);
-    }
+    // (qacc of the last forward pass -- what mujoco keeps as qacc_warmstart -- is a0 + d: both stay in the slabs, the export adds them)
   }
   // ---- implicitfast: (M + h sum_t b_t J_t J_t^T) a_new = F_smooth + F_constraint  (Woodbury over the nine tendons, tendon role).
   V3<F> yl[3], ya[3];    // the damping correction

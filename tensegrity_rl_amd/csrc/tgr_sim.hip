@@ -801,7 +801,8 @@ template <typename T, typename TK, int MODEL> TGR_DEV row::RMem<TK, T> row_mem(R
   M.kd = row::Slab<TK>{sh.kd + slot * k_slab<MODEL>(), 1, 0};
   M.fd = row::Slab<T>{sh.fd + slot * row::F_SLAB, 1, 0};
   M.td = row::Slab<T>{sh.td + slot * row::T_SLAB * 16, 16, r};
-  M.hd = row::Slab<T>{sh.td + slot * row::T_SLAB * 16 + 9, 1, 0};  // columns 9, 10 of the tendon slab (tgr_row.h hidx)
+  M.hd = row::Slab<T>{sh.td + slot * row::T_SLAB * 16 + 9, 1, 0};   // columns 9, 10 of the tendon slab (tgr_row.h hidx)
+  M.lp = row::Slab<T>{sh.td + slot * row::T_SLAB * 16 + 11, 1, 0};  // columns 11..13 (lidx)
   M.rd = row::Slab<TK>{sh.rd, 16, r};
   M.ad = row::Slab<TK>{sh.ad + slot * row::A_SLAB * PAGES * 16, 16, r};
   M.cd = row::Slab<T>{sh.cd + slot * row::C_SLAB * PAGES * 16, 16, r};
@@ -856,22 +857,26 @@ TGR_DEV void row_export(const row::RMem<TK, T>& M, const row::RLag<TK, T>& rl, S
     S.x[b] = mk(T(M.kd.ld(row::KX + 3 * b)), T(M.kd.ld(row::KX + 3 * b + 1)), T(M.kd.ld(row::KX + 3 * b + 2)));
     S.v[b] = mk(M.fd.ld(row::FV + 3 * b), M.fd.ld(row::FV + 3 * b + 1), M.fd.ld(row::FV + 3 * b + 2));
     S.w[b] = mk(M.fd.ld(row::FW + 3 * b), M.fd.ld(row::FW + 3 * b + 1), M.fd.ld(row::FW + 3 * b + 2));
-    S.al[b] = mk(rl.al[b].x, rl.al[b].y, rl.al[b].z); S.aa[b] = mk(rl.aa[b].x, rl.aa[b].y, rl.aa[b].z);
-    lag.x[b] = mk(T(rl.x[b].x), T(rl.x[b].y), T(rl.x[b].z)); lag.z[b] = mk(T(rl.z[b].x), T(rl.z[b].y), T(rl.z[b].z));
+    // qacc of the last forward pass = unconstrained acceleration + the solver's iterate (angular part in the world frame)
+    S.al[b] = mk(T(M.kd.ld(row::KL0 + 3 * b)) + M.fd.ld(row::FDL + 3 * b), T(M.kd.ld(row::KL0 + 3 * b + 1)) + M.fd.ld(row::FDL + 3 * b + 1),
+                 T(M.kd.ld(row::KL0 + 3 * b + 2)) + M.fd.ld(row::FDL + 3 * b + 2));
+    S.aa[b] = mk(T(M.kd.ld(row::KA0 + 3 * b)) + M.fd.ld(row::FDA + 3 * b), T(M.kd.ld(row::KA0 + 3 * b + 1)) + M.fd.ld(row::FDA + 3 * b + 1),
+                 T(M.kd.ld(row::KA0 + 3 * b + 2)) + M.fd.ld(row::FDA + 3 * b + 2));
+    lag.x[b] = mk(M.lp.ld(row::lidx(row::LPX + 3 * b)), M.lp.ld(row::lidx(row::LPX + 3 * b + 1)), M.lp.ld(row::lidx(row::LPX + 3 * b + 2)));
+    lag.z[b] = mk(T(M.kd.ld(row::KEZ + 3 * b)), T(M.kd.ld(row::KEZ + 3 * b + 1)), T(M.kd.ld(row::KEZ + 3 * b + 2)));
 #pragma unroll
-    for (int i = 0; i < 4; i++) { S.q[b][i] = T(M.kd.ld(row::KQ + 4 * b + i)); lag.q[b][i] = T(rl.q[b][i]); }
+    for (int i = 0; i < 4; i++) { S.q[b][i] = T(M.kd.ld(row::KQ + 4 * b + i)); lag.q[b][i] = M.lp.ld(row::lidx(row::LPQ + 4 * b + i)); }
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) { S.ctrl[i] = M.fd.ld(row::FCTRL + i); S.act[i] = MODEL ? T(M.kd.ld(row::KACT + i)) : T(0); }
 #pragma unroll
-  for (int i = 0; i < 9; i++) lag.tenL[i] = rl.tenL[i];
+  for (int i = 0; i < 9; i++) lag.tenL[i] = M.lp.ld(row::lidx(row::LPT + i));
   lag.cfrc_absmax = rl.cfrc_absmax; lag.cfrc_clip_sq = rl.cfrc_clip_sq; lag.bar_contact = rl.bar_contact;
   lag.overflow = (int)rl.overflow; lag.n_it = rl.n_it; lag.n_ls = rl.n_ls; lag.n_unconv = (int)rl.n_unconv;
 }
 template <typename T, typename TK> TGR_DEV void row_lag_init(row::RLag<TK, T>& rl) {
-  rl.cfrc_absmax = T(0); rl.cfrc_clip_sq = T(0); rl.bar_contact = T(0); rl.overflow = T(0); rl.n_unconv = T(0); rl.n_own = T(0); rl.n_it = 0; rl.n_ls = 0;
-#pragma unroll
-  for (int i = 0; i < 9; i++) rl.tenL[i] = T(0);
+  // (cfrc_absmax, cfrc_clip_sq, bar_contact, overflow are assigned by the last sub-step, not accumulated: nothing to initialise)
+  rl.n_unconv = T(0); rl.n_own = T(0); rl.n_it = 0; rl.n_ls = 0;
 }
 
 #ifdef TGR_WAVE_TIMES  // development aid: start / end time, iterations of every wavefront of the last step launch
@@ -885,7 +890,12 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   __shared__ RowShared<T, TK, MODEL> sh;
   const int r = (int)(threadIdx.x & 15u);
   const int slot = (int)(threadIdx.x >> 4);  // environment of this row within the block
-  const int gid = blockIdx.x * ROW_ENVS + slot;
+  // XCD-aware order: blocks are dealt round-robin over the 8 XCDs, each with its own L2.  Within a chunk of 64 blocks the (8 x 8) index is
+  // transposed, so that the 8 blocks an XCD gets from the chunk are 8 CONSECUTIVE groups of environments: the 128-byte line of a state
+  // field they share is fetched into one L2 instead of eight (19 -> 5 MB fetched per launch).  The launch pads the grid to a multiple of 64.
+  const int bx = (int)blockIdx.x;
+  const int lb = (bx & ~63) | ((bx & 7) << 3) | ((bx >> 3) & 7);
+  const int gid = lb * ROW_ENVS + slot;
   const int n = k.n, m = k.m;
   const bool valid = gid < m;
   const int e = valid ? gid : m - 1;
@@ -895,7 +905,8 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   const bool donor_run = valid && e >= n && (phase > 0 || phase == PH_INIT);
   const bool active = live || donor_run;
   const int total = settle_total(E);
-  const int D = E.obs_dim;
+  row::RLag<TK, T> rl;
+  row_lag_init<T, TK>(rl);
   if (__any(active)) {  // (a wavefront of idle donor rows has nothing to do)
     const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
     int episode = k.ist[I_EPISODE * m + e];
@@ -917,11 +928,32 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
       }
     }
     row::store_role_consts<TK, T, TK, MODEL>(ra.PK, M.rd);
-    row::RLag<TK, T> rl;
-    row_lag_init<T, TK>(rl);
 #pragma unroll 1
     for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, M, rl);
     row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, M, rl);
+  }
+  // Who this row is gets worked out a second time, from laundered thread and block numbers: carried through the twenty sub-steps in
+  // registers it was spilled (a dozen dwords per lane: 6 MB of scratch stores per launch), recomputed it is ten instructions.
+  unsigned tx2 = threadIdx.x, bx2 = blockIdx.x;
+  asm volatile("" : "+v"(tx2));
+  asm volatile("" : "+s"(bx2));
+  {
+    const int r = (int)(tx2 & 15u), slot = (int)(tx2 >> 4);
+    const int lb = (int)((bx2 & ~63u) | ((bx2 & 7u) << 3) | ((bx2 >> 3) & 7u));
+    const int gid = lb * ROW_ENVS + slot;
+    const int n = k.n, m = k.m;
+    const bool valid = gid < m;
+    const int e = valid ? gid : m - 1;
+    const EnvCfg<T>& E = k.E;
+    const bool live = valid && e < n;
+    int phase = k.ist[I_PHASE * m + e];  // (only written below)
+    const bool donor_run = valid && e >= n && (phase > 0 || phase == PH_INIT);
+    const bool active = live || donor_run;
+    const int total = settle_total(E);
+    const int D = E.obs_dim;
+    if (!__any(active)) return;
+    if (donor_run && phase == PH_INIT) phase = total;  // (the episode was set up at the top)
+    const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
     Sim<T> S;
     Lag<T> lag;
     row_export<T, TK, MODEL>(M, rl, S, lag);
@@ -1602,10 +1634,10 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
     fill_row_args<T>(h, k, ra);
     if (h->cfg.model_kind) {
       constexpr int NE = row_envs<T, 1>();
-      hipLaunchKernelGGL((step_kernel_row<T, double, 1>), dim3((h->m + NE - 1) / NE), dim3(16 * NE), 0, s, k, ra);
+      hipLaunchKernelGGL((step_kernel_row<T, double, 1>), dim3((((h->m + NE - 1) / NE + 63) / 64) * 64), dim3(16 * NE), 0, s, k, ra);
     } else {
       constexpr int NE = row_envs<T, 0>();
-      hipLaunchKernelGGL((step_kernel_row<T, double, 0>), dim3((h->m + NE - 1) / NE), dim3(16 * NE), 0, s, k, ra);
+      hipLaunchKernelGGL((step_kernel_row<T, double, 0>), dim3((((h->m + NE - 1) / NE + 63) / 64) * 64), dim3(16 * NE), 0, s, k, ra);
     }
   } else {
 #ifndef TGR_FAST_BUILD

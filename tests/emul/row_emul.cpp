@@ -54,10 +54,10 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : bad)
   for (int e = 0; e < n; e++) {
     K kd[K_SLAB], rd[R_SLAB], ad[A_SLAB * n_pages<MODEL>()];
-    F hd[H_SLAB];
+    F hd[H_SLAB], lp[LP_SLAB];
     F fd[F_SLAB], td[T_SLAB], cd[C_SLAB * n_pages<MODEL>()];
     RMem<K, F> M;
-    M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0}; M.cd = Slab<F>{cd, 1, 0}; M.hd = Slab<F>{hd, 1, 0};
+    M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0}; M.cd = Slab<F>{cd, 1, 0}; M.hd = Slab<F>{hd, 1, 0}; M.lp = Slab<F>{lp, 1, 0};
     store_role_consts<K, F, TK, MODEL>(PK, M.rd);
     RLag<K, F> lag;
     for (int b = 0; b < 3; b++) {
@@ -85,7 +85,7 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
       const V3<K> wb = rot_applyT(R, cvt3<K>(ld3(M.fd, FW + 3 * b)));
       double* q = qpos + 21 * e + 7 * b;
       double* v = qvel + 18 * e + 6 * b;
-      bad += check_rep(kd[KX + 3 * b], "x", e) + check_rep(qq[0], "q", e) + check_rep(fd[FV + 3 * b + 2], "v", e) + check_rep(wb.x, "w", e) + check_rep(lag.al[b].x, "a", e);
+      bad += check_rep(kd[KX + 3 * b], "x", e) + check_rep(qq[0], "q", e) + check_rep(fd[FV + 3 * b + 2], "v", e) + check_rep(wb.x, "w", e);
       for (int i = 0; i < 3; i++) q[i] = kd[KX + 3 * b + i].v[0];
       for (int i = 0; i < 4; i++) q[3 + i] = qq[i].v[0];
       for (int i = 0; i < 3; i++) v[i] = fd[FV + 3 * b + i].v[0];
@@ -93,8 +93,8 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
     }
     for (int i = 0; i < 6; i++) act[6 * e + i] = kd[KACT + i].v[0];
     double* o = out + 32 * e;
-    for (int t = 0; t < 9; t++) { o[t] = lag.tenL[t].v[0]; bad += check_rep(lag.tenL[t], "tenL", e); }
-    for (int b = 0; b < 3; b++) { o[9 + 3 * b] = lag.x[b].x.v[0]; o[10 + 3 * b] = lag.x[b].y.v[0]; o[11 + 3 * b] = lag.x[b].z.v[0]; }
+    for (int t = 0; t < 9; t++) { o[t] = lp[LPT + t].v[0]; bad += check_rep(lp[LPT + t], "tenL", e); }
+    for (int i = 0; i < 9; i++) o[9 + i] = lp[LPX + i].v[0];
     o[18] = lag.cfrc_absmax.v[0]; o[19] = lag.cfrc_clip_sq.v[0]; o[20] = lag.bar_contact.v[0]; o[21] = lag.overflow.v[0];
     o[22] = lag.n_unconv.v[0]; o[23] = lag.n_it; o[24] = lag.n_ls; o[25] = lag.n_own.v[0];
     bad += check_rep(lag.cfrc_absmax, "cfrc", e) + check_rep(lag.bar_contact, "bar_contact", e) + check_rep(lag.n_unconv, "n_unconv", e);
