@@ -764,10 +764,10 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
 }
 
 // ------------------------------------------------------------------ row kernels: one environment = one DPP row (tgr_row.h)
-// 256-thread blocks = 4 independent wavefronts x 4 environments; the 16 lanes of a row hold the environment's state replicated and
-// split the work by role.  No LDS in the physics (the observation tile is the only shared memory), no barrier inside a sub-step.
+// A wavefront = 4 environments; the 16 lanes of a row hold the environment's state replicated and split the work by role; between
+// stages the state is parked in LDS slabs only the row itself reads and writes: no barrier anywhere.
 // T: type of the state arrays / outputs; TK: type of pose, kinematics and tendon geometry inside the kernel (double in production).
-// environments per block (16 lanes each).  One wavefront per block: the blocks of a launch finish at very different times (Newton
+// Environments per block (16 lanes each).  One wavefront per block: the blocks of a launch finish at very different times (Newton
 // iterations) and a 4096-env rollout with its donor rows is just over one round of the 2048 wave slots of the chip -- with 4-wave blocks
 // the last 64 blocks waited for whole blocks to drain and the launch took two wave life times; single waves slot in as soon as any
 // wave retires.  (20 KB of LDS per wave for the fp32 flat-floor kernels: 8 blocks per CU = 2 waves per SIMD.)
