@@ -745,6 +745,29 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
     for (int i = 0; i < 6; i++) pr[b][i] = -pr[b][i];
 }
 
+// constraint wrench on bar b from the neighbour sums of the slot lanes (P*: pairsum over lanes 2j, 2j+1; *B: as body B, *A: as body A of
+// a pair slot).  Pairs (A, B): lanes 6,7 = (0,1); 8,9 = (0,2); 10,11 = (1,2).  MODEL 1: bar b's cylinder slot on lane 12 + b (no neighbour).
+template <int L, typename F> TGR_RDEV V3<F> bcast3v(V3<F> a) { return mk<F>(bcast<L>(a.x), bcast<L>(a.y), bcast<L>(a.z)); }
+template <int MODEL, typename K, typename F>
+TGR_RDEV void bar_sum(int b, V3<F> PfB, V3<F> PtB, V3<F> PtA, K PkB, K PkA, V3<F> fB, V3<F> tB, K tauB, V3<F>& f, V3<F>& t, K& tax) {
+  if (b == 0) {
+    f = (bcast3v<0>(PfB) - bcast3v<6>(PfB)) - bcast3v<8>(PfB);
+    t = (bcast3v<0>(PtB) - bcast3v<6>(PtA)) - bcast3v<8>(PtA);
+    tax = (bcast<0>(PkB) - bcast<6>(PkA)) - bcast<8>(PkA);
+    if (MODEL) { f = f + bcast3v<12>(fB); t = t + bcast3v<12>(tB); tax = tax + bcast<12>(tauB); }
+  } else if (b == 1) {
+    f = (bcast3v<2>(PfB) + bcast3v<6>(PfB)) - bcast3v<10>(PfB);
+    t = (bcast3v<2>(PtB) + bcast3v<6>(PtB)) - bcast3v<10>(PtA);
+    tax = (bcast<2>(PkB) + bcast<6>(PkB)) - bcast<10>(PkA);
+    if (MODEL) { f = f + bcast3v<13>(fB); t = t + bcast3v<13>(tB); tax = tax + bcast<13>(tauB); }
+  } else {
+    f = (bcast3v<4>(PfB) + bcast3v<8>(PfB)) + bcast3v<10>(PfB);
+    t = (bcast3v<4>(PtB) + bcast3v<8>(PtB)) + bcast3v<10>(PtB);
+    tax = (bcast<4>(PkB) + bcast<8>(PkB)) + bcast<10>(PkB);
+    if (MODEL) { f = f + bcast3v<14>(fB); t = t + bcast3v<14>(tB); tax = tax + bcast<14>(tauB); }
+  }
+}
+
 // ------------------------------------------------------------------ the sub-step
 // Between its uses the environment's state lives in slabs (LDS on the GPU), not in registers:
 //   kd (K, replicated): pose x, q; unconstrained acceleration l0, a0; bar axes ez       fd (F, replicated): v, w, ctrl, act
@@ -1021,17 +1044,23 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       tauB = tauB + dot(cvt3<K>(o1.fl), ld3(M.ad, A_SLAB + AMB)) + dot(cvt3<K>(o1.fa), ld3(M.ad, A_SLAB + AZB));
     }
     TGR_CENSUS(12);
+    // The slots of a bar sit on fixed lanes (caps 2b, 2b+1; pair (a, b) on two neighbouring lanes), so its wrench is not a masked
+    // sum over the row: neighbour sums first (one DPP add), then three broadcasts per bar (bar_sum below).  Lanes that own no slot are
+    // never read.
+    const V3<F> PfB = mk<F>(pairsum(fB.x), pairsum(fB.y), pairsum(fB.z)), PtB = mk<F>(pairsum(tB.x), pairsum(tB.y), pairsum(tB.z)),
+                PtA = mk<F>(pairsum(tA.x), pairsum(tA.y), pairsum(tA.z));
+    const K PkB = pairsum(tauB), PkA = pairsum(tauA);
     K gn = kzero;  // g^T M^-1 g
     F gd[3];
-    for (int b = 0; b < 3; b++) {
-      const auto onb = Ro.sB == b, ona = Ro.sA == b;
-      // (the slab reads of this bar go out before its row sums, whose DPP chains cover their latency)
+    static_for<3>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      // (the slab reads of this bar go out before its sums, whose DPP chains cover their latency)
       const V3<F> dl = ld3(M.fd, FDL + 3 * b), da = ld3(M.fd, FDA + 3 * b), ezb = ld3(M.fd, FEZ + 3 * b);
       const V3<K> kez = ld3(M.kd, KEZ + 3 * b);
       TGR_SCHED();
-      const V3<F> fcl = rowsum3(sel3(onb, fB, z3) - sel3(ona, o.fl, z3));
-      const V3<F> fca = rowsum3(sel3(onb, tB, z3) - sel3(ona, tA, z3));
-      const K tax = rowsum(sel(onb, tauB, kzero) - sel(ona, tauA, kzero));
+      V3<F> fcl, fca;
+      K tax;
+      bar_sum<MODEL>(b, PfB, PtB, PtA, PkB, PkA, fB, tB, tauB, fcl, fca, tax);
       st3(M.fd, FFCL + 3 * b, fcl); st3(M.fd, FFCA + 3 * b, fca); M.kd.st(KTAX + b, tax);
       const V3<F> gl = P.mass * dl - fcl;
       V3<F> ga = inertia_mul(P, ezb, da) - fca;
@@ -1041,7 +1070,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       gn = gn + cvt<K>(im * dot(gl, gl) + (dot(ga, ga) - gz * gz) * (S(1) / P.Ixx)) + gax * gax * (SK(1) / PK.Izz);
       ga = ga + (cvt<F>(gax) - gz) * ezb;  // the direction is solved for the same axial residual the test looks at
       gd[b] = sel(Ro.is_dof, sel(Ro.is_ang, pick_comp(Ro.k, ga), pick_comp(Ro.k, gl)), zero);
-    }
+    });
     if (LAST) bar_force = rowsum(sel(Ro.is_pair, sqrt_(dot(o.fl, o.fl)), zero));
     conv = conv | !(gn >= PK.tol * PK.tol);
 #ifdef TGR_ROW_TRACE
