@@ -598,6 +598,25 @@ template <int N, typename F> TGR_RDEV void rbwd(const F* Lr, const F* il, const 
     xd = sel(r == i, xi, xd);
   });
 }
+// the same solve with everything replicated: after x_i is known, column i of L^T -- row i of L, which lane i holds -- is broadcast and
+// taken out of the right-hand sides above it.  No row sums: the dependent chain is one multiply and one fma per column (the row-sum form
+// chains four DPP adds per column), and the broadcasts do not wait for x.  yr is consumed.
+template <int N, typename F> TGR_RDEV void rbwd_rep(const F* Lr, const F* il, F* yr, F* xr) {
+  static_for<N>([&](auto ic) {
+    constexpr int i = N - 1 - decltype(ic)::value;
+    const F xi = yr[i] * il[i];
+    xr[i] = xi;
+    static_for<i>([&](auto jc) { constexpr int j = decltype(jc)::value; yr[j] = yr[j] - bcast<i>(Lr[j]) * xi; });
+  });
+}
+// lane i <- xr[i] (i < N), the other lanes zero
+template <int N, typename F> TGR_RDEV F rscatter(const F* xr) {
+  typedef typename LaneTraits<F>::S S;
+  const auto r = lane_id();
+  F xd = F(S(0));
+  static_for<N>([&](auto ic) { constexpr int i = decltype(ic)::value; xd = sel(r == i, xr[i], xd); });
+  return xd;
+}
 template <int N, typename F> TGR_RDEV void rgather(F yd, F* yr) {
   static_for<N>([&](auto ic) { constexpr int i = decltype(ic)::value; yr[i] = bcast<i>(yd); });
 }
@@ -701,7 +720,7 @@ TGR_RDEV void hess_add_slot(RHess<F>& H, const DofC<F>& d, const RContact<F>& c,
 // p = -H^-1 g.  g: per bar distributed (lane r: component r of the bar's 6-vector); returns p replicated, pr[b][0..6)
 // c01 / c02 / c12: does ANY environment of the wavefront couple bars (0,1) / (0,2) / (1,2)?  (uniform flags; an off-diagonal block
 // nobody fills is zero and its part of the factorisation is skipped.  O21 also fills in through O20 O10^T.)
-template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F pr[3][6], F& gx, bool c01, bool c02, bool c12) {
+template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F pr[3][6], F& gHg, bool c01, bool c02, bool c12) {
   typedef typename LaneTraits<F>::S S;
   const bool n21 = c12 || (c01 && c02);
   F il0[6], il1[6], il2[6];
@@ -723,15 +742,20 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
   rfwd<6>(H.D[1], il1, y1, yr1);
   if (n21) rgemv_rep<6>(H.O21, yr1, y2);
   rfwd<6>(H.D[2], il2, y2, yr2);
-  // backward: L^T x = y
-  F x0, x1, x2, t[6];
-  rbwd<6>(H.D[2], il2, yr2, x2, pr[2]);
+  // g^T H^-1 g = |L^-1 g|^2: the Newton decrement falls out of the forward solve (replicated, no row sum)
+  gHg = F(S(0));
+  for (int i = 0; i < 6; i++) gHg = gHg + yr0[i] * yr0[i] + yr1[i] * yr1[i] + yr2[i] * yr2[i];
+  // backward: L^T x = y, replicated (rbwd_rep); a coupled block needs the solution above it spread over the lanes once
+  F t[6];
+  rbwd_rep<6>(H.D[2], il2, yr2, pr[2]);
+  const F x2 = (n21 || c02) ? rscatter<6>(pr[2]) : F(S(0));
   if (n21) {
     rgemvT<6>(H.O21, x2, t);
     for (int i = 0; i < 6; i++) yr1[i] = yr1[i] - t[i];
   }
-  rbwd<6>(H.D[1], il1, yr1, x1, pr[1]);
+  rbwd_rep<6>(H.D[1], il1, yr1, pr[1]);
   if (c01) {
+    const F x1 = rscatter<6>(pr[1]);
     rgemvT<6>(H.O10, x1, t);
     for (int i = 0; i < 6; i++) yr0[i] = yr0[i] - t[i];
   }
@@ -739,8 +763,7 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
     rgemvT<6>(H.O20, x2, t);
     for (int i = 0; i < 6; i++) yr0[i] = yr0[i] - t[i];
   }
-  rbwd<6>(H.D[0], il0, yr0, x0, pr[0]);
-  gx = gd[0] * x0 + gd[1] * x1 + gd[2] * x2;  // lane i: its three terms of g . x
+  rbwd_rep<6>(H.D[0], il0, yr0, pr[0]);
   for (int b = 0; b < 3; b++)
     for (int i = 0; i < 6; i++) pr[b][i] = -pr[b][i];
 }
@@ -879,18 +902,25 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
         st3(M.td, TU, cvt3<F>(u)); st3(M.td, TMA, cvt3<F>(ma)); st3(M.td, TMB, cvt3<F>(mb));
         M.td.st(TDAMP, cvt<F>(damp));
       }
-      for (int b = 0; b < 3; b++) {
-        const auto onb = ib == b, ona = ia == b;
-        const K fb = sel(onb, f, kzero), fa_ = sel(ona, f, kzero);
-        // the force sum only feeds linear accelerations (fp32 resolves them); the torque sum decides the spin about the bar's own axis
-        V3<K> Fb = cvt3<K>(rowsum3(cvt3<F>((fb - fa_) * u)));
-        const V3<K> Tb = rowsum3(fb * mb - fa_ * ma);
+      // Tendon t pulls bars (A, B) = (0,2), (0,1), (1,2) for t mod 3 = 0, 1, 2 (static_assert at lane_roles): the sums per class land on
+      // lanes 0, 1, 2 (trisum) and a bar's wrench is two broadcasts of them -- no masked sum over the row.
+      // the force sum only feeds linear accelerations (fp32 resolves them); the torque sum decides the spin about the bar's own axis
+      const K ften = sel(Ro.is_ten, f, kzero);
+      const V3<F> Sfu = mk<F>(trisum(cvt<F>(ften * u.x)), trisum(cvt<F>(ften * u.y)), trisum(cvt<F>(ften * u.z)));
+      const V3<K> Sma = mk<K>(trisum(ften * ma.x), trisum(ften * ma.y), trisum(ften * ma.z));
+      const V3<K> Smb = mk<K>(trisum(ften * mb.x), trisum(ften * mb.y), trisum(ften * mb.z));
+      static_for<3>([&](auto bc_) {
+        constexpr int b = decltype(bc_)::value;
+        V3<K> Fb, Tb;
+        if (b == 0) { Fb = cvt3<K>(-(bcast3v<0>(Sfu) + bcast3v<1>(Sfu))); Tb = -(bcast3v<0>(Sma) + bcast3v<1>(Sma)); }
+        else if (b == 1) { Fb = cvt3<K>(bcast3v<1>(Sfu) - bcast3v<2>(Sfu)); Tb = bcast3v<1>(Smb) - bcast3v<2>(Sma); }
+        else { Fb = cvt3<K>(bcast3v<0>(Sfu) + bcast3v<2>(Sfu)); Tb = bcast3v<0>(Smb) + bcast3v<2>(Smb); }
         Fb.z = Fb.z - PK.mass * PK.grav;
         const V3<K> wk = cvt3<K>(ld3(M.fd, FW + 3 * b)), kz = ld3(M.kd, KEZ + 3 * b);
         const V3<K> Tq = Tb + (-(PK.Izz - PK.Ixx) * dot(kz, wk)) * cross(wk, kz);  // gyroscopic
         st3(M.kd, KL0 + 3 * b, imk * Fb); st3(M.kd, KA0 + 3 * b, inv_inertia(PK, kz, Tq));
         TGR_SCHED();
-      }
+      });
     }
     TGR_PHASE(2);
     // ---- contacts (slot role)
@@ -1098,9 +1128,9 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
                cp2 = any_slot<10>(cs.active) || any_slot<11>(cs.active);
     TGR_PHASE(6);
     // ---- direction p = -H^-1 g
-    F pr[3][6], gx;
-    newton_direction(H, gd, pr, gx, cp0, cp1, cp2);
-    const F d0 = sel(conv, zero, -rowsum(gx));  // p . g
+    F pr[3][6], gHg;
+    newton_direction(H, gd, pr, gHg, cp0, cp1, cp2);
+    const F d0 = sel(conv, zero, -gHg);  // p . g = -g^T H^-1 g
     TGR_PHASE(7);
     // ---- line search: Gauss part (replicated), cone part (slot role)
     V3<F> pl[3], pa[3];
@@ -1216,15 +1246,20 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     TGR_CENSUS(14);
     rchol<9>(Sr, il9);
     TGR_SCHED();
-    F zr[9], zd;
+    F zr[9];
     rfwd<9>(Sr, il9, zt, zr);
-    rbwd<9>(Sr, il9, zr, zd, zr);
+    rbwd_rep<9>(Sr, il9, zr, zr);
+    const F zd = rscatter<9>(zr);  // lane t: its tendon's multiplier (zero on the lanes without a tendon)
     TGR_CENSUS(15);
-    for (int b = 0; b < 3; b++) {
-      const auto ona = Ro.ba == b, onb = Ro.bb == b;
-      const F ca = sel(ona, zd, zero) - sel(onb, zd, zero);
-      yl[b] = rowsum3((ca * im) * us);
-      ya[b] = rowsum3(sel(ona, zd, zero) * was - sel(onb, zd, zero) * wbs);
+    {
+      // (zd is zero on the lanes without a tendon; classes t mod 3 as in the tendon stage: bar A of a tendon gets +, bar B -)
+      const F zi = zd * im;
+      const V3<F> Su = mk<F>(trisum(zi * us.x), trisum(zi * us.y), trisum(zi * us.z));
+      const V3<F> Swa = mk<F>(trisum(zd * was.x), trisum(zd * was.y), trisum(zd * was.z));
+      const V3<F> Swb = mk<F>(trisum(zd * wbs.x), trisum(zd * wbs.y), trisum(zd * wbs.z));
+      yl[0] = bcast3v<0>(Su) + bcast3v<1>(Su);     ya[0] = bcast3v<0>(Swa) + bcast3v<1>(Swa);
+      yl[1] = bcast3v<2>(Su) - bcast3v<1>(Su);     ya[1] = bcast3v<2>(Swa) - bcast3v<1>(Swb);
+      yl[2] = -(bcast3v<0>(Su) + bcast3v<2>(Su));  ya[2] = -(bcast3v<0>(Swb) + bcast3v<2>(Swb));
     }
   }
   TGR_PHASE(9);

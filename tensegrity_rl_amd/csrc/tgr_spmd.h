@@ -79,6 +79,8 @@ template <typename T> TGR_RDEV T rowsum(T x) {
 }
 // x of my lane + x of its neighbour (lanes 2j and 2j+1 end up with the same sum): quad_perm [1,0,3,2]
 template <typename T> TGR_RDEV T pairsum(T x) { return x + dpp_<0xB1>(x); }
+// lanes 0, 1, 2 <- x[t] + x[t+3] + x[t+6] (row_shl:3, row_shl:6; lanes past the row read zero).  The other lanes hold partial sums.
+template <typename T> TGR_RDEV T trisum(T x) { return x + dpp_<0x103>(x) + dpp_<0x106>(x); }
 template <typename T> TGR_RDEV T rowmax(T x) {
   T y = dpp_<0x128>(x); x = x > y ? x : y; y = dpp_<0x124>(x); x = x > y ? x : y;
   y = dpp_<0x122>(x); x = x > y ? x : y; y = dpp_<0x121>(x); x = x > y ? x : y;
@@ -168,6 +170,12 @@ template <typename T> inline Ln<T> rowsum(const Ln<T>& x) {  // same butterfly a
   return a;
 }
 template <typename T> inline Ln<T> pairsum(const Ln<T>& x) { op_tick<T>(); Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = x.v[i] + x.v[i ^ 1]; return r; }
+template <typename T> inline Ln<T> trisum(const Ln<T>& x) {
+  op_tick<T>(); op_tick<T>();
+  Ln<T> r;
+  for (int i = 0; i < ROW; i++) r.v[i] = x.v[i] + (i + 3 < ROW ? x.v[i + 3] : T(0)) + (i + 6 < ROW ? x.v[i + 6] : T(0));
+  return r;
+}
 template <typename T> inline Ln<T> rowmax(const Ln<T>& x) { T m = x.v[0]; for (int i = 1; i < ROW; i++) m = x.v[i] > m ? x.v[i] : m; return Ln<T>(m); }
 template <int K> inline bool any_slot(const Ln<bool>& flag) { return flag.v[K]; }
 inline Ln<float> gather_f(const float* base, const Ln<int>& idx) { Ln<float> r; for (int i = 0; i < ROW; i++) r.v[i] = base[idx.v[i]]; return r; }
