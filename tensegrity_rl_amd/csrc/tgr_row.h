@@ -472,13 +472,17 @@ template <typename F, typename S> TGR_RDEV void seg_seg_closest(V3<F> ca, V3<F> 
   const F s3 = clamp_(b * t2 - dA, F(-ha), F(ha));
   s_out = sel(interior, s, s3); t_out = sel(interior, t, t2);
 }
-// the r-cylinder of a bar (centre relative to the heightfield's origin in K, axis az) against the terrain: deepest grid edge under the bar,
-// the bar taken as a capsule of the cylinder's radius.  Same rules as tgr_device.h hfield_rod.  Returns dist (>= 0: none), normal, arm.
+// the r-cylinder of a bar (centre relative to the heightfield's origin in K, axis az; both REPLICATED) against the terrain: deepest grid
+// edge under the bar, the bar taken as a capsule of the cylinder's radius.  Same rules as tgr_device.h hfield_rod (3 x 3 cells x 3 edges in
+// the order j, i, k; the first of equally deep edges wins), but the 27 edge tests are dealt out over the 16 lanes of the row (lane l takes
+// edges l and l + 16) and the winner comes back through the row: 2 tests per lane instead of 27.  Returns dist (>= 0: none), normal,
+// arm -- replicated.
 template <typename K, typename F, typename SK, typename S>
-TGR_RDEV F hfield_rod(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, V3<F> az, V3<F>& n_out, V3<F>& arm_out) {
+TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, V3<F> az, V3<F>& n_out, V3<F>& arm_out) {
   typedef typename LaneTraits<F>::I I;
   const S rad = P.rcyl_r, H = P.bar_half;
   const F zero = F(S(0));
+  const V3<F> z3 = mk<F>(zero, zero, zero);
   const F cx = cvt<F>(ck.x), cy = cvt<F>(ck.y), cz = cvt<F>(ck.z);
   const F ex = abs_(az.x) * H + rad, ey = abs_(az.y) * H + rad;
   auto inb = !((cx + ex < -P.hf_rx) | (cx - ex > P.hf_rx) | (cy + ey < -P.hf_ry) | (cy - ey > P.hf_ry));
@@ -489,40 +493,43 @@ TGR_RDEV F hfield_rod(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, V3<F
   c0 = clampi(c0, 0, P.hf_ncol - 2); r0 = clampi(r0, 0, P.hf_nrow - 2);
   c1 = clampi(c1, 0, P.hf_ncol - 2); r1 = clampi(r1, 0, P.hf_nrow - 2);
   c1 = sel(c1 > c0 + 2, c0 + 2, c1); r1 = sel(r1 > r0 + 2, r0 + 2, r1);
-  F hz[4][4];
-  for (int j = 0; j < 4; j++)
-    for (int i = 0; i < 4; i++) hz[j][i] = hf_at<F>(P, c0 + i, r0 + j);
   const K x0 = cvt<K>(from_int(c0, F())) * PK.hf_dx - PK.hf_rx, y0 = cvt<K>(from_int(r0, F())) * PK.hf_dy - PK.hf_ry;
   const V3<F> c = mk<F>(cvt<F>(ck.x - x0), cvt<F>(ck.y - y0), cz);
-  F best = F(S(1));
+  F best = F(S(1)), bt = F(S(99));
   V3<F> bpa = c, bpb = c;
-  for (int j = 0; j < 3; j++)
-    for (int i = 0; i < 3; i++) {
-      const auto cell = inb & ((c0 + i) <= c1) & ((r0 + j) <= r1);
-      const S xa = S(i) * P.hf_dx, ya = S(j) * P.hf_dy;
-      for (int k = 0; k < 3; k++) {
-        // edges of cell (c, r): (c,r)-(c+1,r), (c,r)-(c,r+1), and the strip diagonal (c,r+1)-(c+1,r)
-        const V3<F> va = k == 2 ? mk<F>(F(xa), F(ya + P.hf_dy), hz[j + 1][i]) : mk<F>(F(xa), F(ya), hz[j][i]);
-        const V3<F> vb = k == 1 ? mk<F>(F(xa), F(ya + P.hf_dy), hz[j + 1][i]) : mk<F>(F(xa + P.hf_dx), F(ya), hz[j][i + 1]);
-        V3<F> ed = vb - va;
-        const F el = sqrt_(dot(ed, ed));
-        ed = rcp_(el) * ed;
-        const V3<F> mid = S(0.5) * (va + vb);
-        F s_, t_;
-        seg_seg_closest(c, az, H, mid, ed, S(0.5) * el, s_, t_);
-        const V3<F> pa = c + s_ * az, pb = mid + t_ * ed;
-        const V3<F> df = pa - pb;
-        const F dist = sqrt_(dot(df, df)) - rad;
-        const auto take = cell & (dist < S(0)) & (dist < best);
-        best = sel(take, dist, best); bpa = sel3(take, pa, bpa); bpb = sel3(take, pb, bpb);
-      }
-    }
-  const V3<F> df = bpa - bpb;
+  const I l = lane_id();
+  for (int h = 0; h < 2; h++) {
+    // my edge t = (j * 3 + i) * 3 + k of cell (c0 + i, r0 + j): k = 0: (c,r)-(c+1,r), 1: (c,r)-(c,r+1), 2: the strip diagonal (c,r+1)-(c+1,r)
+    const I t = l + 16 * h;
+    const I j = (t * 57) >> 9, rem = t - j * 9, i = (rem * 43) >> 7, k = rem - i * 3;
+    const auto cell = inb & (t < 27) & ((c0 + i) <= c1) & ((r0 + j) <= r1);
+    const I ia = i, ja = j + sel(k == 2, I(1), I(0)), ib = i + sel(k == 1, I(0), I(1)), jb = j + sel(k == 1, I(1), I(0));
+    const V3<F> va = mk<F>(from_int(ia, F()) * P.hf_dx, from_int(ja, F()) * P.hf_dy, hf_at<F>(P, c0 + ia, r0 + ja));
+    const V3<F> vb = mk<F>(from_int(ib, F()) * P.hf_dx, from_int(jb, F()) * P.hf_dy, hf_at<F>(P, c0 + ib, r0 + jb));
+    V3<F> ed = vb - va;
+    const F el = sqrt_(dot(ed, ed));
+    ed = rcp_(el) * ed;
+    const V3<F> mid = S(0.5) * (va + vb);
+    F s_, t_;
+    seg_seg_closest(c, az, H, mid, ed, S(0.5) * el, s_, t_);
+    const V3<F> pa = c + s_ * az, pb = mid + t_ * ed;
+    const V3<F> df = pa - pb;
+    const F dist = sqrt_(dot(df, df)) - rad;
+    const auto take = cell & (dist < S(0)) & (dist < best);
+    best = sel(take, dist, best); bpa = sel3(take, pa, bpa); bpb = sel3(take, pb, bpb); bt = sel(take, from_int(t, F()), bt);
+  }
+  // the deepest edge of the row; of equally deep ones the first in the order of the plain loop
+  const F dmin = -rowmax(-best);
+  const auto cand = (best == dmin) & (best < S(0));
+  const F tmin = -rowmax(-sel(cand, bt, F(S(99))));
+  const auto win = cand & (bt == tmin);
+  const V3<F> wpa = rowsum3(sel3(win, bpa, z3)), wpb = rowsum3(sel3(win, bpb, z3));
+  const V3<F> df = wpa - wpb;
   const F nn = sqrt_(dot(df, df));
-  const auto ok = (best < S(0)) & (nn > S(1e-12));
+  const auto ok = (dmin < S(0)) & (nn > S(1e-12));
   n_out = sel3(ok, rcp_(max_(nn, F(S(1e-30)))) * df, mk<F>(zero, zero, F(S(1))));
-  arm_out = sel3(ok, (bpa - c) - (rad + S(0.5) * best) * n_out, mk<F>(zero, zero, zero));
-  return sel(ok, best, F(S(1)));
+  arm_out = sel3(ok, (wpa - c) - (rad + S(0.5) * dmin) * n_out, z3);
+  return sel(ok, dmin, F(S(1)));
 }
 
 // ------------------------------------------------------------------ row-distributed dense algebra (lane i holds row i)
@@ -939,7 +946,15 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
         F d2[2]; V3<F> n2[2];
         V3<F> rn, rarm;
         hfield_cap<K, F>(PK, P, (kxc + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc) - org, d2, n2);
-        const F rd = hfield_rod<K, F>(PK, P, kxc - org, cvt3<F>(kzc), rn, rarm);
+        F rd = F(S(1));
+        rn = mk<F>(zero, zero, F(S(1))); rarm = z3;
+        static_for<3>([&](auto bc_) {  // (every bar's cylinder: the whole row works on it, lane 12 + b keeps the outcome)
+          constexpr int b = decltype(bc_)::value;
+          V3<F> bn, barm;
+          const F bd = hfield_rod_row<K, F>(PK, P, ld3(M.kd, KX + 3 * b) - org, cvt3<F>(ld3(M.kd, KEZ + 3 * b)), bn, barm);
+          const auto mine = Ro.r == 12 + b;
+          rd = sel(mine, bd, rd); rn = sel3(mine, bn, rn); rarm = sel3(mine, barm, rarm);
+        });
         const auto hit0 = sel(Ro.is_cap, d2[0] < S(0), sel(Ro.is_rod, rd < S(0), false));
         dist = sel(hit0, sel(Ro.is_cap, d2[0], rd), zero);
         fn = sel3(Ro.is_cap, n2[0], rn);
