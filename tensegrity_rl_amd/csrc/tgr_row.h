@@ -1013,6 +1013,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   }
   if (LAST) lag.overflow = rowsum(dropped);
   const auto any_contact = rowsum(sel(c.active | any1, F(S(1)), zero)) > S(0);
+  // MODEL 1: does any cap of the wavefront rest on two facets?  (uniform; the whole second page is skipped otherwise -- the common case)
+  const bool page1 = MODEL && any_lane(any1);
   // ---- Newton on d = a - a0 (replicated).  Stopping rule: sqrt(g^T M^-1 g) < tol, in sqrt(kg) m/s^2.  mujoco's rule -- the plain norm
   // of g over (mean inertia x nv) -- lets a torque residual about a bar's own axis (inertia 0.0038 kg m^2) pass that still spins the bar
   // up by 1e-2 rad/s^2; weighting by M^-1 bounds the acceleration error itself (H >= M), which is what the tolerance on qvel is about.
@@ -1067,7 +1069,9 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     RContact<F> cs1;
     V3<F> jl1 = z3, ja1 = z3;
     RCone<F> o1;
-    if (MODEL) {
+    cs1.active = typename LaneTraits<F>::B(false);
+    o1.fl = z3; o1.fa = z3;
+    if (page1) {
       cs1.n = ld3(M.cd, C_SLAB + CN); cs1.rA = z3; cs1.rB = ld3(M.cd, C_SLAB + CRB);
       cs1.c0 = M.cd.ld(C_SLAB + CC0); cs1.Dn = M.cd.ld(C_SLAB + CDN); cs1.active = M.cd.ld(C_SLAB + CACT) != S(0);
       jl1 = ld3(M.cd, C_SLAB + CJL0) + (ld3(M.cd, CDLB) + cross(ld3(M.cd, CDAB), cs1.rB));
@@ -1084,7 +1088,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       tauB = dot(kfl, ld3(M.ad, AMB)) + dot(kfa, ld3(M.ad, AZB));
       tauA = dot(kfl, ld3(M.ad, AMA)) + dot(kfa, ld3(M.ad, AZA));
     }
-    if (MODEL) {
+    if (page1) {
       fB = fB + o1.fl; tB = tB + cross(cs1.rB, o1.fl) + o1.fa;
       tauB = tauB + dot(cvt3<K>(o1.fl), ld3(M.ad, A_SLAB + AMB)) + dot(cvt3<K>(o1.fa), ld3(M.ad, A_SLAB + AZB));
     }
@@ -1137,7 +1141,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     }
     for (int i = 0; i < 6; i++) { H.O10[i] = zero; H.O20[i] = zero; H.O21[i] = zero; }
     static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<0, decltype(cc)::value>(H, dc, cs, o); });
-    if (MODEL) static_for<6>([&](auto cc) { hess_add_slot<1, decltype(cc)::value>(H, dc, cs1, o1); });
+    if (page1) static_for<6>([&](auto cc) { hess_add_slot<1, decltype(cc)::value>(H, dc, cs1, o1); });
     // which bar pairs does any environment of the wavefront couple?  (uniform: lets the factorisation skip zero blocks)
     const bool cp0 = any_slot<6>(cs.active) || any_slot<7>(cs.active), cp1 = any_slot<8>(cs.active) || any_slot<9>(cs.active),
                cp2 = any_slot<10>(cs.active) || any_slot<11>(cs.active);
@@ -1162,7 +1166,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     const V3<F> qa = paB - paA;
     const RLSlot<F> ls = ls_make(cs, jl, ja, ql, qa);
     RLSlot<F> ls1;
-    if (MODEL) ls1 = ls_make(cs1, jl1, ja1, plB + cross(paB, cs1.rB), paB);
+    if (page1) ls1 = ls_make(cs1, jl1, ja1, plB + cross(paB, cs1.rB), paB);
     conv = conv | !(abs_(d0) >= P.tol * P.tol);  // Newton decrement g^T H^-1 g (<= g^T M^-1 g) below tolerance
     conv = conv | !(d0 < S(0));                  // no descent left at working precision
     if (!any_lane(!conv)) break;                 // (the iterate stays where the wrench above was taken)
@@ -1173,7 +1177,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     for (int k = 0;; k++) {
       F s1, s2;
       ls_slot(P, ls, alpha, s1, s2);
-      if (MODEL) {
+      if (page1) {
         F t1, t2;
         ls_slot(P, ls1, alpha, t1, t2);
         s1 = s1 + t1; s2 = s2 + t2;
