@@ -32,7 +32,7 @@ enum : int {
   F_QPOS = 0, F_QVEL = 21, F_WARM = 39, F_CTRL = 57, F_XYLAG = 63, F_PSILAG = 65, F_RESETPSI = 66,
   F_EPRET = 67, F_WAYPT = 68, F_ORI = 70, F_VCMD = 72, F_ACT = 75, NF = 81
 };
-enum : int { I_STEPNUM = 0, I_ELAPSED, I_RINGLEN, I_RINGHEAD, I_EPISODE, I_PHASE, I_SRC, I_SRCEP, NI };
+enum : int { I_STEPNUM = 0, I_ELAPSED, I_RINGLEN, I_RINGHEAD, I_EPISODE, I_PHASE, I_SRC, I_SRCEP, I_HALF, NI };  // I_HALF: row kernels, paced donor rows
 constexpr int RING = 32;
 static_assert(RING == TGR_RING_CAPACITY && TGR_AUX_K == TGR_AUX_RING + RING, "aux layout of tgr_get_state / tgr_set_state");
 constexpr double PI = 3.14159265358979323846;
@@ -52,6 +52,7 @@ template <typename T> struct KArgs {
   Params<T> P;
   EnvCfg<T> E;
   int n, m;  // live envs, total lanes (live + donors)
+  int slow_e;  // row kernels: donor rows from this index on (a multiple of 4) settle in half quanta -- see step_kernel_row; >= m: none
   T* st; int* ist; T* ring;
   const float* actions;
   T* obs; T* reward; uint8_t* terminated; uint8_t* truncated; T* terminal_obs; T* info;
@@ -905,6 +906,13 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   const bool donor_run = valid && e >= n && (phase > 0 || phase == PH_INIT);
   const bool active = live || donor_run;
   const int total = settle_total(E);
+  // Paced donor rows.  A launch whose busy wavefronts slightly exceed the wave slots of the chip (4096 envs + ~4300 settling donors =
+  // 2110 wavefronts for 2048 slots) ends with the wavefronts that had to wait for a slot: they start when the first ones retire and
+  // then run a whole period.  Those are the highest-indexed busy donors.  The donor rows from slow_e on therefore advance HALF a
+  // control period per launch (same sub-steps in the same order, over two launches; I_HALF says which half is due): half as long,
+  // they end before the longest first-round wavefront does.  Wavefront-uniform: slow_e and the rows of a wavefront are multiples of 4.
+  const bool slow = lb * ROW_ENVS >= k.slow_e;
+  const int nsub = slow ? E.frame_skip / 2 : E.frame_skip;
   row::RLag<TK, T> rl;
   row_lag_init<T, TK>(rl);
   if (__any(active)) {  // (a wavefront of idle donor rows has nothing to do)
@@ -929,7 +937,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
     }
     row::store_role_consts<TK, T, TK, MODEL>(ra.PK, M.rd);
 #pragma unroll 1
-    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, M, rl);
+    for (int s = 0; s + 1 < nsub; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, M, rl);
     row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, M, rl);
   }
   // Who this row is gets worked out a second time, from laundered thread and block numbers: carried through the twenty sub-steps in
@@ -952,6 +960,10 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
     const int total = settle_total(E);
     const int D = E.obs_dim;
     if (!__any(active)) return;
+    const bool slow = lb * ROW_ENVS >= k.slow_e;
+    const int nsub = slow ? E.frame_skip / 2 : E.frame_skip;
+    // a paced row that has just been set up, or whose half flag is clear, has run the FIRST half of its period
+    const bool first_half = slow && donor_run && (phase == PH_INIT || k.ist[I_HALF * m + e] == 0);
     if (donor_run && phase == PH_INIT) phase = total;  // (the episode was set up at the top)
     const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
     Sim<T> S;
@@ -961,12 +973,27 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
     if ((threadIdx.x & 63u) == 0) {
       atomicAdd(&k.counters[3], (unsigned long long)lag.n_it);
       atomicAdd(&k.counters[4], (unsigned long long)lag.n_ls);
-      atomicAdd(&k.counters[5], (unsigned long long)E.frame_skip);
+      atomicAdd(&k.counters[5], (unsigned long long)nsub);
     }
     if (active && w0 && lag.n_unconv) atomicAdd(&k.counters[6], (unsigned long long)lag.n_unconv);
     {
       const int nact = __popcll(__ballot(active && w0));
-      if ((threadIdx.x & 63u) == 0) atomicAdd(&k.counters[7], (unsigned long long)(nact * E.frame_skip));
+      if ((threadIdx.x & 63u) == 0) atomicAdd(&k.counters[7], (unsigned long long)(nact * nsub));
+    }
+    if (slow) {
+      // (every busy row of a paced wavefront is a donor row; a wavefront is never half live)
+      if (first_half) {
+        // mid-period: the state goes back as it is, nothing of the period's end happens yet
+        if (w0) {
+          V3<T> wb[3];
+          store_sim(k.st, m, e, S, lag, wb);
+          k.ist[I_PHASE * m + e] = phase;  // (a freshly set up row leaves PH_INIT here)
+          k.ist[I_HALF * m + e] = 1;
+          if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
+        }
+        return;
+      }
+      if (donor_run && w0) k.ist[I_HALF * m + e] = 0;
     }
     T* const orow = sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16);  // the contact slots are dead now
     finish_lane<T, true>(k, S, lag, e, valid, live, active, w0, phase, total, orow, orow + 64);  // (orow: <= 49 values of the row's 480)
@@ -1162,6 +1189,7 @@ template <typename T> __global__ __launch_bounds__(1024) void match_kernel(KArgs
     k.ist[I_SRC * m + slot] = donor;
     k.ist[I_SRCEP * m + slot] = k.ist[I_SRCEP * m + donor];
     k.ist[I_PHASE * m + donor] = PH_INIT;
+    k.ist[I_HALF * m + donor] = 0;
     k.doneflag[slot] = 0;
   }
   __syncthreads();
@@ -1206,6 +1234,7 @@ using namespace tgr;
 struct tgr_handle {
   tgr_config cfg;
   int n = 0, m = 0, device = 0, obs_dim = 0;
+  int n_cu = 256;  // compute units of the device (how many rows one round of the row kernels holds)
   void* st = nullptr;   // T[NF][m]
   int* ist = nullptr;   // int[NI][m]
   void* ring = nullptr; // T[RING][m]
@@ -1395,6 +1424,17 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   E.ten_mean = c.tendon_reset_mean; E.ten_std = c.tendon_reset_stdev; E.ten_max = c.tendon_max_length; E.ten_min = c.tendon_min_length;
   E.seed = c.seed; E.first_env_id = c.first_env_id; E.reset_noise = c.reset_noise_scale;
   k.n = h->n; k.m = h->m;
+  {
+    // Paced donor rows (step_kernel_row): the rows that do not fit the first round of wave slots -- one round holds 4 rows per wavefront,
+    // 8 wavefronts per CU for the fp32 flat-floor kernels (4 otherwise) -- but never more than the upper half of the donor pool, and only
+    // when the live rows alone leave room in that round (otherwise a launch is several rounds anyway and pacing would only slow resets).
+    const int donors = h->m - h->n;
+    const int round_rows = h->n_cu * ((c.precision != TGR_PRECISION_F64 && c.model_kind == 0) ? 8 : 4) * 4;
+    int from = round_rows > h->n + donors / 2 ? round_rows : h->n + donors / 2;
+    from = ((from + 3) / 4) * 4;
+    const bool pace = c.auto_reset && donors >= 64 && (c.frame_skip % 2) == 0 && h->n < round_rows && from < h->m;
+    k.slow_e = pace ? from : h->m + 4;
+  }
   k.st = (T*)h->st; k.ist = h->ist; k.ring = (T*)h->ring; k.dobs = (T*)h->dobs;
   k.list_count = h->list_count; k.list = h->list; k.rlist = h->rlist; k.doneflag = h->doneflag; k.counters = h->counters;
   k.auto_reset = c.auto_reset;
@@ -1476,6 +1516,10 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   tgr_handle* h = new (std::nothrow) tgr_handle();
   if (!h) return TGR_ERR_INVALID;
   h->cfg = *cfg; h->n = n_envs; h->device = device; h->obs_dim = obs_dim_of(*cfg);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+  }
   int donors = cfg->n_donors < 0 ? 2 * n_envs : cfg->n_donors;
   if (!cfg->auto_reset) donors = 0;
   h->m = n_envs + donors;
