@@ -21,7 +21,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROFILE = os.path.join(ROOT, "profiles", "round2_bench_rocprofv3_summary.json")
+PROFILE = os.path.join(ROOT, "profiles", "round3_bench_rocprofv3_summary.json")
+CENSUS = os.path.join(ROOT, "profiles", "round3_lane_census.json")
 
 
 def profiled():
@@ -48,6 +49,35 @@ def profiled():
 
 BYTES_PER_ENV_STEP = 674  # fp32: 61 state words in + 6 action words in, 61 state words + 39 obs words + reward + 2 flags out
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate 6290
+
+
+def useful_lane_fraction():
+    """Share of the lanes of a VALU instruction of the step kernel that own distinct work (the rest replicate a value or idle in their role):
+    from the operation census of the host emulation of the same kernel source (tests/emul_census.py -> profiles/round3_lane_census.json)."""
+    try:
+        return float(json.load(open(CENSUS))["useful_lane_frac"])
+    except Exception:
+        return None
+
+
+def vecenv_rate(n, env_id, device, steps=150):
+    """env-steps/s through the numpy-facing SB3 surface -- TensegrityVecEnv.step(actions), info_mode="minimal": host actions in, host
+    obs / rewards / dones / infos out (what SB3's collect_rollouts drives, run.py:41-101).  Measured on its own env AFTER the headline
+    region; reported as config.vecenv_step_wait_env_steps_per_s, never as `value`."""
+    import numpy as np
+    from tensegrity_rl_amd import TensegrityVecEnv
+    env = TensegrityVecEnv(n, env_id, device=device, desired_action="straight", desired_direction=1, seed=1234, n_donors=5 * n // 4)
+    env.reset()
+    rng = np.random.default_rng(0)
+    acts = [rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32) for _ in range(8)]
+    for i in range(20):
+        env.step(acts[i % 8])
+    t0 = time.perf_counter()
+    for i in range(steps):
+        env.step(acts[i % 8])
+    dt = time.perf_counter() - t0
+    env.close()
+    return n * steps / dt
 
 
 def cpu_baseline(seconds, envs):
@@ -157,6 +187,7 @@ def main():
     ap.add_argument("--gather-every", type=int, default=16)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vecenv", action="store_true", help="skip the numpy-facing VecEnv.step() measurement (reported beside the headline)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -254,6 +285,8 @@ def main():
         default_workload = args.model == "flat" and args.env_id == "tensegrity_env-v0" and n_local == 4096 and row_layout and args.donors is None
         prof = profiled() if default_workload else {"traffic": None, "valu_per_launch": None, "source": "not the profiled (default) workload"}
         lane_sub = max(stats1["lane_substeps"] - stats0["lane_substeps"], 1)
+        ulf = useful_lane_fraction()
+        valu_rate = (prof["valu_per_launch"] * 64 / (kern_ms * 1e-3)) if prof["valu_per_launch"] else None
         out = {
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -261,7 +294,7 @@ def main():
             "config": {"workload": f"3-bar {'uneven-ground (heightfield)' if args.model == 'uneven' else 'flat-ground'} {args.env_id} straight/+1, N_envs={n_local} per GPU ({n_total} total), "
                                    "random-action rollout U[-0.45,0.15]^6, auto-reset via donor lanes, 20 sub-steps of 1 ms per step",
                        "envs_per_gpu": n_local, "donor_lanes_per_gpu": donors,
-                       "kernel_layout": "row (one env per 16-lane DPP row; fp32 with pose / kinematics / tendon geometry / axial torques in fp64)" if row_layout
+                       "kernel_layout": "row (one env per 16-lane DPP row; fp32 with pose / kinematics / tendon geometry / axial torques in fp64; qpos kept in fp64 in HBM)" if row_layout
                                         else "block (64 envs x 4 wavefronts, LDS columns; fp32 throughout)",
                        "gather_every": args.gather_every if world > 1 else None,
                        "resets_per_step_rank0": resets / args.steps,
@@ -278,9 +311,18 @@ def main():
                          "kernel_ms": kern_ms, "kernel_ms_p50": step_ms[len(step_ms) // 2],
                          # the practical bound is VALU issue of the resident waves, so report those too
                          "resident_waves": ((n_local + donors + 3) // 4) if row_layout else 4 * ((n_local + donors + 63) // 64),
-                         "valu_lane_ops_per_s": (prof["valu_per_launch"] * 64 / (kern_ms * 1e-3)) if prof["valu_per_launch"] else None,
-                         "valu_frac_of_peak": (prof["valu_per_launch"] * 64 / (kern_ms * 1e-3) / 78.6e12) if prof["valu_per_launch"] else None},
+                         # 78.6e12 = 1024 SIMDs x 32 lanes x 2.4 GHz: one wave64 VALU instruction per SIMD every 2 cycles (MI355X_MICROARCH.md)
+                         "valu_lane_ops_per_s": valu_rate,
+                         "valu_frac_of_peak": (valu_rate / 78.6e12) if valu_rate else None,
+                         # the same rate counting only lanes that own distinct work (replicated values and idle role lanes excluded)
+                         "useful_lane_frac": ulf,
+                         "valu_useful_frac_of_peak": (valu_rate * ulf / 78.6e12) if (valu_rate and ulf) else None},
         }
+        if not args.no_vecenv and world == 1 and args.model == "flat":
+            try:
+                out["config"]["vecenv_step_wait_env_steps_per_s"] = vecenv_rate(n_local, args.env_id, local_rank)
+            except Exception as e:
+                out["config"]["vecenv_step_wait_env_steps_per_s"] = f"failed: {e}"
         if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed once: rank 0 of the one-GPU run
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 64)

@@ -132,6 +132,16 @@ typedef struct tgr_config {
    * precision"); solver_tolerance then bounds sqrt(g^T M^-1 g).  TGR_KERNEL_BLOCK: 64 environments x 4 wavefronts with per-lane LDS
    * columns (tgr_device.h), all arithmetic in the handle's precision, mujoco's stopping rule: kept as a cross-check.  AUTO = ROW */
   int32_t kernel_layout;
+  /* row kernels: the solve of a sub-step also stops when sqrt(g^T M^-1 g) < solver_rel_tolerance * sqrt(d^T M d), d the constraint
+   * acceleration: what the arithmetic resolves of the gradient when contact forces are large.  0: default for the precision (fp32 handles
+   * 2e-5 on the flat floor and 5e-6 on the heightfield, fp64 handles off), < 0: off */
+  double solver_rel_tolerance;
+  /* auto-reset that does not depend on the sharding.  0 (default): one donor pool per handle, a finished env takes the
+   * lowest-indexed ready donor -- which episode that is depends on the other envs of the handle.  B > 0: envs are grouped in classes of B
+   * consecutive GLOBAL env ids, each with its own n_donors / (n_envs / B) donor lanes and ONE stream of episodes keyed (class, 0), (class, 1),
+   * ... handed out strictly in order: the k-th reset of a class gets episode k.  Any sharding whose shards are whole classes (n_envs and
+   * first_env_id multiples of B) then gives every env the same trajectory, resets included.  Costs the paced donor rows */
+  int32_t reset_stream_envs;
 } tgr_config;
 
 typedef struct tgr_handle tgr_handle;
@@ -206,6 +216,14 @@ int tgr_set_seed(tgr_handle* h, uint64_t seed);
  * valid until unbound with NULL or the handle is destroyed); every tgr_step then also writes the noise-free observation of the step
  * (for an env that finished: of its last step, like terminal_obs) there.  Without observation noise it equals obs before auto-reset. */
 int tgr_bind_real_observation(tgr_handle* h, void* real_obs_dev);
+/* diagnostic (accuracy classification, tests/gpu_accuracy_report.py): bind a DEVICE buffer uint32 [N][TGR_TRACE_WORDS] (caller-owned, valid
+ * until unbound with NULL); every tgr_step of a row-kernel handle then records, per env and sub-step s < frame_skip, word s =
+ * contact slots instantiated in the forward pass of that sub-step (bit c < 6: cap c on the floor; 6 + 2p / 7 + 2p: the r-cylinders of bar
+ * pair p side to side / any other contact of the pair; 12 + b: bar b's cylinder on the terrain; 16 + c: cap c on a second facet)
+ * | (Newton iterations the env itself needed so far this step, mod 256) << 22 | (the solver left this sub-step at its iteration cap) << 30.
+ * replaces: reads of env.data.contact / data.solver_iter after mj_step (run.py:154-161 reads data.contact the same way) */
+#define TGR_TRACE_WORDS 24
+int tgr_bind_substep_trace(tgr_handle* h, uint32_t* trace_dev);
 int tgr_synchronize(tgr_handle* h);
 const char* tgr_last_error(const tgr_handle* h);
 const char* tgr_version(void);

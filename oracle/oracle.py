@@ -47,7 +47,8 @@ class Data(C.Structure):
                 ("ten_J", (d * NV) * NTEN), ("actuator_force", d * NU), ("qfrc_passive", d * NV),
                 ("qfrc_actuator", d * NV), ("qfrc_bias", d * NV), ("qfrc_smooth", d * NV), ("qacc_smooth", d * NV),
                 ("qfrc_constraint", d * NV), ("qacc", d * NV), ("ncon", C.c_int), ("con", Contact * MAXCON),
-                ("cfrc_ext", (d * 6) * 4), ("solver_iter", C.c_int), ("flags", C.c_int), ("act", d * NU), ("act_dot", d * NU)]
+                ("cfrc_ext", (d * 6) * 4), ("solver_iter", C.c_int), ("flags", C.c_int), ("act", d * NU), ("act_dot", d * NU),
+                ("trace_n", C.c_int), ("trace", C.c_uint32 * 32)]
 
 
 class EnvCfg(C.Structure):

@@ -963,9 +963,36 @@ static void implicitfast_advance(const tgo_model* m, tgo_data* d) {
   d->time += h;
 }
 
+uint32_t tgo_contact_mask(const tgo_model* m, const tgo_data* d) {
+  uint32_t mask = 0;
+  int floor_hits[6] = {0, 0, 0, 0, 0, 0}, others[3] = {0, 0, 0};
+  for (int ci = 0; ci < d->ncon; ci++) {
+    const tgo_contact* c = &d->con[ci];
+    if (c->body1 < 0) { /* floor (plane or heightfield) against geom2 of bar body2 */
+      const int g = c->geom2 - 1 - 5 * c->body2; /* 0 r-cylinder, 1 cap +z, 2 cap -z */
+      if (g == 0) mask |= 1u << (12 + c->body2);
+      else if (g == 1 || g == 2) {
+        const int cap = 2 * c->body2 + (g - 1);
+        mask |= (floor_hits[cap]++ == 0) ? (1u << cap) : (1u << (16 + cap));
+      }
+    } else {
+      const int A = c->body1 < c->body2 ? c->body1 : c->body2, B = c->body1 < c->body2 ? c->body2 : c->body1;
+      const int p = A == 0 ? (B == 1 ? 0 : 1) : 2;
+      const int g1 = c->geom1 - 1 - 5 * c->body1, g2 = c->geom2 - 1 - 5 * c->body2;
+      if (g1 == 0 && g2 == 0) mask |= 1u << (6 + 2 * p);
+      else if (others[p]++ == 0) mask |= 1u << (7 + 2 * p);
+      else if (!m->hf_data) mask |= 1u << (12 + p); /* flat-floor model: the row kernels keep a second one of these on lane 12 + p */
+    }
+  }
+  return mask;
+}
+
 void tgo_step(const tgo_model* m, tgo_data* d, int nstep) {
+  d->trace_n = 0;
   for (int i = 0; i < nstep; i++) {
     tgo_forward(m, d);
+    if (d->trace_n < TGO_TRACE)
+      d->trace[d->trace_n++] = tgo_contact_mask(m, d) | ((uint32_t)(d->solver_iter & 0xff) << 22) | ((d->flags & TGO_FLAG_NOCONV) ? 1u << 30 : 0u);
     implicitfast_advance(m, d);
   }
 }

@@ -13,6 +13,7 @@ PRECISION = {"f32": 0, "f64": 1, "float32": 0, "float64": 1}
 KERNEL_LAYOUT = {"auto": 0, "block": 1, "row": 2}
 INFO_K, AUX_K, NQ, NV, NU = 26, 55, 21, 18, 6
 AUX_RING, RING_CAPACITY = 23, 32
+TRACE_WORDS = 24
 INFO_TENDON_LENGTH, INFO_BAR_CONTACT = 16, 25
 INFO_KEYS = ["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
              "distance_from_origin", "x_velocity", "y_velocity", "forward_reward"]
@@ -37,13 +38,14 @@ class Config(C.Structure):
         ("waypt_reward_amplitude", f64), ("waypt_reward_stdev", f64), ("yaw_reward_weight", f64), ("solver_warm_start", i32),
         ("use_obs_noise", i32), ("obs_noise_tendon_stdev", f64), ("obs_noise_cap_pos_stdev", f64),
         ("model_kind", i32), ("site_offset", f64), ("act_tau", f64), ("hf_size", f64 * 4), ("hf_pos", f64 * 3),
-        ("reset_noise_scale", f64), ("kernel_layout", i32),
+        ("reset_noise_scale", f64), ("kernel_layout", i32), ("solver_rel_tolerance", f64), ("reset_stream_envs", i32),
     ]
 
 
 SYMBOLS = ["tgr_default_config", "tgr_create", "tgr_destroy", "tgr_num_envs", "tgr_obs_dim", "tgr_precision", "tgr_reset",
            "tgr_step", "tgr_step_f64", "tgr_get_state", "tgr_set_state", "tgr_stats", "tgr_set_seed", "tgr_synchronize",
-           "tgr_last_error", "tgr_version", "tgr_sizeof_config", "tgr_lane_key", "tgr_uneven_config", "tgr_set_hfield", "tgr_bind_real_observation"]
+           "tgr_last_error", "tgr_version", "tgr_sizeof_config", "tgr_lane_key", "tgr_uneven_config", "tgr_set_hfield", "tgr_bind_real_observation",
+           "tgr_bind_substep_trace"]
 
 _lib = None
 
@@ -88,6 +90,7 @@ def load():
     L.tgr_set_hfield.argtypes = [vp, vp, C.c_int, C.c_int]
     L.tgr_lane_key.restype = C.c_uint64
     L.tgr_bind_real_observation.argtypes = [vp, vp]
+    L.tgr_bind_substep_trace.argtypes = [vp, vp]
     if L.tgr_sizeof_config() != C.sizeof(Config):
         raise RuntimeError(f"tgr_config layout mismatch: C {L.tgr_sizeof_config()} vs ctypes {C.sizeof(Config)}")
     _lib = L

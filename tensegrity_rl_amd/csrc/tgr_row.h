@@ -27,7 +27,7 @@ template <typename S> struct RParams {
   S imp0, imp1, imp_width, imp_mid;
   S f0, f1sq, f3sq, f4sq, impratio;
   S invweight;
-  S tol, ls_tol;
+  S tol, rtol, ls_tol;  // stopping rule: sqrt(g^T M^-1 g) < max(tol, rtol * sqrt(d^T M d)) -- tgr_sim.hip params_to_row
   S cf_lo, cf_hi;
   int max_iter, ls_iter, skip_clamped, warm_start;
   S act_itau;
@@ -47,12 +47,18 @@ constexpr int ten_ba(int t) { return RTab::TEN0[t][0]; }  // the bars of a tendo
 constexpr int ten_bb(int t) { return RTab::TEN0[t][2]; }
 constexpr int pair_a(int p) { return p == 2 ? 1 : 0; }    // bar pairs (A,B): (0,1), (0,2), (1,2)
 constexpr int pair_b(int p) { return p == 0 ? 1 : 2; }
-// contact slot c of page 0: 0..5 cap c on the floor, 6..11 sub-slot (c-6)&1 of pair (c-6)>>1, MODEL 1: 12..14 rod of bar c-12 on the
-// terrain; page 1 (MODEL 1 only): 0..5 second terrain contact of cap c
-constexpr int slot_bar_a(int page, int c) { return (page == 0 && c >= 6 && c < 12) ? pair_a((c - 6) >> 1) : -1; }
-constexpr int slot_bar_b(int page, int c) { return c < 6 ? (c >> 1) : (c < 12 ? (page == 0 ? pair_b((c - 6) >> 1) : -1) : (page == 0 && c < 15 ? c - 12 : -1)); }
+// contact slot c of page 0: 0..5 cap c on the floor, 6..11 sub-slot (c-6)&1 of pair (c-6)>>1 (sub-slot 0: the r-cylinders side to side, 1: the
+// deepest of every other contact of the two bars), 12..14 -- MODEL 0: the second deepest of those other contacts of pair c-12 (a bar
+// crossing deeper than 3.1 mm touches the b-cylinder inside the r-cylinder as well: mujoco keeps every geom pair), MODEL 1: rod of bar c-12
+// on the terrain; page 1 (MODEL 1 only): 0..5 second terrain contact of cap c
+template <int MODEL> constexpr int slot_bar_a(int page, int c) {
+  return page != 0 ? -1 : ((c >= 6 && c < 12) ? pair_a((c - 6) >> 1) : ((!MODEL && c >= 12 && c < 15) ? pair_a(c - 12) : -1));
+}
+template <int MODEL> constexpr int slot_bar_b(int page, int c) {
+  return c < 6 ? (c >> 1) : (page != 0 ? -1 : (c < 12 ? pair_b((c - 6) >> 1) : (c < 15 ? (MODEL ? c - 12 : pair_b(c - 12)) : -1)));
+}
 template <int MODEL> constexpr int n_pages() { return MODEL ? 2 : 1; }
-template <int MODEL> constexpr int n_slots(int page) { return MODEL ? (page == 0 ? 15 : 6) : 12; }
+template <int MODEL> constexpr int n_slots(int page) { return page == 0 ? 15 : (MODEL ? 6 : 0); }
 
 // ------------------------------------------------------------------ replicated state of one environment
 // K: the lane type of pose, kinematics, tendon geometry and smooth forces (double in the mixed-precision production kernels: a tendon
@@ -94,6 +100,9 @@ template <typename F, typename S> TGR_RDEV V3<F> inertia_mul(const RParams<S>& P
   return P.Ixx * a + ((P.Izz - P.Ixx) * dot(z, a)) * z;
 }
 // lane-dependent choice among the three bars' replicated vectors
+template <bool USEK, typename SK, typename S> TGR_RDEV const auto& pick_params(const RParams<SK>& PK, const RParams<S>& P) {
+  if constexpr (USEK) return PK; else return P;
+}
 template <typename F, typename I> TGR_RDEV V3<F> pick_bar(I b, const V3<F>* a) { return sel3(b == 0, a[0], sel3(b == 1, a[1], a[2])); }
 template <typename F, typename I> TGR_RDEV V3<F> pick_bar0(I b, const V3<F>* a) {  // b < 0: the world (zero)
   typedef typename LaneTraits<F>::S S;
@@ -110,7 +119,7 @@ template <typename F> struct Roles {
   // tendon role (its K constants -- site coordinates, stiffness, damping, spring length -- live in the role slab)
   B is_ten; I ba, bb; B actuated;
   // slot role (page 0)
-  B is_cap, is_pair, is_rod; I sub; I sA, sB; F cap_sign;
+  B is_cap, is_pair, is_pair2, is_rod; I sub; I sA, sB; F cap_sign;
   // dof role
   B is_dof, is_ang; I k;
 };
@@ -153,10 +162,12 @@ template <typename F, int MODEL> TGR_RDEV Roles<F> lane_roles() {
   R.is_cap = r < 6;
   R.is_pair = (r >= 6) & (r < 12);
   R.is_rod = MODEL ? ((r >= 12) & (r < 15)) : (r < 0);
-  const I pr = (r - 6) >> 1;
+  R.is_pair2 = MODEL ? (r < 0) : ((r >= 12) & (r < 15));  // third slot of a bar pair (flat-floor model)
+  const I pr = sel(R.is_pair2, r - 12, (r - 6) >> 1);
+  const auto anypair = R.is_pair | R.is_pair2;
   R.sub = (r - 6) & 1;
-  R.sA = sel(R.is_pair, sel(pr == 2, I(1), I(0)), I(-1));
-  R.sB = sel(R.is_cap, r >> 1, sel(R.is_pair, sel(pr == 0, I(1), I(2)), sel(R.is_rod, r - 12, I(-1))));
+  R.sA = sel(anypair, sel(pr == 2, I(1), I(0)), I(-1));
+  R.sB = sel(R.is_cap, r >> 1, sel(anypair, sel(pr == 0, I(1), I(2)), sel(R.is_rod, r - 12, I(-1))));
   R.cap_sign = sel((r & 1) == 0, F(S(1)), F(S(-1)));
   R.is_dof = r < 6;
   R.is_ang = (r >= 3) & (r < 6);
@@ -239,18 +250,24 @@ template <typename F, typename S> TGR_RDEV RCone<F> cone_eval(const RParams<S>& 
 
 // ---- contact geometry between two bars (slot role, pair lanes); same rules as tgr_device.h bar_pair_contacts
 template <typename F> struct RCand { F dist; V3<F> n, p; typename LaneTraits<F>::B ok; };
-template <typename F, typename B> TGR_RDEV void keep_deeper(RCand<F>& best, F& count, F dist, V3<F> n, V3<F> p, B valid) {
+// the deepest and the second deepest of the candidates seen so far
+template <typename F, typename B> TGR_RDEV void keep_deeper(RCand<F>& best, RCand<F>& second, F& count, F dist, V3<F> n, V3<F> p, B valid) {
   typedef typename LaneTraits<F>::S S;
   auto hit = valid & (dist < S(0));
   count = count + sel(hit, F(S(1)), F(S(0)));
-  auto take = hit & (!best.ok | (dist < best.dist));
-  best.dist = sel(take, dist, best.dist);
-  best.n = sel3(take, n, best.n);
-  best.p = sel3(take, p, best.p);
+  auto first = hit & (!best.ok | (dist < best.dist));
+  auto sec = hit & !first & (!second.ok | (dist < second.dist));
+  second.dist = sel(first, best.dist, sel(sec, dist, second.dist));
+  second.n = sel3(first, best.n, sel3(sec, n, second.n));
+  second.p = sel3(first, best.p, sel3(sec, p, second.p));
+  second.ok = (first & best.ok) | (!first & (second.ok | sec));
+  best.dist = sel(first, dist, best.dist);
+  best.n = sel3(first, n, best.n);
+  best.p = sel3(first, p, best.p);
   best.ok = best.ok | hit;
 }
 template <typename F, typename S, typename B>
-TGR_RDEV void sphere_vs_bar(const RParams<S>& P, V3<F> c, V3<F> xo, V3<F> zo, bool flip, B enable, RCand<F>& best, F& count) {
+TGR_RDEV void sphere_vs_bar(const RParams<S>& P, V3<F> c, V3<F> xo, V3<F> zo, bool flip, B enable, RCand<F>& best, RCand<F>& second, F& count) {
   V3<F> wv = c - xo;
   F t = dot(wv, zo);
   V3<F> rad = wv - t * zo;
@@ -273,19 +290,20 @@ TGR_RDEV void sphere_vs_bar(const RParams<S>& P, V3<F> c, V3<F> xo, V3<F> zo, bo
     V3<F> pos = c + (P.cap_r + S(0.5) * dist) * n;
     auto valid = enable & sel(inside, rho > S(1e-12), dd > S(1e-12));
     V3<F> nn = flip ? -n : n;
-    keep_deeper(best, count, dist, nn, pos, valid);
+    keep_deeper(best, second, count, dist, nn, pos, valid);
   }
 }
-// c0: r-cylinder against r-cylinder (side-side); c1: the deepest of everything else; dropped: further hits that found no slot
+// c0: r-cylinder against r-cylinder (side-side); c1, c2: the deepest and the second deepest of everything else; dropped: further hits that
+// found no slot
 template <typename F, typename S>
 TGR_RDEV void bar_pair_contacts(const RParams<S>& P, V3<F> xA, V3<F> zA, V3<F> xB, V3<F> zB, typename LaneTraits<F>::B lanes,
-                                RContact<F>& c0, RContact<F>& c1, F& dropped) {
+                                RContact<F>& c0, RContact<F>& c1, RContact<F>& c2, F& dropped) {
   typedef typename LaneTraits<F>::B B;
   const F zero = F(S(0));
-  c0.active = B(false); c1.active = B(false);
-  c0.n = mk<F>(zero, zero, F(S(1))); c1.n = c0.n;
-  c0.rA = mk<F>(zero, zero, zero); c0.rB = c0.rA; c1.rA = c0.rA; c1.rB = c0.rA;
-  c0.c0 = zero; c1.c0 = zero; c0.Dn = zero; c1.Dn = zero;
+  c0.active = B(false); c1.active = B(false); c2.active = B(false);
+  c0.n = mk<F>(zero, zero, F(S(1))); c1.n = c0.n; c2.n = c0.n;
+  c0.rA = mk<F>(zero, zero, zero); c0.rB = c0.rA; c1.rA = c0.rA; c1.rB = c0.rA; c2.rA = c0.rA; c2.rB = c0.rA;
+  c0.c0 = zero; c1.c0 = zero; c2.c0 = zero; c0.Dn = zero; c1.Dn = zero; c2.Dn = zero;
   dropped = zero;
   V3<F> wv = xA - xB;
   F b = dot(zA, zB), dA = dot(zA, wv), dB = dot(zB, wv);
@@ -339,6 +357,7 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, V3<F> xA, V3<F> zA, V3<F> x
   }
   if (!any_lane(deep | ends)) return;
   RCand<F> best; best.ok = B(false); best.dist = zero; best.n = c0.n; best.p = xA;
+  RCand<F> second = best;
   F count = zero;
   const S bc = S(0.5) * (P.bcyl_hi + P.bcyl_lo), bh = S(0.5) * (P.bcyl_hi - P.bcyl_lo);
   for (int i = 0; i < 3; i++)
@@ -349,11 +368,11 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, V3<F> xA, V3<F> zA, V3<F> x
       auto interior = near_ & okdir & (abs_(s - ci) < hi_) & (abs_(t - cj) < hj_);
       F dist = dd - (ri + rj);
       V3<F> pos = pa + (ri + S(0.5) * dist) * n;
-      keep_deeper(best, count, dist, n, pos, interior);
+      keep_deeper(best, second, count, dist, n, pos, interior);
     }
   for (int ea = 0; ea < 2; ea++) {
     V3<F> ca = xA + (ea == 0 ? P.bar_half : -P.bar_half) * zA;
-    sphere_vs_bar(P, ca, xB, zB, false, near_, best, count);
+    sphere_vs_bar(P, ca, xB, zB, false, near_, best, second, count);
     for (int eb = 0; eb < 2; eb++) {
       V3<F> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
       V3<F> dv = cb - ca;
@@ -361,12 +380,12 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, V3<F> xA, V3<F> zA, V3<F> x
       F dist = cd - S(2) * P.cap_r;
       V3<F> nn = rcp_(max_(cd, F(S(1e-30)))) * dv;
       V3<F> pos = ca + (P.cap_r + S(0.5) * dist) * nn;
-      keep_deeper(best, count, dist, nn, pos, near_ & (cd > S(1e-12)));
+      keep_deeper(best, second, count, dist, nn, pos, near_ & (cd > S(1e-12)));
     }
   }
   for (int eb = 0; eb < 2; eb++) {
     V3<F> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
-    sphere_vs_bar(P, cb, xA, zA, true, near_, best, count);
+    sphere_vs_bar(P, cb, xA, zA, true, near_, best, second, count);
   }
   {
     auto hit = best.ok;
@@ -377,13 +396,22 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, V3<F> xA, V3<F> zA, V3<F> x
     contact_params(P, sel(hit, best.dist, zero), S(2), cc, dn);
     c1.c0 = sel(hit, cc, zero); c1.Dn = sel(hit, dn, zero);
   }
-  dropped = sel(count > S(1), count - S(1), zero);
+  {
+    auto hit = second.ok;
+    c2.active = hit;
+    c2.n = sel3(hit, second.n, c2.n);
+    c2.rA = sel3(hit, second.p - xA, c2.rA); c2.rB = sel3(hit, second.p - xB, c2.rB);
+    F cc, dn;
+    contact_params(P, sel(hit, second.dist, zero), S(2), cc, dn);
+    c2.c0 = sel(hit, cc, zero); c2.Dn = sel(hit, dn, zero);
+  }
+  dropped = sel(count > S(2), count - S(2), zero);
 }
 
 // ------------------------------------------------------------------ heightfield floor (MODEL 1), slot role, select form
 // closest point of triangle (a, b, c) to p (Ericson, Real-Time Collision Detection 5.1.5): every region evaluated, the first that applies
 // taken -- lanes of a row sit in different regions, so there is nothing to branch on
-template <typename F> TGR_RDEV V3<F> closest_on_triangle(V3<F> p, V3<F> a, V3<F> b, V3<F> c) {
+template <typename F> TGR_RDEV V3<F> closest_on_triangle(V3<F> p, V3<F> a, V3<F> b, V3<F> c, typename LaneTraits<F>::B& interior) {
   typedef typename LaneTraits<F>::S S;
   const V3<F> ab = b - a, ac = c - a, ap = p - a, bp = p - b, cp = p - c;
   const F d1 = dot(ab, ap), d2 = dot(ac, ap), d3 = dot(ab, bp), d4 = dot(ac, bp), d5 = dot(ab, cp), d6 = dot(ac, cp);
@@ -399,6 +427,7 @@ template <typename F> TGR_RDEV V3<F> closest_on_triangle(V3<F> p, V3<F> a, V3<F>
   const V3<F> qBC = b + ((d4 - d3) / ((d4 - d3) + (d5 - d6))) * (c - b);
   const F den = S(1) / (va + vb + vc);
   const V3<F> qI = a + (vb * den) * ab + (vc * den) * ac;
+  interior = !(rA | rB | rAB | rC | rAC | rBC);
   return sel3(rA, a, sel3(rB, b, sel3(rAB, qAB, sel3(rC, c, sel3(rAC, qAC, sel3(rBC, qBC, qI))))));
 }
 // normalised elevation at grid vertex (cc, rr), clamped to the grid
@@ -426,7 +455,8 @@ TGR_RDEV void hfield_cap(const RParams<SK>& PK, const RParams<S>& P, V3<K> pk, F
     for (int i = 0; i < 3; i++) hz[j][i] = hf_at<F>(P, c0 + i, r0 + j);
   // position relative to the corner vertex (c0, r0), formed in K
   const K x0 = cvt<K>(from_int(c0, F())) * PK.hf_dx - PK.hf_rx, y0 = cvt<K>(from_int(r0, F())) * PK.hf_dy - PK.hf_ry;
-  const V3<F> p = mk<F>(cvt<F>(pk.x - x0), cvt<F>(pk.y - y0), pz);
+  const K pxk = pk.x - x0, pyk = pk.y - y0;
+  const V3<F> p = mk<F>(cvt<F>(pxk), cvt<F>(pyk), pz);
   F bd0 = F(S(1)), bd1 = F(S(1));
   V3<F> bq0 = p, bq1 = p;
   for (int j = 0; j < 2; j++)
@@ -436,9 +466,24 @@ TGR_RDEV void hfield_cap(const RParams<SK>& PK, const RParams<S>& P, V3<K> pk, F
       const V3<F> v[4] = {mk<F>(F(xa), F(ya), hz[j][i]), mk<F>(F(xa), F(ya + P.hf_dy), hz[j + 1][i]), mk<F>(F(xa + P.hf_dx), F(ya), hz[j][i + 1]),
                           mk<F>(F(xa + P.hf_dx), F(ya + P.hf_dy), hz[j + 1][i + 1])};  // (c,r) (c,r+1) (c+1,r) (c+1,r+1)
       for (int tri = 0; tri < 2; tri++) {
-        const V3<F> q = closest_on_triangle(p, v[tri], v[tri + 1], v[tri + 2]);
+        typename LaneTraits<F>::B interior;
+        const V3<F> q = closest_on_triangle(p, v[tri], v[tri + 1], v[tri + 2], interior);
         const V3<F> df = p - q;
-        const F dist = sqrt_(dot(df, df)) - rad;
+        F dist = sqrt_(dot(df, df)) - rad;
+        {
+          // A cap that rests on the face of a facet (the usual case): its distance is the distance to the facet's plane, formed in K like the
+          // floor distance of the flat model -- in F the metre-sized cell coordinates leave 6e-8 m of noise in it, enough to move a cap
+          // across dist = 0 in 0.3 % of env-steps.  Edges of the triangles: tri 0 = (c,r) (c,r+1) (c+1,r), tri 1 = (c,r+1) (c+1,r) (c+1,r+1);
+          // both have the normal (-dy (h_e - h_0), -dx (h_n - h_0), dx dy) with (h_0, h_e, h_n) = heights at the corner the two axis-parallel
+          // edges meet in, along x and along y from it.
+          const K h0 = cvt<K>(tri == 0 ? hz[j][i] : hz[j + 1][i + 1]), he = cvt<K>(tri == 0 ? hz[j][i + 1] : hz[j + 1][i]),
+                  hn = cvt<K>(tri == 0 ? hz[j + 1][i] : hz[j][i + 1]);
+          const SK sg = tri == 0 ? SK(1) : SK(-1);  // tri 1: the corner is (c+1, r+1), its edges run towards -x and -y
+          const K nx = -(PK.hf_dy * (he - h0)) * sg, ny = -(PK.hf_dx * (hn - h0)) * sg, nz = K(PK.hf_dx * PK.hf_dy);
+          const K rx = pxk - SK(tri == 0 ? i : i + 1) * PK.hf_dx, ry = pyk - SK(tri == 0 ? j : j + 1) * PK.hf_dy, rz = pk.z - h0;
+          const K dpl = (nx * rx + ny * ry + nz * rz) * rsqrt_(nx * nx + ny * ny + nz * nz) - PK.cap_r;
+          dist = sel(interior, cvt<F>(dpl), dist);
+        }
         const auto hit = cell & (dist < S(0));
         const auto first = hit & (dist < bd0), second = hit & !(dist < bd0) & (dist < bd1);
         bd1 = sel(first, bd0, sel(second, dist, bd1)); bq1 = sel3(first, bq0, sel3(second, q, bq1));
@@ -701,7 +746,7 @@ template <typename F> TGR_RDEV void row_acc(F* R, V3<F> wl, V3<F> wa, V3<F> arm,
 template <typename F> struct RHess { F D[3][6]; F O10[6], O20[6], O21[6]; };
 template <typename F> TGR_RDEV F* hess_off(RHess<F>& H, int a, int b) { return (a == 0 && b == 1) ? H.O10 : ((a == 0 && b == 2) ? H.O20 : H.O21); }
 
-template <int PAGE, int C, typename F>
+template <int MODEL, int PAGE, int C, typename F>
 TGR_RDEV void hess_add_slot(RHess<F>& H, const DofC<F>& d, const RContact<F>& c, const RCone<F>& o) {
   typedef typename LaneTraits<F>::S S;
   if (!any_slot<C>(c.active)) return;
@@ -710,7 +755,7 @@ TGR_RDEV void hess_add_slot(RHess<F>& H, const DofC<F>& d, const RContact<F>& c,
   s.a1 = bcast<C>(o.a1); s.a2 = bcast<C>(o.a2); s.b1 = bcast<C>(o.b1); s.b2 = bcast<C>(o.b2);
   const bool cone = any_slot<C>(o.cg != S(0));
   if (cone) { s.cg = bcast<C>(o.cg); s.cw = bcast<C>(o.cw); s.gl = bcast3<C>(o.gl); s.ga = bcast3<C>(o.ga); s.wl = bcast3<C>(o.wl); s.wa = bcast3<C>(o.wa); }
-  constexpr int A = slot_bar_a(PAGE, C), Bb = slot_bar_b(PAGE, C);
+  constexpr int A = slot_bar_a<MODEL>(PAGE, C), Bb = slot_bar_b<MODEL>(PAGE, C);
   static_assert(Bb >= 0, "slot without a body");
   V3<F> ul, ua, wl, wa;
   dof_col(d, s.rB, ul, ua);
@@ -778,23 +823,28 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
 // constraint wrench on bar b from the neighbour sums of the slot lanes (P*: pairsum over lanes 2j, 2j+1; *B: as body B, *A: as body A of
 // a pair slot).  Pairs (A, B): lanes 6,7 = (0,1); 8,9 = (0,2); 10,11 = (1,2).  MODEL 1: bar b's cylinder slot on lane 12 + b (no neighbour).
 template <int L, typename F> TGR_RDEV V3<F> bcast3v(V3<F> a) { return mk<F>(bcast<L>(a.x), bcast<L>(a.y), bcast<L>(a.z)); }
+// MODEL 0: the third slot of pair (0,1) / (0,2) / (1,2) sits alone on lane 12 / 13 / 14; `third`: does any environment of the wavefront use one?
 template <int MODEL, typename K, typename F>
-TGR_RDEV void bar_sum(int b, V3<F> PfB, V3<F> PtB, V3<F> PtA, K PkB, K PkA, V3<F> fB, V3<F> tB, K tauB, V3<F>& f, V3<F>& t, K& tax) {
+TGR_RDEV void bar_sum(int b, V3<F> PfB, V3<F> PtB, V3<F> PtA, K PkB, K PkA, V3<F> fB, V3<F> tB, V3<F> tA, K tauB, K tauA, bool third, V3<F>& f,
+                      V3<F>& t, K& tax) {
   if (b == 0) {
     f = (bcast3v<0>(PfB) - bcast3v<6>(PfB)) - bcast3v<8>(PfB);
     t = (bcast3v<0>(PtB) - bcast3v<6>(PtA)) - bcast3v<8>(PtA);
     tax = (bcast<0>(PkB) - bcast<6>(PkA)) - bcast<8>(PkA);
     if (MODEL) { f = f + bcast3v<12>(fB); t = t + bcast3v<12>(tB); tax = tax + bcast<12>(tauB); }
+    else if (third) { f = (f - bcast3v<12>(fB)) - bcast3v<13>(fB); t = (t - bcast3v<12>(tA)) - bcast3v<13>(tA); tax = (tax - bcast<12>(tauA)) - bcast<13>(tauA); }
   } else if (b == 1) {
     f = (bcast3v<2>(PfB) + bcast3v<6>(PfB)) - bcast3v<10>(PfB);
     t = (bcast3v<2>(PtB) + bcast3v<6>(PtB)) - bcast3v<10>(PtA);
     tax = (bcast<2>(PkB) + bcast<6>(PkB)) - bcast<10>(PkA);
     if (MODEL) { f = f + bcast3v<13>(fB); t = t + bcast3v<13>(tB); tax = tax + bcast<13>(tauB); }
+    else if (third) { f = (f + bcast3v<12>(fB)) - bcast3v<14>(fB); t = (t + bcast3v<12>(tB)) - bcast3v<14>(tA); tax = (tax + bcast<12>(tauB)) - bcast<14>(tauA); }
   } else {
     f = (bcast3v<4>(PfB) + bcast3v<8>(PfB)) + bcast3v<10>(PfB);
     t = (bcast3v<4>(PtB) + bcast3v<8>(PtB)) + bcast3v<10>(PtB);
     tax = (bcast<4>(PkB) + bcast<8>(PkB)) + bcast<10>(PkB);
     if (MODEL) { f = f + bcast3v<14>(fB); t = t + bcast3v<14>(tB); tax = tax + bcast<14>(tauB); }
+    else if (third) { f = (f + bcast3v<13>(fB)) + bcast3v<14>(fB); t = (t + bcast3v<13>(tB)) + bcast3v<14>(tB); tax = (tax + bcast<13>(tauB)) + bcast<14>(tauB); }
   }
 }
 
@@ -820,12 +870,15 @@ constexpr int lidx(int i) { return i; }
 constexpr int hidx(int i) { return (i % 10) * 16 + i / 10; }
 constexpr int lidx(int i) { return (i % 10) * 16 + i / 10; }
 #endif
-template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; Slab<F> hd; Slab<F> lp; };
+// dbg: optional sub-step trace of this environment (null in production; tgr_bind_substep_trace): word s = contact slots active in sub-step s
+// (bits 0..15 page 0, 16..21 page 1) | (Newton iterations the environment itself needed so far, mod 256) << 22 | (left at the cap or stalled) << 30 | (stalled) << 31
+constexpr int TRACE_WORDS = 24;
+template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; Slab<F> hd; Slab<F> lp; unsigned* dbg; };
 
 // `LAST`: what only the last sub-step of a control period records (lagged kinematics, tendon lengths, contact wrench).
 // K / PK: lane and scalar type of the pose, the kinematics, the tendon geometry and the smooth forces; F / P: of the rest.
 template <typename K, typename F, typename SK, typename S, int MODEL, bool LAST>
-TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, F>& M, RLag<K, F>& lag) {
+TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, F>& M, RLag<K, F>& lag, int sidx = 0) {
   typedef typename LaneTraits<F>::I I;
   typedef typename LaneTraits<F>::B B;
   const F zero = F(S(0));
@@ -913,7 +966,9 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       // lanes 0, 1, 2 (trisum) and a bar's wrench is two broadcasts of them -- no masked sum over the row.
       // the force sum only feeds linear accelerations (fp32 resolves them); the torque sum decides the spin about the bar's own axis
       const K ften = sel(Ro.is_ten, f, kzero);
-      const V3<F> Sfu = mk<F>(trisum(cvt<F>(ften * u.x)), trisum(cvt<F>(ften * u.y)), trisum(cvt<F>(ften * u.z)));
+      // (uneven-ground model: tendon forces of 1e3 N that cancel to a few N per bar -- their sum, too, is formed in K)
+      typedef typename std::conditional<MODEL != 0, K, F>::type FS;
+      const V3<FS> Sfu = mk<FS>(trisum(cvt<FS>(ften * u.x)), trisum(cvt<FS>(ften * u.y)), trisum(cvt<FS>(ften * u.z)));
       const V3<K> Sma = mk<K>(trisum(ften * ma.x), trisum(ften * ma.y), trisum(ften * ma.z));
       const V3<K> Smb = mk<K>(trisum(ften * mb.x), trisum(ften * mb.y), trisum(ften * mb.z));
       static_for<3>([&](auto bc_) {
@@ -982,17 +1037,19 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       const auto is_floor = MODEL ? (Ro.is_cap | Ro.is_rod) : Ro.is_cap;
       // bar pairs (every lane runs the routine; only pair lanes keep the outcome)
       const V3<F> pxA = cvt3<F>(ld3(M.kd, KX + 3 * ja_)), pzA = ld3(M.fd, FEZ + 3 * ja_), pxB = cvt3<F>(kxc), pzB = cvt3<F>(kzc);
-      RContact<F> p0, p1;
+      RContact<F> p0, p1, p2;
       TGR_SCHED();
-      bar_pair_contacts(P, pxA, pzA, pxB, pzB, Ro.is_pair, p0, p1, dropped);
+      bar_pair_contacts(P, pxA, pzA, pxB, pzB, Ro.is_pair | Ro.is_pair2, p0, p1, p2, dropped);
       TGR_SCHED();
       const auto s0 = Ro.sub == 0;
-      c.n = sel3(is_floor, fn, sel3(s0, p0.n, p1.n));
-      c.rA = sel3(is_floor, z3, sel3(s0, p0.rA, p1.rA));
-      c.rB = sel3(is_floor, frB, sel3(s0, p0.rB, p1.rB));
-      c.c0 = sel(is_floor, cc, sel(s0, p0.c0, p1.c0));
-      c.Dn = sel(is_floor, dn, sel(s0, p0.Dn, p1.Dn));
-      c.active = sel(is_floor, fhit, sel(Ro.is_pair, sel(s0, p0.active, p1.active), false));
+      const auto s2 = Ro.is_pair2;
+      c.n = sel3(is_floor, fn, sel3(s2, p2.n, sel3(s0, p0.n, p1.n)));
+      c.rA = sel3(is_floor, z3, sel3(s2, p2.rA, sel3(s0, p0.rA, p1.rA)));
+      c.rB = sel3(is_floor, frB, sel3(s2, p2.rB, sel3(s0, p0.rB, p1.rB)));
+      c.c0 = sel(is_floor, cc, sel(s2, p2.c0, sel(s0, p0.c0, p1.c0)));
+      c.Dn = sel(is_floor, dn, sel(s2, p2.Dn, sel(s0, p0.Dn, p1.Dn)));
+      c.active = sel(is_floor, fhit, sel(s2, p2.active, sel(Ro.is_pair, sel(s0, p0.active, p1.active), false)));
+      if (MODEL) dropped = dropped + sel(p2.active, F(S(1)), zero);  // (lanes 12..14 carry the rods there: the second other contact has no slot)
       dropped = sel(Ro.is_pair & s0, dropped, zero);
       // The torque of my contact force about the OWN AXIS of each of its bars is the one place where fp32 is not enough (1e-6 N m inside
       // 10 N m cross products; the bar's inertia about that axis is 0.0038 kg m^2):  z . (r x f + t) = f . (z x r) + t . z, with the
@@ -1049,6 +1106,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     st3(M.cd, CJL0, jl0); st3(M.cd, CJA0, ja0);
   }
   auto conv = !any_contact;
+  auto stall = conv & !conv;  // rows whose line search found no descent at working precision
   F bar_force = zero;
   int n_it = 0, n_ls = 0;
   TGR_FENCE();
@@ -1099,7 +1157,9 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     const V3<F> PfB = mk<F>(pairsum(fB.x), pairsum(fB.y), pairsum(fB.z)), PtB = mk<F>(pairsum(tB.x), pairsum(tB.y), pairsum(tB.z)),
                 PtA = mk<F>(pairsum(tA.x), pairsum(tA.y), pairsum(tA.z));
     const K PkB = pairsum(tauB), PkA = pairsum(tauA);
+    const bool third = !MODEL && any_slots<0x7000u>(cs.active);
     K gn = kzero;  // g^T M^-1 g
+    F dn = zero;   // d^T M d: the scale of the forces the gradient is the difference of
     F gd[3];
     static_for<3>([&](auto bc) {
       constexpr int b = decltype(bc)::value;
@@ -1109,10 +1169,12 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       TGR_SCHED();
       V3<F> fcl, fca;
       K tax;
-      bar_sum<MODEL>(b, PfB, PtB, PtA, PkB, PkA, fB, tB, tauB, fcl, fca, tax);
+      bar_sum<MODEL>(b, PfB, PtB, PtA, PkB, PkA, fB, tB, tA, tauB, tauA, third, fcl, fca, tax);
       st3(M.fd, FFCL + 3 * b, fcl); st3(M.fd, FFCA + 3 * b, fca); M.kd.st(KTAX + b, tax);
       const V3<F> gl = P.mass * dl - fcl;
-      V3<F> ga = inertia_mul(P, ezb, da) - fca;
+      const V3<F> Ida = inertia_mul(P, ezb, da);
+      V3<F> ga = Ida - fca;
+      dn = dn + P.mass * dot(dl, dl) + dot(Ida, da);
       // M-norm of the residual: force and transverse torque in F, the axial torque from K
       const K gax = PK.Izz * dot(kez, cvt3<K>(da)) - tax;
       const F gz = dot(ezb, ga);
@@ -1120,8 +1182,10 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       ga = ga + (cvt<F>(gax) - gz) * ezb;  // the direction is solved for the same axial residual the test looks at
       gd[b] = sel(Ro.is_dof, sel(Ro.is_ang, pick_comp(Ro.k, ga), pick_comp(Ro.k, gl)), zero);
     });
-    if (LAST) bar_force = rowsum(sel(Ro.is_pair, sqrt_(dot(o.fl, o.fl)), zero));
-    conv = conv | !(gn >= PK.tol * PK.tol);
+    if (LAST) bar_force = rowsum(sel(Ro.is_pair | Ro.is_pair2, sqrt_(dot(o.fl, o.fl)), zero));
+    // converged: the M^-1-norm of the gradient is below the tolerance -- or below what the arithmetic resolves of it: the gradient is the
+    // difference of inertial and contact forces of size sqrt(d^T M d) (a hard contact onset: 1e3 sqrt(kg) m/s^2), each known to a few ulp
+    conv = conv | !(gn >= PK.tol * PK.tol + (PK.rtol * PK.rtol) * cvt<K>(dn));
 #ifdef TGR_ROW_TRACE
     std::fprintf(stderr, "it %d gn %.3e conv %d\n", it, (double)gn.v[0], (int)conv.v[0]);
 #endif
@@ -1140,11 +1204,11 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       H.D[b][0] = lin.x; H.D[b][1] = lin.y; H.D[b][2] = lin.z; H.D[b][3] = ang.x; H.D[b][4] = ang.y; H.D[b][5] = ang.z;
     }
     for (int i = 0; i < 6; i++) { H.O10[i] = zero; H.O20[i] = zero; H.O21[i] = zero; }
-    static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<0, decltype(cc)::value>(H, dc, cs, o); });
-    if (page1) static_for<6>([&](auto cc) { hess_add_slot<1, decltype(cc)::value>(H, dc, cs1, o1); });
+    static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<MODEL, 0, decltype(cc)::value>(H, dc, cs, o); });
+    if (page1) static_for<6>([&](auto cc) { hess_add_slot<MODEL, 1, decltype(cc)::value>(H, dc, cs1, o1); });
     // which bar pairs does any environment of the wavefront couple?  (uniform: lets the factorisation skip zero blocks)
-    const bool cp0 = any_slot<6>(cs.active) || any_slot<7>(cs.active), cp1 = any_slot<8>(cs.active) || any_slot<9>(cs.active),
-               cp2 = any_slot<10>(cs.active) || any_slot<11>(cs.active);
+    const bool cp0 = any_slots<MODEL ? 0x00c0u : 0x10c0u>(cs.active), cp1 = any_slots<MODEL ? 0x0300u : 0x2300u>(cs.active),
+               cp2 = any_slots<MODEL ? 0x0c00u : 0x4c00u>(cs.active);
     TGR_PHASE(6);
     // ---- direction p = -H^-1 g
     F pr[3][6], gHg;
@@ -1198,6 +1262,18 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       if (!any_lane(!ls_done) || k + 1 >= P.ls_iter) break;
     }
     TGR_CENSUS(11);
+    {
+      // every trial step pointed uphill although the Newton decrement promises descent: the slope at the iterate is below what the
+      // arithmetic resolves (hard contact onsets: residuals of 1e2..1e3 m/s^2 in fp32).  The iterate stays; the row is done, and counted
+      // with the unconverged ones.
+      const auto stalled = !ls_done & (hi > S(0)) & !(lo > S(0));
+      alpha = sel(stalled, zero, alpha);
+      stall = stall | stalled;
+      conv = conv | stalled;
+    }
+#ifdef TGR_ROW_TRACE
+    std::fprintf(stderr, "      d0 %.3e alpha %.6f lo %.4f hi %.4f g1 %.3e g2 %.3e ls_done %d n_ls %d\n", (double)d0.v[0], (double)alpha.v[0], (double)lo.v[0], (double)hi.v[0], (double)g1.v[0], (double)g2.v[0], (int)ls_done.v[0], n_ls);
+#endif
     for (int b = 0; b < 3; b++) {
       st3(M.fd, FDL + 3 * b, ld3(M.fd, FDL + 3 * b) + alpha * pl[b]);
       st3(M.fd, FDA + 3 * b, ld3(M.fd, FDA + 3 * b) + alpha * pa[b]);
@@ -1205,11 +1281,20 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     st3(M.cd, CDLA, ld3(M.cd, CDLA) + alpha * plA); st3(M.cd, CDAA, ld3(M.cd, CDAA) + alpha * paA);
     st3(M.cd, CDLB, ld3(M.cd, CDLB) + alpha * plB); st3(M.cd, CDAB, ld3(M.cd, CDAB) + alpha * paB);
     TGR_FENCE();
+    if (!any_lane(!conv)) break;  // (only stalled rows were left: their iterate has not moved, the wrench above is the one of the iterate)
   }
   TGR_PHASE(8);
   TGR_FENCE();
   lag.n_it += n_it; lag.n_ls += n_ls;
-  lag.n_unconv = lag.n_unconv + sel(conv, zero, F(S(1)));
+  lag.n_unconv = lag.n_unconv + sel(conv & !stall, zero, F(S(1)));
+  if (M.dbg && sidx < TRACE_WORDS) {  // (every lane of the row stores the same word)
+    unsigned w = row_bits(M.cd.ld(CACT) != S(0));
+    if (MODEL) w |= (row_bits(M.cd.ld(C_SLAB + CACT) != S(0)) & 0x3fu) << 16;
+    w |= ((unsigned)(int)lane0(lag.n_own) & 0xffu) << 22;
+    w |= lane0(conv & !stall) ? 0u : 1u << 30;
+    w |= lane0(stall) ? 1u << 31 : 0u;
+    M.dbg[sidx] = w;
+  }
   if (LAST) {
     F sq = zero, cfrc_max = zero;
     for (int b = 0; b < 3; b++) {
@@ -1225,61 +1310,78 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     // (qacc of the last forward pass -- what mujoco keeps as qacc_warmstart -- is a0 + d: both stay in the slabs, the export adds them)
   }
   // ---- implicitfast: (M + h sum_t b_t J_t J_t^T) a_new = F_smooth + F_constraint  (Woodbury over the nine tendons, tendon role).
-  V3<F> yl[3], ya[3];    // the damping correction
+  // W: the arithmetic of this stage.  F for the flat-floor model; K for the uneven-ground model, whose nine tendons carry 1e4 N/m and
+  // 1e3 N s/m (uneven xml:38): accelerations of 1e3 m/s^2 that cancel to the few m/s^2 the robot really does -- in F that cancellation left
+  // 1e-4 m/s^2 of rounding in every sub-step, 0.4 % of tr_env env-steps outside the 1e-4 bound on qvel with no contact flip to blame.
+#ifndef TGR_IMPLICIT_K
+#define TGR_IMPLICIT_K 1
+#endif
+  constexpr bool WK = (MODEL != 0) && TGR_IMPLICIT_K;
+  typedef typename std::conditional<WK, K, F>::type W;
+  typedef typename std::conditional<WK, SK, S>::type SW;
+  const RParams<SW>& PW = pick_params<WK>(PK, P);
+  const SW imw = SW(1) / PW.mass;
+  const W wzero = W(SW(0));
+  const V3<W> wz3 = mk<W>(wzero, wzero, wzero);
+  V3<W> yl[3], ya[3];    // the damping correction
   {
     const Roles<F> Ro = lane_roles<F, MODEL>();
     // acceleration before the damping correction, at my tendon's two bars (lane-indexed slab reads)
-    auto accel = [&](I bar, V3<F>& al_, V3<F>& aa_) {
+    auto accel = [&](I bar, V3<W>& al_, V3<W>& aa_) {
       const V3<K> kz = ld3(M.kd, KEZ + 3 * bar);
       const V3<K> kf = cvt3<K>(ld3(M.fd, FFCA + 3 * bar));
       const V3<K> yak = (SK(1) / PK.Ixx) * kf + (M.kd.ld(KTAX + bar) * (SK(1) / PK.Izz) - dot(kz, kf) * (SK(1) / PK.Ixx)) * kz;
-      al_ = cvt3<F>(ld3(M.kd, KL0 + 3 * bar)) + im * ld3(M.fd, FFCL + 3 * bar);
-      aa_ = cvt3<F>(ld3(M.kd, KA0 + 3 * bar) + yak);
+      if (WK) al_ = cvt3<W>(ld3(M.kd, KL0 + 3 * bar) + imk * cvt3<K>(ld3(M.fd, FFCL + 3 * bar)));
+      else al_ = cvt3<W>(cvt3<F>(ld3(M.kd, KL0 + 3 * bar)) + im * ld3(M.fd, FFCL + 3 * bar));
+      aa_ = cvt3<W>(ld3(M.kd, KA0 + 3 * bar) + yak);
     };
-    V3<F> flA, faA, flB, faB;
+    V3<W> flA, faA, flB, faB;
     accel(Ro.ba, flA, faA);
     TGR_SCHED();
     accel(Ro.bb, flB, faB);
     TGR_SCHED();
     // (lanes 9.. own no tendon: what they read here is the solver's history or never written -- zero, not garbage, enters the row sums)
-    const F sc = sqrt_(P.h * sel(Ro.is_ten, M.td.ld(TDAMP), zero));
-    const V3<F> us = sc * sel3(Ro.is_ten, ld3(M.td, TU), z3), mas = sc * sel3(Ro.is_ten, ld3(M.td, TMA), z3), mbs = sc * sel3(Ro.is_ten, ld3(M.td, TMB), z3);
-    const V3<F> was = inv_inertia(P, ld3(M.fd, FEZ + 3 * Ro.ba), mas), wbs = inv_inertia(P, ld3(M.fd, FEZ + 3 * Ro.bb), mbs);
-    F zt = dot(us, flB - flA) + dot(mbs, faB) - dot(mas, faA);
+    const W sc = sqrt_(PW.h * cvt<W>(sel(Ro.is_ten, M.td.ld(TDAMP), zero)));
+    const V3<W> us = sc * cvt3<W>(sel3(Ro.is_ten, ld3(M.td, TU), z3)), mas = sc * cvt3<W>(sel3(Ro.is_ten, ld3(M.td, TMA), z3)),
+                mbs = sc * cvt3<W>(sel3(Ro.is_ten, ld3(M.td, TMB), z3));
+    auto ezw = [&](I bar) { return WK ? cvt3<W>(ld3(M.kd, KEZ + 3 * bar)) : cvt3<W>(ld3(M.fd, FEZ + 3 * bar)); };
+    const V3<W> was = inv_inertia(PW, ezw(Ro.ba), mas), wbs = inv_inertia(PW, ezw(Ro.bb), mbs);
+    W zt = dot(us, flB - flA) + dot(mbs, faB) - dot(mas, faA);
     TGR_SCHED();
     TGR_CENSUS(13);
-    F Sr[9], il9[9];
+    W Sr[9], il9[9];
     static_for<9>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
       constexpr int as = ten_ba(s), bs = ten_bb(s);
-      const V3<F> u2 = bcast3<s>(us), wa2 = bcast3<s>(was), wb2 = bcast3<s>(wbs);
-      const F uu = im * dot(us, u2);
-      F v = sel(Ro.r == s, F(S(1)), zero);
-      v = v + sel(Ro.ba == as, uu + dot(mas, wa2), zero);
-      v = v + sel(Ro.bb == bs, uu + dot(mbs, wb2), zero);
-      v = v - sel(Ro.ba == bs, uu + dot(mas, wb2), zero);
-      v = v - sel(Ro.bb == as, uu + dot(mbs, wa2), zero);
-      Sr[s] = sel(Ro.is_ten, v, zero);
+      const V3<W> u2 = bcast3<s>(us), wa2 = bcast3<s>(was), wb2 = bcast3<s>(wbs);
+      const W uu = imw * dot(us, u2);
+      W v = sel(Ro.r == s, W(SW(1)), wzero);
+      v = v + sel(Ro.ba == as, uu + dot(mas, wa2), wzero);
+      v = v + sel(Ro.bb == bs, uu + dot(mbs, wb2), wzero);
+      v = v - sel(Ro.ba == bs, uu + dot(mas, wb2), wzero);
+      v = v - sel(Ro.bb == as, uu + dot(mbs, wa2), wzero);
+      Sr[s] = sel(Ro.is_ten, v, wzero);
     });
     TGR_SCHED();
     TGR_CENSUS(14);
     rchol<9>(Sr, il9);
     TGR_SCHED();
-    F zr[9];
+    W zr[9];
     rfwd<9>(Sr, il9, zt, zr);
     rbwd_rep<9>(Sr, il9, zr, zr);
-    const F zd = rscatter<9>(zr);  // lane t: its tendon's multiplier (zero on the lanes without a tendon)
+    const W zd = rscatter<9>(zr);  // lane t: its tendon's multiplier (zero on the lanes without a tendon)
     TGR_CENSUS(15);
     {
       // (zd is zero on the lanes without a tendon; classes t mod 3 as in the tendon stage: bar A of a tendon gets +, bar B -)
-      const F zi = zd * im;
-      const V3<F> Su = mk<F>(trisum(zi * us.x), trisum(zi * us.y), trisum(zi * us.z));
-      const V3<F> Swa = mk<F>(trisum(zd * was.x), trisum(zd * was.y), trisum(zd * was.z));
-      const V3<F> Swb = mk<F>(trisum(zd * wbs.x), trisum(zd * wbs.y), trisum(zd * wbs.z));
+      const W zi = zd * imw;
+      const V3<W> Su = mk<W>(trisum(zi * us.x), trisum(zi * us.y), trisum(zi * us.z));
+      const V3<W> Swa = mk<W>(trisum(zd * was.x), trisum(zd * was.y), trisum(zd * was.z));
+      const V3<W> Swb = mk<W>(trisum(zd * wbs.x), trisum(zd * wbs.y), trisum(zd * wbs.z));
       yl[0] = bcast3v<0>(Su) + bcast3v<1>(Su);     ya[0] = bcast3v<0>(Swa) + bcast3v<1>(Swa);
       yl[1] = bcast3v<2>(Su) - bcast3v<1>(Su);     ya[1] = bcast3v<2>(Swa) - bcast3v<1>(Swb);
       yl[2] = -(bcast3v<0>(Su) + bcast3v<2>(Su));  ya[2] = -(bcast3v<0>(Swb) + bcast3v<2>(Swb));
     }
+    (void)wz3;
   }
   TGR_PHASE(9);
   // ---- advance: v += h a ; x += h v ; q <- exp(h w / 2) * q   (world-frame w: left multiplication)
@@ -1288,7 +1390,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     const V3<K> kz = ld3(M.kd, KEZ + 3 * b);
     const V3<K> kf = cvt3<K>(ld3(M.fd, FFCA + 3 * b));
     const V3<K> yak = (SK(1) / PK.Ixx) * kf + (M.kd.ld(KTAX + b) * (SK(1) / PK.Izz) - dot(kz, kf) * (SK(1) / PK.Ixx)) * kz;
-    const V3<K> vk = cvt3<K>(ld3(M.fd, FV + 3 * b)) + PK.h * (ld3(M.kd, KL0 + 3 * b) + cvt3<K>(im * ld3(M.fd, FFCL + 3 * b) + yl[b]));
+    const V3<K> vk = cvt3<K>(ld3(M.fd, FV + 3 * b)) + PK.h * (WK ? (ld3(M.kd, KL0 + 3 * b) + imk * cvt3<K>(ld3(M.fd, FFCL + 3 * b))) + cvt3<K>(yl[b])
+                                                                        : ld3(M.kd, KL0 + 3 * b) + cvt3<K>(cvt3<W>(im * ld3(M.fd, FFCL + 3 * b)) + yl[b]));
     const V3<K> wk = cvt3<K>(ld3(M.fd, FW + 3 * b)) + PK.h * ((ld3(M.kd, KA0 + 3 * b) + yak) + cvt3<K>(ya[b]));
     st3(M.fd, FV + 3 * b, cvt3<F>(vk));
     st3(M.fd, FW + 3 * b, cvt3<F>(wk));

@@ -46,6 +46,8 @@ template <typename T> struct EnvCfg {
   double waypt_range[2], waypt_angle_range[2];
   double min_heading, max_heading, ten_mean, ten_std, ten_max, ten_min, reset_noise;
   unsigned long long seed, first_env_id;
+  // reset streams (tgr_config.reset_stream_envs): envs per class (0: one pool per handle), donor lanes per class
+  int stream_envs, stream_donors;
 };
 
 template <typename T> struct KArgs {
@@ -54,15 +56,22 @@ template <typename T> struct KArgs {
   int n, m;  // live envs, total lanes (live + donors)
   int slow_e;  // row kernels: donor rows from this index on (a multiple of 4) settle in half quanta -- see step_kernel_row; >= m: none
   T* st; int* ist; T* ring;
+  double* hp;  // fp32 handles stepped by the row kernels: qpos in fp64, [21][m] (the pose is fp64 inside the kernels; rounding it to fp32 between
+               // env-steps alone moved a cap across dist = 0 in 0.1..0.4 % of env-steps).  null: the pose lives in st only
   const float* actions;
   T* obs; T* reward; uint8_t* terminated; uint8_t* truncated; T* terminal_obs; T* info;
   int* list_count; int* list; int* rlist;  // envs to (re)settle / ready donors
+  int* list_ep;   // reset streams: the stream episode a starved env is to be settled with (parallel to list), or null
+  int* cls;       // reset streams: per class {next episode to start settling, next episode to hand out}
+  int* holder;    // reset streams: per class, which donor lane holds episode (ep % stream_table)
+  int stream_table;
   uint8_t* doneflag;
   T* dobs;  // reset observations of the donors [m-n][D]
   unsigned long long* counters;
   int auto_reset;
   T* obs_reset;  // where the settle kernel writes reset observations ([N][D]) or null
   T* obs_clean;  // info["real_observation"] of tr_env.py:507: the noise-free observation of the step ([N][D]) or null
+  unsigned* dbg;  // row kernels: sub-step trace of the live envs ([N][row::TRACE_WORDS], tgr_bind_substep_trace) or null
 };
 
 __constant__ double c_qpos0[21] = {0.08369179, -0.28792231, 0.24830847, -0.49145555, 0.7539914, -0.27511722, -0.33805166,
@@ -426,9 +435,14 @@ TGR_DEV StepOut<T> env_epilogue(const Params<T>& P, const EnvCfg<T>& E, const Si
 //                 donor state and the donor starts over.  Nothing ever waits for a settle.
 enum : int { PH_LIVE = -1, PH_READY = 0, PH_INIT = -2 };  // > 0: settle periods still to run
 
+// RNG key of a lane's episodes.  Live lane: the env's global id.  Donor lane: its own key -- or, with reset streams, the key of its
+// CLASS (a block of stream_envs consecutive global env ids and the donor lanes that serve it): the episodes of a class form one stream
+// (class key, 0), (class key, 1), ... handed out in order, so that what an env restarts with depends on its class alone, not on the
+// sharding, the donor lane that happened to settle the episode, or the timing.
 template <typename T> TGR_DEV unsigned long long lane_key(const EnvCfg<T>& E, int n, int lane) {
-  return lane < n ? E.first_env_id + (unsigned long long)lane
-                  : (1ull << 62) + E.first_env_id * 8ull + (unsigned long long)(lane - n);
+  if (lane < n) return E.first_env_id + (unsigned long long)lane;
+  if (E.stream_envs > 0) return (1ull << 62) + (1ull << 40) + E.first_env_id / (unsigned long long)E.stream_envs + (unsigned long long)((lane - n) / E.stream_donors);
+  return (1ull << 62) + E.first_env_id * 8ull + (unsigned long long)(lane - n);
 }
 
 // start pose of an episode: yaw-randomised table pose, zero velocity, random tendon targets
@@ -776,6 +790,7 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
 #define TGR_ROW_ENVS 4
 #endif
 template <typename T, int MODEL> constexpr int row_envs() { return TGR_ROW_ENVS; }
+static_assert(TGR_ROW_ENVS % 4 == 0 && row::ROW == 16, "a row (16 lanes) must lie inside one wavefront: its LDS slabs are not guarded by barriers");
 // the flat-floor model keeps no activations: its K slab ends before KACT
 template <int MODEL> constexpr int k_slab() { return MODEL ? row::K_SLAB : row::KACT; }
 // wavefronts per SIMD the row kernels are compiled for (register budget 512 / waves): two for fp32 handles -- the donor rows of a
@@ -796,9 +811,10 @@ template <typename T, typename TK, int MODEL> struct RowShared {
   T td[NE * row::T_SLAB * 16];
   T cd[NE * row::C_SLAB * PAGES * 16];  // (after the last sub-step: the row's observation line, <= 49 values)
 };
-template <typename T, typename TK, int MODEL> TGR_DEV row::RMem<TK, T> row_mem(RowShared<T, TK, MODEL>& sh, int slot, int r) {
+template <typename T, typename TK, int MODEL> TGR_DEV row::RMem<TK, T> row_mem(RowShared<T, TK, MODEL>& sh, int slot, int r, unsigned* dbg = nullptr) {
   constexpr int PAGES = row::n_pages<MODEL>();
   row::RMem<TK, T> M;
+  M.dbg = dbg;
   M.kd = row::Slab<TK>{sh.kd + slot * k_slab<MODEL>(), 1, 0};
   M.fd = row::Slab<T>{sh.fd + slot * row::F_SLAB, 1, 0};
   M.td = row::Slab<T>{sh.td + slot * row::T_SLAB * 16, 16, r};
@@ -826,14 +842,14 @@ template <typename T, typename TK, int MODEL> TGR_DEV void row_import(const Sim<
 #pragma unroll
   for (int i = 0; i < row::H_SLAB; i++) M.hd.st(row::hidx(i), T(0));
 }
-template <typename T, typename TK, int MODEL> TGR_DEV void row_load(const T* st, int m, int e, const row::RMem<TK, T>& M) {
+template <typename T, typename TK, int MODEL> TGR_DEV void row_load(const T* st, const double* hp, int m, int e, const row::RMem<TK, T>& M) {
 #pragma unroll
   for (int b = 0; b < 3; b++) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) M.kd.st(row::KX + 3 * b + i, TK(st[(F_QPOS + 7 * b + i) * m + e]));
+    for (int i = 0; i < 3; i++) M.kd.st(row::KX + 3 * b + i, hp ? TK(hp[(7 * b + i) * m + e]) : TK(st[(F_QPOS + 7 * b + i) * m + e]));
     TK q[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) q[i] = TK(st[(F_QPOS + 7 * b + 3 + i) * m + e]);
+    for (int i = 0; i < 4; i++) q[i] = hp ? TK(hp[(7 * b + 3 + i) * m + e]) : TK(st[(F_QPOS + 7 * b + 3 + i) * m + e]);
     row::normalize_quat(q);
 #pragma unroll
     for (int i = 0; i < 4; i++) M.kd.st(row::KQ + 4 * b + i, q[i]);
@@ -874,6 +890,18 @@ TGR_DEV void row_export(const row::RMem<TK, T>& M, const row::RLag<TK, T>& rl, S
   for (int i = 0; i < 9; i++) lag.tenL[i] = M.lp.ld(row::lidx(row::LPT + i));
   lag.cfrc_absmax = rl.cfrc_absmax; lag.cfrc_clip_sq = rl.cfrc_clip_sq; lag.bar_contact = rl.bar_contact;
   lag.overflow = (int)rl.overflow; lag.n_it = rl.n_it; lag.n_ls = rl.n_ls; lag.n_unconv = (int)rl.n_unconv;
+}
+// the pose of the row's environment at full precision -> hp (called by the lane that owns the env's global stores, next to store_sim)
+template <typename T, typename TK> TGR_DEV void row_store_pose(const row::RMem<TK, T>& M, double* hp, int m, int e) {
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) hp[(7 * b + i) * m + e] = (double)M.kd.ld(row::KX + 3 * b + i);
+    TK q[4] = {M.kd.ld(row::KQ + 4 * b), M.kd.ld(row::KQ + 4 * b + 1), M.kd.ld(row::KQ + 4 * b + 2), M.kd.ld(row::KQ + 4 * b + 3)};
+    row::normalize_quat(q);
+#pragma unroll
+    for (int i = 0; i < 4; i++) hp[(7 * b + 3 + i) * m + e] = (double)q[i];
+  }
 }
 template <typename T, typename TK> TGR_DEV void row_lag_init(row::RLag<TK, T>& rl) {
   // (cfrc_absmax, cfrc_clip_sq, bar_contact, overflow are assigned by the last sub-step, not accumulated: nothing to initialise)
@@ -916,7 +944,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   row::RLag<TK, T> rl;
   row_lag_init<T, TK>(rl);
   if (__any(active)) {  // (a wavefront of idle donor rows has nothing to do)
-    const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
+    const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r, (k.dbg && live) ? k.dbg + (size_t)e * row::TRACE_WORDS : nullptr);
     int episode = k.ist[I_EPISODE * m + e];
     if (donor_run && phase == PH_INIT) {
       Sim<T> S0;
@@ -925,7 +953,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
       phase = total;
       if (valid && r == 0) { k.ist[I_SRC * m + e] = e; k.ist[I_SRCEP * m + e] = episode; k.ist[I_EPISODE * m + e] = episode + 1; }
     } else {
-      row_load<T, TK, MODEL>(k.st, m, e, M);
+      row_load<T, TK, MODEL>(k.st, k.hp, m, e, M);
     }
     if (live) {
 #pragma unroll
@@ -937,8 +965,8 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
     }
     row::store_role_consts<TK, T, TK, MODEL>(ra.PK, M.rd);
 #pragma unroll 1
-    for (int s = 0; s + 1 < nsub; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, M, rl);
-    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, M, rl);
+    for (int s = 0; s + 1 < nsub; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, M, rl, s);
+    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, M, rl, nsub - 1);
   }
   // Who this row is gets worked out a second time, from laundered thread and block numbers: carried through the twenty sub-steps in
   // registers it was spilled (a dozen dwords per lane: 6 MB of scratch stores per launch), recomputed it is ten instructions.
@@ -987,6 +1015,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
         if (w0) {
           V3<T> wb[3];
           store_sim(k.st, m, e, S, lag, wb);
+          if (k.hp) row_store_pose<T, TK>(M, k.hp, m, e);
           k.ist[I_PHASE * m + e] = phase;  // (a freshly set up row leaves PH_INIT here)
           k.ist[I_HALF * m + e] = 1;
           if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
@@ -996,6 +1025,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
       if (donor_run && w0) k.ist[I_HALF * m + e] = 0;
     }
     T* const orow = sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16);  // the contact slots are dead now
+    if (k.hp && active && w0) row_store_pose<T, TK>(M, k.hp, m, e);  // (before the observation line takes over the contact slab; kd stays)
     finish_lane<T, true>(k, S, lag, e, valid, live, active, w0, phase, total, orow, orow + 64);  // (orow: <= 49 values of the row's 480)
 #ifdef TGR_WAVE_TIMES
     if ((threadIdx.x & 63u) == 0) {
@@ -1003,8 +1033,11 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
       if (wv < 16384) { g_wave_times[4 * wv] = wt0; g_wave_times[4 * wv + 1] = wall_clock64(); g_wave_times[4 * wv + 2] = (unsigned long long)lag.n_it; g_wave_times[4 * wv + 3] = __popcll(__ballot(active && w0)); }
     }
 #endif
-    // the observation of a live env leaves through the row's tile line: lane 0 wrote it, the 16 lanes store it (LDS operations of one
-    // wavefront complete in order, so no barrier is needed)
+    // the observation of a live env leaves through the row's tile line: lane 0 wrote it, the 16 lanes store it.  A row never spans two
+    // wavefronts (static_assert below), and LDS operations of one wavefront complete in order; the fence keeps the compiler from moving
+    // the loads above lane 0's stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (live)
       for (int c = r; c < D; c += 16) k.obs[(size_t)e * D + c] = orow[c];
   }
@@ -1025,9 +1058,13 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   const int n = k.n, m = k.m;
   const EnvCfg<T>& E = k.E;
   const Params<T>& P = k.P;
-  const int episode = k.ist[I_EPISODE * m + e];
+  // reset streams: a live env that found its stream episode not settled yet settles it here itself -- same (class key, episode), same state
+  const int sep = k.list_ep ? k.list_ep[valid ? li : count - 1] : -1;
+  const int klane = sep >= 0 ? n + (e / E.stream_envs) * E.stream_donors : e;  // the lane whose key the episode is drawn under
+  const int episode = sep >= 0 ? sep : k.ist[I_EPISODE * m + e];
+  const unsigned long long key = lane_key(E, n, klane);
   Sim<T> S;
-  init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S, (double*)(sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16)));
+  init_episode(E, key, (unsigned long long)(unsigned)episode, S, (double*)(sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16)));
   const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
   row_import<T, TK, MODEL>(S, M);
   RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
@@ -1049,24 +1086,25 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
     row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, M, rl);
     row_export<T, TK, MODEL>(M, rl, S, lag);
     // the heading deque lives in global memory: one lane of the row pushes (the others would push the same value again)
-    if (w0) settle_period_done(P, E, lag, st, ring, step_num, reset_psi, ms, xy_prev, lane_key(E, n, e), (unsigned long long)(unsigned)episode);
+    if (w0) settle_period_done(P, E, lag, st, ring, step_num, reset_psi, ms, xy_prev, key, (unsigned long long)(unsigned)episode);
   }
   if (!w0) return;
   V3<T> wb[3];
   store_sim(k.st, m, e, S, lag, wb);
+  if (k.hp) row_store_pose<T, TK>(M, k.hp, m, e);
   store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
   store_modes(k.st, m, e, ms);
   ms.step_num = step_num;
-  k.ist[I_SRC * m + e] = e;
+  k.ist[I_SRC * m + e] = klane;
   k.ist[I_SRCEP * m + e] = episode;
-  k.ist[I_EPISODE * m + e] = episode + 1;
+  if (sep < 0) k.ist[I_EPISODE * m + e] = episode + 1;  // (a stream episode does not advance the env's own counter of explicit resets)
   k.ist[I_PHASE * m + e] = e < n ? PH_LIVE : PH_READY;
   atomicAdd(&k.counters[1], 1ull);
   if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
   const int D = E.obs_dim;
   T* orow = sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16);
   make_obs(P, E, S, lag, wb, ms, orow);
-  if (E.use_obs_noise) apply_obs_noise<T, true>(E, lane_key(E, n, e), (unsigned)episode, 0, orow, orow + 64);
+  if (E.use_obs_noise) apply_obs_noise<T, true>(E, key, (unsigned)episode, 0, orow, orow + 64);
   T* op = e < n ? (k.obs_reset ? k.obs_reset + (size_t)e * D : nullptr) : k.dobs + (size_t)(e - n) * D;
   if (op)
     for (int i = 0; i < D; i++) op[i] = orow[i];
@@ -1171,13 +1209,15 @@ template <typename T> __global__ __launch_bounds__(1024) void match_kernel(KArgs
   const int pairs = min(nd, nr);
   const int D = k.E.obs_dim;
   // copy donor -> slot : state fields, int fields, heading ring, reset observation
-  const int per = NF + RING + D;
+  const int NH = k.hp ? 21 : 0;
+  const int per = NF + RING + NH + D;
   for (int w = tid; w < pairs * per; w += NT) {
     int p = w / per, f = w - p * per;
     int slot = k.list[p], donor = n + k.rlist[p];
     if (f < NF) k.st[f * m + slot] = k.st[f * m + donor];
     else if (f < NF + RING) k.ring[(f - NF) * m + slot] = k.ring[(f - NF) * m + donor];
-    else if (k.obs_reset) k.obs_reset[(size_t)slot * D + (f - NF - RING)] = k.dobs[(size_t)(donor - n) * D + (f - NF - RING)];
+    else if (f < NF + RING + NH) k.hp[(f - NF - RING) * m + slot] = k.hp[(f - NF - RING) * m + donor];
+    else if (k.obs_reset) k.obs_reset[(size_t)slot * D + (f - NF - RING - NH)] = k.dobs[(size_t)(donor - n) * D + (f - NF - RING - NH)];
   }
   __syncthreads();
   for (int p = tid; p < pairs; p += NT) {
@@ -1202,6 +1242,122 @@ template <typename T> __global__ __launch_bounds__(1024) void match_kernel(KArgs
     *k.list_count = starved;
     if (pairs) atomicAdd(&k.counters[2], (unsigned long long)pairs);
   }
+}
+
+// ------------------------------------------------------------------ match kernel, reset streams (one block per class)
+// A class = stream_envs consecutive envs + stream_donors donor lanes.  Its donors settle the episodes (class key, 0), (class key, 1), ...
+// of ONE stream; finished envs of the class take them strictly in order -- the k-th reset of the class (by step, then by env index) gets
+// episode k, whichever donor holds it.  Every donor needs the same number of launches (no paced rows in this mode), so episodes become
+// ready in the order they were started and the ready ones are the contiguous range [next_hand, next_hand + nr).  An env whose episode is
+// not ready settles it itself (settle kernel, same key and episode -> same state) and the donor working on it starts a new one.  What an
+// env restarts with is therefore a function of its class's history alone: identical for every sharding whose shards are whole classes.
+template <typename T> __global__ __launch_bounds__(256) void match_kernel_stream(KArgs<T> k) {
+  __shared__ int cnt[256];
+  __shared__ int nd_s, nr_s;
+  const int tid = threadIdx.x, NT = blockDim.x, c = blockIdx.x;
+  const int n = k.n, m = k.m, B = k.E.stream_envs, Dc = k.E.stream_donors, TB = k.stream_table;
+  const int e0 = c * B, d0 = n + c * Dc;
+  int* const list = k.list + e0;      // this class's finished envs, ascending
+  int* const rl = k.rlist + c * Dc;   // donor lane holding episode next_hand + i, or -1
+  int* const hold = k.holder + c * TB;
+  const int next_start = k.cls[2 * c], next_hand = k.cls[2 * c + 1];
+  {  // ordered compaction of the class's done flags
+    const int chunk = (B + NT - 1) / NT;
+    const int lo = min(tid * chunk, B), hi = min(lo + chunk, B);
+    int cc = 0;
+    for (int i = lo; i < hi; i++) cc += k.doneflag[e0 + i] != 0 ? 1 : 0;
+    cnt[tid] = cc;
+    __syncthreads();
+    for (int off = 1; off < NT; off <<= 1) {
+      int v = tid >= off ? cnt[tid - off] : 0;
+      __syncthreads();
+      cnt[tid] += v;
+      __syncthreads();
+    }
+    int start = cnt[tid] - cc;
+    for (int i = lo; i < hi; i++)
+      if (k.doneflag[e0 + i] != 0) list[start++] = e0 + i;
+    if (tid == NT - 1) nd_s = cnt[tid];
+  }
+  if (tid == 0) nr_s = 0;
+  for (int j = tid; j < Dc; j += NT) rl[j] = -1;
+  __syncthreads();
+  for (int j = tid; j < Dc; j += NT)
+    if (k.ist[I_PHASE * m + d0 + j] == PH_READY) {
+      const int off = k.ist[I_SRCEP * m + d0 + j] - next_hand;
+      if (off >= 0 && off < Dc) { rl[off] = d0 + j; atomicAdd(&nr_s, 1); }
+    }
+  __syncthreads();
+  const int nd = nd_s;
+  if (nd == 0) return;
+  // the ready prefix: episodes next_hand, next_hand + 1, ... as long as their holders are ready
+  int nr = 0;
+  if (tid == 0) {
+    while (nr < nr_s && nr < nd && rl[nr] >= 0) nr++;
+    nr_s = nr;
+  }
+  __syncthreads();
+  nr = nr_s;
+  const int pairs = min(nd, nr);
+  const int D = k.E.obs_dim;
+  const int NH = k.hp ? 21 : 0;
+  const int per = NF + RING + NH + D;
+  for (int w = tid; w < pairs * per; w += NT) {
+    const int p = w / per, f = w - p * per;
+    const int slot = list[p], donor = rl[p];
+    if (f < NF) k.st[f * m + slot] = k.st[f * m + donor];
+    else if (f < NF + RING) k.ring[(f - NF) * m + slot] = k.ring[(f - NF) * m + donor];
+    else if (f < NF + RING + NH) k.hp[(f - NF - RING) * m + slot] = k.hp[(f - NF - RING) * m + donor];
+    else if (k.obs_reset) k.obs_reset[(size_t)slot * D + (f - NF - RING - NH)] = k.dobs[(size_t)(donor - n) * D + (f - NF - RING - NH)];
+  }
+  __syncthreads();
+  for (int p = tid; p < pairs; p += NT) {
+    const int slot = list[p], donor = rl[p];
+    k.ist[I_STEPNUM * m + slot] = k.ist[I_STEPNUM * m + donor];
+    k.ist[I_ELAPSED * m + slot] = 0;
+    k.ist[I_RINGLEN * m + slot] = k.ist[I_RINGLEN * m + donor];
+    k.ist[I_RINGHEAD * m + slot] = k.ist[I_RINGHEAD * m + donor];
+    k.ist[I_SRC * m + slot] = donor;
+    k.ist[I_SRCEP * m + slot] = k.ist[I_SRCEP * m + donor];
+    // the donor starts the next episode nobody has started yet
+    k.ist[I_PHASE * m + donor] = PH_INIT;
+    k.ist[I_EPISODE * m + donor] = next_start + p;
+    k.ist[I_HALF * m + donor] = 0;
+    hold[(next_start + p) & (TB - 1)] = donor;
+    k.doneflag[slot] = 0;
+  }
+  __syncthreads();
+  // envs whose episode is not ready: they settle it themselves; a donor that is working on it takes a new one
+  if (tid == 0) {
+    const int starved = nd - pairs;
+    int fresh = next_start + pairs;  // next episode index nobody holds
+    if (starved > 0) {
+      const int base = atomicAdd(k.list_count, starved);
+      for (int s_ = 0; s_ < starved; s_++) {
+        const int env = list[pairs + s_], ep = next_hand + pairs + s_;
+        k.list_ep[base + s_] = ep;
+        k.rlist[k.m + base + s_] = env;  // (staged: the global list is filled below, after every class has read its own part of it)
+        k.doneflag[env] = 0;
+        if (ep < next_start) {  // somebody is settling it (or holds it behind a gap): re-arm that donor
+          const int donor = hold[ep & (TB - 1)];
+          k.ist[I_PHASE * m + donor] = PH_INIT;
+          k.ist[I_EPISODE * m + donor] = fresh;
+          k.ist[I_HALF * m + donor] = 0;
+          hold[fresh & (TB - 1)] = donor;
+          fresh++;
+        }
+      }
+    }
+    const int hand = next_hand + nd;
+    k.cls[2 * c] = fresh > hand ? fresh : hand;
+    k.cls[2 * c + 1] = hand;
+    if (pairs) atomicAdd(&k.counters[2], (unsigned long long)pairs);
+  }
+}
+// the starved envs the classes staged -> the list the settle kernel reads (a class's own part of list[] was its scratch space above)
+template <typename T> __global__ void stream_starved_kernel(KArgs<T> k) {
+  const int cntv = *k.list_count;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cntv; i += gridDim.x * blockDim.x) k.list[i] = k.rlist[k.m + i];
 }
 
 // set_state: recompute the derived (lagged) fields from qpos the way mj_forward would
@@ -1235,17 +1391,24 @@ struct tgr_handle {
   tgr_config cfg;
   int n = 0, m = 0, device = 0, obs_dim = 0;
   int n_cu = 256;  // compute units of the device (how many rows one round of the row kernels holds)
+  int pace_from = -1;  // TGR_PACE_FROM=<lane>: test hook -- pace the donor rows from this lane on, whatever the device's size
   void* st = nullptr;   // T[NF][m]
   int* ist = nullptr;   // int[NI][m]
+  double* hp = nullptr; // double[21][m]: qpos at full precision (fp32 handles on the row kernels), else null
   void* ring = nullptr; // T[RING][m]
   void* dobs = nullptr; // T[m-n][D]
   int* list_count = nullptr;
   int* list = nullptr;
   int* rlist = nullptr;
+  int* list_ep = nullptr;  // reset streams (tgr_config.reset_stream_envs > 0): see KArgs
+  int* cls = nullptr;
+  int* holder = nullptr;
+  int n_classes = 0, stream_donors = 0, stream_table = 0;
   uint8_t* doneflag = nullptr;
   unsigned long long* counters = nullptr;
   float* hf = nullptr;  // heightfield elevations (model_kind 1)
   void* obs_clean = nullptr;  // caller-owned [N][D] buffer bound with tgr_bind_real_observation, or null
+  unsigned* trace = nullptr;  // caller-owned [N][TGR_TRACE_WORDS] buffer bound with tgr_bind_substep_trace, or null
   int hf_nrow = 0, hf_ncol = 0;
   std::string err;
 };
@@ -1262,9 +1425,10 @@ static thread_local std::string g_err;
   } while (0)
 
 static void free_handle(tgr_handle* h) {
-  (void)hipFree(h->hf);
+  (void)hipFree(h->hf); (void)hipFree(h->hp);
   (void)hipFree(h->st); (void)hipFree(h->ist); (void)hipFree(h->ring); (void)hipFree(h->dobs); (void)hipFree(h->list_count);
   (void)hipFree(h->list); (void)hipFree(h->rlist); (void)hipFree(h->doneflag); (void)hipFree(h->counters);
+  (void)hipFree(h->list_ep); (void)hipFree(h->cls); (void)hipFree(h->holder);
   delete h;
 }
 
@@ -1341,6 +1505,7 @@ extern "C" int tgr_default_config(tgr_config* c, int env_kind, int desired_actio
   c->hf_pos[0] = 0; c->hf_pos[1] = 0; c->hf_pos[2] = -1.0;
   c->reset_noise_scale = 0.0;
   c->kernel_layout = TGR_KERNEL_AUTO;
+  c->solver_rel_tolerance = 0;
   return TGR_OK;
 }
 
@@ -1423,6 +1588,7 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   E.min_heading = c.min_reset_heading; E.max_heading = c.max_reset_heading;
   E.ten_mean = c.tendon_reset_mean; E.ten_std = c.tendon_reset_stdev; E.ten_max = c.tendon_max_length; E.ten_min = c.tendon_min_length;
   E.seed = c.seed; E.first_env_id = c.first_env_id; E.reset_noise = c.reset_noise_scale;
+  E.stream_envs = h->n_classes > 0 ? c.reset_stream_envs : 0; E.stream_donors = h->stream_donors;
   k.n = h->n; k.m = h->m;
   {
     // Paced donor rows (step_kernel_row): the rows that do not fit the first round of wave slots -- one round holds 4 rows per wavefront,
@@ -1432,14 +1598,20 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
     const int round_rows = h->n_cu * ((c.precision != TGR_PRECISION_F64 && c.model_kind == 0) ? 8 : 4) * 4;
     int from = round_rows > h->n + donors / 2 ? round_rows : h->n + donors / 2;
     from = ((from + 3) / 4) * 4;
-    const bool pace = c.auto_reset && donors >= 64 && (c.frame_skip % 2) == 0 && h->n < round_rows && from < h->m;
+    // (reset streams hand episodes out in the order they were started: every donor must need the same number of launches)
+    bool pace = c.auto_reset && donors >= 64 && (c.frame_skip % 2) == 0 && h->n < round_rows && from < h->m && h->n_classes == 0;
+    if (h->pace_from >= 0) {  // test hook (tests/test_gpu_reset_vecenv.py): which rows are paced no longer depends on n or the CU count
+      from = ((h->pace_from > h->n ? h->pace_from : h->n) + 3) / 4 * 4;
+      pace = c.auto_reset && donors > 0 && (c.frame_skip % 2) == 0 && from < h->m && h->n_classes == 0;
+    }
     k.slow_e = pace ? from : h->m + 4;
   }
-  k.st = (T*)h->st; k.ist = h->ist; k.ring = (T*)h->ring; k.dobs = (T*)h->dobs;
+  k.st = (T*)h->st; k.ist = h->ist; k.ring = (T*)h->ring; k.dobs = (T*)h->dobs; k.hp = h->hp;
   k.list_count = h->list_count; k.list = h->list; k.rlist = h->rlist; k.doneflag = h->doneflag; k.counters = h->counters;
+  k.list_ep = h->list_ep; k.cls = h->cls; k.holder = h->holder; k.stream_table = h->stream_table;
   k.auto_reset = c.auto_reset;
   k.actions = nullptr; k.obs = nullptr; k.reward = nullptr; k.terminated = nullptr; k.truncated = nullptr;
-  k.terminal_obs = nullptr; k.info = nullptr; k.obs_reset = nullptr; k.obs_clean = nullptr;
+  k.terminal_obs = nullptr; k.info = nullptr; k.obs_reset = nullptr; k.obs_clean = nullptr; k.dbg = nullptr;
 }
 
 static int alloc_handle(tgr_handle* h, int n_envs, int donors) {
@@ -1454,13 +1626,25 @@ static int alloc_handle(tgr_handle* h, int n_envs, int donors) {
     for (size_t e = 0; e < m; e++) ist[I_PHASE * m + e] = e < (size_t)n_envs ? PH_LIVE : PH_INIT;
     HIP_TRY(h, hipMemcpy(h->ist, ist.data(), sizeof(int) * NI * m, hipMemcpyHostToDevice));
   }
+  if (h->cfg.precision != TGR_PRECISION_F64 && use_row_kernels(h)) {
+    HIP_TRY(h, hipMalloc((void**)&h->hp, sizeof(double) * 21 * m));
+    HIP_TRY(h, hipMemset(h->hp, 0, sizeof(double) * 21 * m));
+  }
   HIP_TRY(h, hipMalloc(&h->ring, ts * RING * m));
   HIP_TRY(h, hipMemset(h->ring, 0, ts * RING * m));
   HIP_TRY(h, hipMalloc(&h->dobs, ts * (size_t)h->obs_dim * (size_t)(donors > 0 ? donors : 1)));
   HIP_TRY(h, hipMalloc((void**)&h->list_count, sizeof(int)));
   HIP_TRY(h, hipMemset(h->list_count, 0, sizeof(int)));
   HIP_TRY(h, hipMalloc((void**)&h->list, sizeof(int) * m));
-  HIP_TRY(h, hipMalloc((void**)&h->rlist, sizeof(int) * m));
+  HIP_TRY(h, hipMalloc((void**)&h->rlist, sizeof(int) * 2 * m));
+  if (h->n_classes > 0) {
+    HIP_TRY(h, hipMalloc((void**)&h->list_ep, sizeof(int) * m));
+    HIP_TRY(h, hipMemset(h->list_ep, 0xff, sizeof(int) * m));
+    HIP_TRY(h, hipMalloc((void**)&h->cls, sizeof(int) * 2 * h->n_classes));
+    HIP_TRY(h, hipMemset(h->cls, 0, sizeof(int) * 2 * h->n_classes));
+    HIP_TRY(h, hipMalloc((void**)&h->holder, sizeof(int) * (size_t)h->n_classes * h->stream_table));
+    HIP_TRY(h, hipMemset(h->holder, 0, sizeof(int) * (size_t)h->n_classes * h->stream_table));
+  }
   HIP_TRY(h, hipMalloc((void**)&h->doneflag, m));
   HIP_TRY(h, hipMemset(h->doneflag, 0, m));
   HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 160));
@@ -1486,8 +1670,13 @@ template <typename T> static void params_to_row(const Params<T>& P, const tgr_co
   R.hf_nrow = P.hf_nrow; R.hf_ncol = P.hf_ncol; R.hf = P.hf;
   const bool f32 = c.precision != TGR_PRECISION_F64;
   // (uneven-ground model: 5 cm caps on tilted facets put more contact torque about the bars' own axes -- a tighter default keeps qvel inside 1e-4)
-  R.tol = T(c.solver_tolerance > 0 ? c.solver_tolerance : (f32 ? (c.model_kind ? 3e-4 : 1e-3) : 1e-8));
-  R.max_iter = c.solver_iterations > 0 ? c.solver_iterations : (f32 ? 8 : 40);
+  // fp32 handles: g^T M^-1 g < tol^2 + rtol^2 d^T M d with (tol, rtol) = (5e-4, 2e-5) on the flat floor, (3e-4, 5e-6) on the heightfield --
+  // the relative term is what fp32 resolves of a gradient that is the difference of forces of that size (DESIGN.md 4.1,
+  // profiles/round3_tolerance_study.log); iteration cap 16, and a row whose line search finds no descent at working precision leaves at
+  // once (counted with the unconverged ones)
+  R.tol = T(c.solver_tolerance > 0 ? c.solver_tolerance : (f32 ? (c.model_kind ? 3e-4 : 5e-4) : 1e-8));
+  R.rtol = T(c.solver_rel_tolerance > 0 ? c.solver_rel_tolerance : (c.solver_rel_tolerance < 0 ? 0.0 : (f32 ? (c.model_kind ? 5e-6 : 2e-5) : 0.0)));
+  R.max_iter = c.solver_iterations > 0 ? c.solver_iterations : (f32 ? 16 : 40);
   R.ls_iter = f32 ? 6 : 50;
 }
 template <typename T> static void fill_row_args(const tgr_handle* h, const KArgs<T>& k, RowArgs<T, double>& ra) {
@@ -1520,8 +1709,22 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
   }
+  if (const char* v = getenv("TGR_PACE_FROM")) h->pace_from = atoi(v);
   int donors = cfg->n_donors < 0 ? 2 * n_envs : cfg->n_donors;
   if (!cfg->auto_reset) donors = 0;
+  if (cfg->reset_stream_envs > 0 && donors > 0) {
+    const int B = cfg->reset_stream_envs;
+    const bool ok = use_row_kernels(h) && n_envs % B == 0 && cfg->first_env_id % (uint64_t)B == 0 && donors % (n_envs / B) == 0;
+    if (!ok) {
+      g_err = "tgr_create: reset_stream_envs needs the row kernels, n_envs and first_env_id multiples of it, and n_donors a multiple of the number of classes";
+      delete h;
+      return TGR_ERR_INVALID;
+    }
+    h->n_classes = n_envs / B;
+    h->stream_donors = donors / h->n_classes;
+    h->stream_table = 1;
+    while (h->stream_table < 2 * h->stream_donors) h->stream_table <<= 1;
+  }
   h->m = n_envs + donors;
   *out = nullptr;
   const int rc = alloc_handle(h, n_envs, donors);
@@ -1571,7 +1774,10 @@ extern "C" int tgr_synchronize(tgr_handle* h) {
 }
 extern "C" uint64_t tgr_lane_key(const tgr_handle* h, int lane) {
   if (!h) return 0;
-  return lane < h->n ? h->cfg.first_env_id + (uint64_t)lane : (1ull << 62) + h->cfg.first_env_id * 8ull + (uint64_t)(lane - h->n);
+  if (lane < h->n) return h->cfg.first_env_id + (uint64_t)lane;
+  if (h->n_classes > 0)  // reset streams: the key of the donor lane's class (tgr_sim.hip lane_key)
+    return (1ull << 62) + (1ull << 40) + h->cfg.first_env_id / (uint64_t)h->cfg.reset_stream_envs + (uint64_t)((lane - h->n) / h->stream_donors);
+  return (1ull << 62) + h->cfg.first_env_id * 8ull + (uint64_t)(lane - h->n);
 }
 extern "C" int tgr_set_seed(tgr_handle* h, uint64_t seed) {
   if (!h) return TGR_ERR_INVALID;
@@ -1580,11 +1786,18 @@ extern "C" int tgr_set_seed(tgr_handle* h, uint64_t seed) {
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipDeviceSynchronize());
   HIP_TRY(h, hipMemset(h->ist + (size_t)I_EPISODE * h->m, 0, sizeof(int) * (size_t)h->m));
+  if (h->n_classes > 0) HIP_TRY(h, hipMemset(h->cls, 0, sizeof(int) * 2 * h->n_classes));  // (the full reset that follows deals the streams out afresh)
   return TGR_OK;
 }
 extern "C" int tgr_bind_real_observation(tgr_handle* h, void* real_obs_dev) {
   if (!h) return TGR_ERR_INVALID;
   h->obs_clean = real_obs_dev;
+  return TGR_OK;
+}
+static_assert(TGR_TRACE_WORDS == row::TRACE_WORDS, "sub-step trace layout");
+extern "C" int tgr_bind_substep_trace(tgr_handle* h, uint32_t* trace_dev) {
+  if (!h) return TGR_ERR_INVALID;
+  h->trace = trace_dev;
   return TGR_OK;
 }
 extern "C" int tgr_stats(tgr_handle* h, uint64_t out[8]) {
@@ -1623,6 +1836,25 @@ template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, 
     for (int i = h->n; i < h->m; i++) idx.push_back(i);
   int cnt = (int)idx.size();
   if (cnt == 0) return TGR_OK;
+  if (h->n_classes > 0) {
+    // reset streams: explicit resets of live envs run under the env's own key; a full reset also deals each class's donors the next
+    // stream_donors episodes of its stream (donor j of the class: episode next_start + j), ready to be handed out in that order
+    HIP_TRY(h, hipStreamSynchronize(s));
+    HIP_TRY(h, hipMemset(h->list_ep, 0xff, sizeof(int) * (size_t)h->m));
+    if (!mask) {
+      const int C_ = h->n_classes, Dc = h->stream_donors, TB = h->stream_table;
+      std::vector<int> cls(2 * C_), ep((size_t)C_ * Dc), hold((size_t)C_ * TB, 0);
+      HIP_TRY(h, hipMemcpy(cls.data(), h->cls, sizeof(int) * 2 * C_, hipMemcpyDeviceToHost));
+      for (int c = 0; c < C_; c++) {
+        const int base = cls[2 * c];
+        for (int j = 0; j < Dc; j++) { ep[(size_t)c * Dc + j] = base + j; hold[(size_t)c * TB + ((base + j) & (TB - 1))] = h->n + c * Dc + j; }
+        cls[2 * c] = base + Dc; cls[2 * c + 1] = base;
+      }
+      HIP_TRY(h, hipMemcpy(h->cls, cls.data(), sizeof(int) * 2 * C_, hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->holder, hold.data(), sizeof(int) * hold.size(), hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->ist + (size_t)I_EPISODE * h->m + h->n, ep.data(), sizeof(int) * ep.size(), hipMemcpyHostToDevice));
+    }
+  }
   HIP_TRY(h, hipMemcpyAsync(h->list, idx.data(), sizeof(int) * cnt, hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemcpyAsync(h->list_count, &cnt, sizeof(int), hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipStreamSynchronize(s));  // idx / cnt are host temporaries
@@ -1671,6 +1903,7 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
   k.terminal_obs = terminal_obs; k.info = info;
   k.obs_reset = obs;
   k.obs_clean = (T*)h->obs_clean;
+  k.dbg = h->trace;
   constexpr int LW = LaneW<T>::value;
   const bool rowk = use_row_kernels(h);
   RowArgs<T, double> ra;
@@ -1694,7 +1927,13 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
   }
   HIP_TRY(h, hipGetLastError());
   if (h->cfg.auto_reset) {
-    hipLaunchKernelGGL((match_kernel<T>), dim3(1), dim3(1024), 0, s, k);
+    if (h->n_classes > 0) {
+      HIP_TRY(h, hipMemsetAsync(h->list_count, 0, sizeof(int), s));
+      hipLaunchKernelGGL((match_kernel_stream<T>), dim3(h->n_classes), dim3(256), 0, s, k);
+      hipLaunchKernelGGL((stream_starved_kernel<T>), dim3(8), dim3(256), 0, s, k);
+    } else {
+      hipLaunchKernelGGL((match_kernel<T>), dim3(1), dim3(1024), 0, s, k);
+    }
     HIP_TRY(h, hipGetLastError());
     // envs that found no ready donor are settled here and now (grid sized for the worst case, exits on an empty list)
     if (rowk) {
@@ -1743,8 +1982,13 @@ template <typename T> static int get_state_impl(tgr_handle* h, double* qpos, dou
     ring.resize(RING * n);
     HIP_TRY(h, hipMemcpy(ring.data(), h->ring, sizeof(T) * RING * n, hipMemcpyDeviceToHost));
   }
+  std::vector<double> hp;
+  if (qpos && h->hp) {
+    hp.resize(21 * n);
+    HIP_TRY(h, hipMemcpy(hp.data(), h->hp, sizeof(double) * 21 * n, hipMemcpyDeviceToHost));
+  }
   for (size_t e = 0; e < nlive; e++) {
-    if (qpos) for (int i = 0; i < 21; i++) qpos[e * 21 + i] = (double)st[(F_QPOS + i) * n + e];
+    if (qpos) for (int i = 0; i < 21; i++) qpos[e * 21 + i] = h->hp ? hp[i * n + e] : (double)st[(F_QPOS + i) * n + e];
     if (qvel) for (int i = 0; i < 18; i++) qvel[e * 18 + i] = (double)st[(F_QVEL + i) * n + e];
     if (ctrl) for (int i = 0; i < 6; i++) ctrl[e * 6 + i] = (double)st[(F_CTRL + i) * n + e];
     if (warm) for (int i = 0; i < 18; i++) warm[e * 18 + i] = (double)st[(F_WARM + i) * n + e];
@@ -1781,6 +2025,13 @@ static int set_state_impl(tgr_handle* h, const double* qpos, const double* qvel,
     if (warm) for (int i = 0; i < 18; i++) st[(F_WARM + i) * n + e] = (T)warm[e * 18 + i];
   }
   HIP_TRY(h, hipMemcpy(h->st, st.data(), sizeof(T) * NF * n, hipMemcpyHostToDevice));
+  if (qpos && h->hp) {
+    std::vector<double> hp(21 * n);
+    HIP_TRY(h, hipMemcpy(hp.data(), h->hp, sizeof(double) * 21 * n, hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < nlive; e++)
+      for (int i = 0; i < 21; i++) hp[i * n + e] = qpos[e * 21 + i];
+    HIP_TRY(h, hipMemcpy(h->hp, hp.data(), sizeof(double) * 21 * n, hipMemcpyHostToDevice));
+  }
   if (qpos) {
     KArgs<T> k;
     fill_args<T>(h, k);

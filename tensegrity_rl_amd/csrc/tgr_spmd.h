@@ -90,6 +90,11 @@ template <typename T> TGR_RDEV T rowmax(T x) {
 template <int K> TGR_RDEV bool any_slot(bool flag) {
   return (__ballot(flag) & (0x0001000100010001ull << K)) != 0ull;
 }
+// the flags of my row's 16 lanes as a bit mask (replicated), and a replicated value as a plain scalar -- for the sub-step trace
+TGR_RDEV unsigned row_bits(bool flag) { return (unsigned)((__ballot(flag) >> (threadIdx.x & 48u)) & 0xffffull); }
+template <typename T> TGR_RDEV T lane0(T x) { return x; }
+// ... or the flag of any of the slots in MASK (bit K = slot K)
+template <unsigned MASK> TGR_RDEV bool any_slots(bool flag) { return (__ballot(flag) & (0x0001000100010001ull * (unsigned long long)MASK)) != 0ull; }
 template <typename To, typename From> TGR_RDEV To cvt(From x) { return (To)x; }
 TGR_RDEV float gather_f(const float* base, int idx) { return base[idx]; }
 TGR_RDEV int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -178,6 +183,9 @@ template <typename T> inline Ln<T> trisum(const Ln<T>& x) {
 }
 template <typename T> inline Ln<T> rowmax(const Ln<T>& x) { T m = x.v[0]; for (int i = 1; i < ROW; i++) m = x.v[i] > m ? x.v[i] : m; return Ln<T>(m); }
 template <int K> inline bool any_slot(const Ln<bool>& flag) { return flag.v[K]; }
+template <unsigned MASK> inline bool any_slots(const Ln<bool>& flag) { for (int i = 0; i < ROW; i++) if (((MASK >> i) & 1u) && flag.v[i]) return true; return false; }
+inline unsigned row_bits(const Ln<bool>& f) { unsigned m = 0; for (int i = 0; i < ROW; i++) m |= f.v[i] ? 1u << i : 0u; return m; }
+template <typename T> inline T lane0(const Ln<T>& x) { return x.v[0]; }
 inline Ln<float> gather_f(const float* base, const Ln<int>& idx) { Ln<float> r; for (int i = 0; i < ROW; i++) r.v[i] = base[idx.v[i]]; return r; }
 inline Ln<int> clampi(const Ln<int>& x, int lo, int hi) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = x.v[i] < lo ? lo : (x.v[i] > hi ? hi : x.v[i]); return r; }
 template <typename To, typename T> inline To cvt(const Ln<T>& x) { To r; for (int i = 0; i < ROW; i++) r.v[i] = (decltype(r.v[0] + 0))x.v[i]; return r; }

@@ -34,7 +34,7 @@ class _GymEnvBase:
 
     def reset(self, *, seed=None, options=None):
         if seed is not None:
-            self._venv.seed(seed)
+            self._venv.seed(seed, reset=False)
             self.np_random = np.random.default_rng(seed)
         obs = self._venv.reset()
         return obs[0], {}

@@ -99,7 +99,8 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
             setattr(cfg, k, type(cur)(v))
     if "kernel_layout" in kwargs:
         cfg.kernel_layout = N.KERNEL_LAYOUT[kwargs.pop("kernel_layout")]
-    for k in ("actuator_deriv_skip_clamped", "solver_tolerance", "solver_iterations", "n_donors", "solver_warm_start"):
+    for k in ("actuator_deriv_skip_clamped", "solver_tolerance", "solver_rel_tolerance", "solver_iterations", "n_donors", "solver_warm_start",
+              "reset_stream_envs"):
         if k in kwargs:
             setattr(cfg, k, type(getattr(cfg, k))(kwargs.pop(k)))
     if kwargs:
@@ -148,12 +149,25 @@ class TensegrityVecEnv:
         dt = torch.float64 if self.f64 else torch.float32
         n, D = self.num_envs, self.obs_dim
         with torch.cuda.device(self.device):
-            self.obs = torch.zeros((n, D), dtype=dt, device=self.device)
-            self.terminal_obs = torch.zeros((n, D), dtype=dt, device=self.device)
-            self.reward = torch.zeros(n, dtype=dt, device=self.device)
-            self.terminated = torch.zeros(n, dtype=torch.uint8, device=self.device)
-            self.truncated = torch.zeros(n, dtype=torch.uint8, device=self.device)
-            self.info = torch.zeros((n, N.INFO_K), dtype=dt, device=self.device)
+            # every output of a step lives in ONE device allocation, so that the numpy-facing step_wait() brings a step home with a single
+            # device-to-host copy into a pinned mirror (hard part 6): [obs | terminal_obs | info | reward | terminated | truncated]
+            isz = 8 if self.f64 else 4
+            sizes = [n * D * isz, n * D * isz, n * N.INFO_K * isz, n * isz, n, n]
+            offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+            self._pack = torch.zeros(int(offs[-1]), dtype=torch.uint8, device=self.device)
+            self._pack_h = torch.zeros(int(offs[-1]), dtype=torch.uint8).pin_memory()
+            sec = lambda buf, i, dtype, shape: buf[int(offs[i]):int(offs[i + 1])].view(dtype).view(shape)
+            self.obs = sec(self._pack, 0, dt, (n, D))
+            self.terminal_obs = sec(self._pack, 1, dt, (n, D))
+            self.info = sec(self._pack, 2, dt, (n, N.INFO_K))
+            self.reward = sec(self._pack, 3, dt, (n,))
+            self.terminated = sec(self._pack, 4, torch.uint8, (n,))
+            self.truncated = sec(self._pack, 5, torch.uint8, (n,))
+            hv = [sec(self._pack_h, i, d_, sh).numpy() for i, (d_, sh) in enumerate([(dt, (n, D)), (dt, (n, D)), (dt, (n, N.INFO_K)), (dt, (n,)),
+                                                                                      (torch.uint8, (n,)), (torch.uint8, (n,))])]
+            self._h_obs, self._h_tobs, self._h_info, self._h_rew, self._h_term, self._h_trunc = hv
+            self._act_h = torch.zeros((n, 6), dtype=torch.float32).pin_memory()
+            self._act_d = torch.zeros((n, 6), dtype=torch.float32, device=self.device)
             # info["real_observation"] (tr_env.py:507): the noise-free observation; only needed (and bound) with use_obs_noise
             self.real_obs = torch.zeros((n, D), dtype=dt, device=self.device) if self.cfg.use_obs_noise and self.cfg.env_kind == N.ENV_TR else None
         if self.real_obs is not None:
@@ -209,24 +223,41 @@ class TensegrityVecEnv:
         self._actions = actions
 
     def step_wait(self):
-        obs, rew, term, trunc, tobs, info = self.step_tensors(self._actions)
-        obs_h = obs.cpu().numpy().astype(np.float64)
-        rew_h = rew.cpu().numpy().astype(np.float32)
-        term_h = term.cpu().numpy().astype(bool)
-        trunc_h = trunc.cpu().numpy().astype(bool)
+        """SB3's VecEnv.step_wait: numpy in, numpy out.  One pinned host-to-device copy of the actions, the step launches, ONE
+        device-to-host copy of the packed outputs, one stream synchronisation; terminal observations and episode statistics are
+        read from the pinned mirror for finished envs only."""
+        t = self.torch
+        a = self._actions
+        if isinstance(a, t.Tensor):
+            self.step_tensors(a)
+        else:
+            a = np.asarray(a, dtype=np.float32)
+            if a.shape != (self.num_envs, 6):
+                raise ValueError("Action dimension mismatch")
+            np.copyto(self._act_h.numpy(), a)
+            self._act_d.copy_(self._act_h, non_blocking=True)
+            self.step_tensors(self._act_d)
+        self._pack_h.copy_(self._pack, non_blocking=True)
+        t.cuda.current_stream(self.device).synchronize()
+        obs_h = self._h_obs.astype(np.float64)
+        rew_h = self._h_rew.astype(np.float32)
+        term_h = self._h_term.astype(bool)
+        trunc_h = self._h_trunc.astype(bool)
         dones = term_h | trunc_h
-        infos = self._infos(dones, term_h, trunc_h, tobs, info, obs_h)
+        infos = self._infos(dones, term_h, trunc_h, obs_h)
         return obs_h, rew_h, dones, infos
 
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
 
-    def _infos(self, dones, term_h, trunc_h, tobs, info, obs_h=None):
-        """info_mode="minimal": empty dicts except for finished envs (all SB3 itself reads); "full": the reference's info dict."""
+    def _infos(self, dones, term_h, trunc_h, obs_h):
+        """info_mode="minimal": empty dicts except for finished envs (all SB3 itself reads); "full": the reference's info dict.
+        Reads the pinned host mirror of the step that has just been brought home."""
         n = self.num_envs
+        ih = self._h_info
         if self.info_mode == "full":
-            ih = info.cpu().numpy().astype(np.float64)
+            ih = ih.astype(np.float64)
             infos = [dict(zip(N.INFO_KEYS, ih[i, :10])) for i in range(n)]
             tr = self.cfg.env_kind == N.ENV_TR
             for i in range(n):
@@ -238,26 +269,24 @@ class TensegrityVecEnv:
                 if self.real_obs is not None:
                     rh = self.real_obs.cpu().numpy().astype(np.float64)
                 else:
-                    rh = obs_h.copy() if obs_h is not None else self.obs.cpu().numpy().astype(np.float64)
+                    rh = obs_h.copy()
                     fin = np.nonzero(dones)[0]
                     if fin.size and self.cfg.auto_reset:
-                        rh[fin] = tobs.cpu().numpy().astype(np.float64)[fin]
+                        rh[fin] = self._h_tobs[fin]
                 for i in range(n):
                     infos[i]["real_observation"] = rh[i]
         else:
             infos = [{} for _ in range(n)]
-            ih = None
         idx = np.nonzero(dones)[0]
         if idx.size:
-            if ih is None:
-                ih = info.cpu().numpy().astype(np.float64)
-            th = tobs.cpu().numpy().astype(np.float64)
+            th = self._h_tobs[idx].astype(np.float64)  # (a copy: the mirror is overwritten by the next step)
+            ep = ih[idx, 14:16]
             now = round(time.time() - self._t0, 6)
-            for i in idx:
+            for j, i in enumerate(idx):
                 d = infos[i]
-                d["terminal_observation"] = th[i]
+                d["terminal_observation"] = th[j]
                 d["TimeLimit.truncated"] = bool(trunc_h[i] and not term_h[i])
-                d["episode"] = {"r": float(ih[i, 14]), "l": int(ih[i, 15]), "t": now}
+                d["episode"] = {"r": float(ep[j, 0]), "l": int(ep[j, 1]), "t": now}
         return infos
 
     def close(self):
@@ -271,9 +300,13 @@ class TensegrityVecEnv:
         except Exception:
             pass
 
-    def seed(self, seed=None):
+    def seed(self, seed=None, reset=True):
+        """re-key the reset RNG (SB3's VecEnv.seed).  Every lane's episode counter starts over, and the donor lanes -- which hold episodes
+        settled under the old key -- are settled afresh by the full reset that follows, so that seed(s) twice gives the same episodes twice"""
         if seed is not None:
-            self.lib.tgr_set_seed(self.handle, int(seed))
+            N.check(self.handle, self.lib.tgr_set_seed(self.handle, int(seed)), "tgr_set_seed")
+            if reset:  # (reset=False: the caller resets right away itself)
+                self.reset_tensors()
         return [seed] * self.num_envs
 
     def get_attr(self, attr_name, indices=None):
@@ -317,6 +350,14 @@ class TensegrityVecEnv:
         keep = [p(qpos, N.NQ), p(qvel, N.NV), p(ctrl, N.NU), p(qacc_warmstart, N.NV), p(aux, N.AUX_K)]
         rc = self.lib.tgr_set_state(self.handle, *[k[1] for k in keep])
         N.check(self.handle, rc, "tgr_set_state")
+
+    def bind_substep_trace(self, on=True):
+        """diagnostic: a uint32 [N, 24] device tensor that every step fills with the per-sub-step contact / solver trace of each env
+        (include/tensegrity.h tgr_bind_substep_trace); None unbinds"""
+        t = self.torch
+        self.trace = t.zeros((self.num_envs, N.TRACE_WORDS), dtype=t.int32, device=self.device) if on else None
+        N.check(self.handle, self.lib.tgr_bind_substep_trace(self.handle, self.trace.data_ptr() if on else None), "tgr_bind_substep_trace")
+        return self.trace
 
     def stats(self):
         out = (C.c_uint64 * 8)()

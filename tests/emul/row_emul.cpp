@@ -22,7 +22,7 @@ template <typename T> static void fill_params(const double* p, RParams<T>& P, co
   P.ctrl_lo = T(p[i++]); P.ctrl_hi = T(p[i++]); P.K = T(p[i++]); P.B = T(p[i++]);
   P.imp0 = T(p[i++]); P.imp1 = T(p[i++]); P.imp_width = T(p[i++]); P.imp_mid = T(p[i++]);
   P.f0 = T(p[i++]); P.f1sq = T(p[i++]); P.f3sq = T(p[i++]); P.f4sq = T(p[i++]); P.impratio = T(p[i++]); P.invweight = T(p[i++]);
-  P.tol = T(p[i++]); P.ls_tol = T(p[i++]); P.cf_lo = T(p[i++]); P.cf_hi = T(p[i++]);
+  P.tol = T(p[i++]); P.rtol = T(p[i++]); P.ls_tol = T(p[i++]); P.cf_lo = T(p[i++]); P.cf_hi = T(p[i++]);
   P.max_iter = (int)p[i++]; P.ls_iter = (int)p[i++]; P.skip_clamped = (int)p[i++]; P.act_itau = T(p[i++]);
   P.warm_start = 0;
   P.hf_rx = T(p[i++]); P.hf_ry = T(p[i++]); P.hf_ez = T(p[i++]); P.hf_x0 = T(p[i++]); P.hf_y0 = T(p[i++]); P.hf_z0 = T(p[i++]);
@@ -42,7 +42,7 @@ template <typename T> static int check_rep(const Ln<T>& x, const char* what, int
 
 template <typename TK, typename T, int MODEL>
 static int run(const double* params, const float* hf, int nrow, int ncol, int n, int nsub, double* qpos, double* qvel, const double* ctrl, double* act,
-               double* out /* [n][32] */) {
+               double* out /* [n][32] */, unsigned* trace /* [n][TRACE_WORDS] or null */) {
   typedef Ln<T> F;
   typedef Ln<TK> K;
   RParams<T> P;
@@ -58,6 +58,7 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
     F fd[F_SLAB], td[T_SLAB], cd[C_SLAB * n_pages<MODEL>()];
     RMem<K, F> M;
     M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0}; M.cd = Slab<F>{cd, 1, 0}; M.hd = Slab<F>{hd, 1, 0}; M.lp = Slab<F>{lp, 1, 0};
+    M.dbg = trace ? trace + (size_t)TRACE_WORDS * e : nullptr;
     store_role_consts<K, F, TK, MODEL>(PK, M.rd);
     RLag<K, F> lag;
     for (int b = 0; b < 3; b++) {
@@ -76,8 +77,8 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
     for (int i = 0; i < 18; i++) fd[FDL + i] = F(T(0));
     for (int i = 0; i < H_SLAB; i++) hd[i] = F(T(0));
     lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = F(T(0)); lag.n_own = F(T(0)); lag.cfrc_absmax = F(T(0)); lag.cfrc_clip_sq = F(T(0)); lag.bar_contact = F(T(0)); lag.overflow = F(T(0));
-    for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, M, lag);
-    substep<K, F, TK, T, MODEL, true>(PK, P, M, lag);
+    for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, M, lag, s);
+    substep<K, F, TK, T, MODEL, true>(PK, P, M, lag, nsub - 1);
     for (int b = 0; b < 3; b++) {
       K qq[4] = {kd[KQ + 4 * b], kd[KQ + 4 * b + 1], kd[KQ + 4 * b + 2], kd[KQ + 4 * b + 3]};
       normalize_quat(qq);
@@ -110,13 +111,13 @@ extern "C" void tgr_row_opcount(long long* out /* [2][16] */, int reset) {
 #endif
 // precision: 0 = fp32 throughout, 1 = fp64 throughout, 2 = mixed (pose / kinematics / tendons fp64, the rest fp32)
 extern "C" int tgr_row_emul(int precision, int model, const double* params, const float* hf, int nrow, int ncol, int n, int nsub, double* qpos,
-                            double* qvel, const double* ctrl, double* act, double* out) {
+                            double* qvel, const double* ctrl, double* act, double* out, unsigned* trace) {
   if (model == 0) {
-    if (precision == 1) return run<double, double, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
-    if (precision == 2) return run<double, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
-    return run<float, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
+    if (precision == 1) return run<double, double, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
+    if (precision == 2) return run<double, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
+    return run<float, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
   }
-  if (precision == 1) return run<double, double, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
-  if (precision == 2) return run<double, float, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
-  return run<float, float, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out);
+  if (precision == 1) return run<double, double, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
+  if (precision == 2) return run<double, float, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
+  return run<float, float, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
 }

@@ -26,7 +26,7 @@ def lib():
     return _lib
 
 
-def params_from_oracle_model(m, tol, max_iter, ls_iter=50, ls_tol=0.01, cf=(-1.0, 1.0)):
+def params_from_oracle_model(m, tol, max_iter, ls_iter=50, ls_tol=0.01, cf=(-1.0, 1.0), rtol=0.0):
     """RParams of tgr_row.h from the oracle's tgo_model, the way fill_args (tgr_sim.hip) derives them from tgr_config"""
     dmax = m.solimp[1]
     fr = list(m.friction)
@@ -34,14 +34,14 @@ def params_from_oracle_model(m, tol, max_iter, ls_iter=50, ls_tol=0.01, cf=(-1.0
          m.site_off, m.site_z] + list(m.ten_stiffness) + list(m.ten_damping) + list(m.ten_springlen) + \
         [m.gain, m.bias0, m.bias1, m.bias2, m.force_lo, m.force_hi, m.ctrl_lo, m.ctrl_hi, -m.solref[0] / dmax ** 2, -m.solref[1] / dmax,
          m.solimp[0], m.solimp[1], m.solimp[2], m.solimp[3], fr[0], fr[1] ** 2, fr[2] ** 2, fr[3] ** 2, m.impratio, m.invweight_tran,
-         tol, ls_tol, cf[0], cf[1], max_iter, ls_iter, m.actuator_deriv_skip_clamped, 1.0 / max(m.act_tau, 1e-12),
+         tol, rtol, ls_tol, cf[0], cf[1], max_iter, ls_iter, m.actuator_deriv_skip_clamped, 1.0 / max(m.act_tau, 1e-12),
          m.hf_size[0], m.hf_size[1], m.hf_size[2], m.hf_pos[0], m.hf_pos[1], m.hf_pos[2]]
     return np.ascontiguousarray(p, dtype=np.float64)
 
 
-def step(params, qpos, qvel, ctrl, act=None, nsub=20, f64=True, model=0, heights=None, precision=None):
+def step(params, qpos, qvel, ctrl, act=None, nsub=20, f64=True, model=0, heights=None, precision=None, trace=None):
     """nsub sub-steps for n envs; returns (qpos, qvel, act, out[n, 32]) -- out: tenL[9], lag x[9], cfrc_absmax, cfrc_clip_sq, bar_contact,
-    overflow, n_unconv, n_it, n_ls"""
+    overflow, n_unconv, n_it, n_ls, n_own.  trace: optional uint32 [n, 24] array that receives the sub-step trace (tgr_row.h RMem::dbg)"""
     n = qpos.shape[0]
     qpos = np.ascontiguousarray(qpos, dtype=np.float64).copy(); qvel = np.ascontiguousarray(qvel, dtype=np.float64).copy()
     ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
@@ -51,7 +51,8 @@ def step(params, qpos, qvel, ctrl, act=None, nsub=20, f64=True, model=0, heights
     P = C.POINTER(C.c_double)
     bad = lib().tgr_row_emul(int(f64) if precision is None else {'f32': 0, 'f64': 1, 'mixed': 2}[precision], int(model), params.ctypes.data_as(P), None if hf is None else hf.ctypes.data_as(C.c_void_p),
                              0 if hf is None else hf.shape[0], 0 if hf is None else hf.shape[1], n, nsub, qpos.ctypes.data_as(P),
-                             qvel.ctypes.data_as(P), ctrl.ctypes.data_as(P), act.ctypes.data_as(P), out.ctypes.data_as(P))
+                             qvel.ctypes.data_as(P), ctrl.ctypes.data_as(P), act.ctypes.data_as(P), out.ctypes.data_as(P),
+                             None if trace is None else trace.ctypes.data_as(C.c_void_p))
     if bad != 0:
         raise RuntimeError(f"row emulation: {bad} replicated values differed across the lanes of a row (or unsupported model)")
     return qpos, qvel, act, out

@@ -1,25 +1,42 @@
-"""accuracy of the fp32 handles (production precision) against the oracle on identical (state, action), larger sample than the tests:
-fraction of env-steps with the per-env relative error of qpos / qvel below 1e-4 (BASELINE.json's bound), medians, solver statistics.
-usage: python tests/gpu_accuracy_report.py [n] [steps]"""
+"""accuracy of the fp32 handles (production precision) against the oracle on identical (state, action), larger sample than the tests,
+with EVERY env-step outside the bound classified on flags the device records (tgr_bind_substep_trace) next to the oracle's own trace
+(tgo_data.trace):
+  flip     the set of contacts the forward pass instantiated differs from the oracle's in some sub-step (a cap or bar crossing dist = 0
+           one sub-step earlier or later: mujoco's contacts switch their damping force on there, so a 1e-9 m difference becomes a velocity
+           difference of O(0.1 m/s))
+  capped   same contacts in all twenty sub-steps, but the solver left a sub-step at its iteration cap or stalled at working precision
+  neither  same contacts, every sub-step converged to the tolerance
+usage: python tests/gpu_accuracy_report.py [n] [steps] [key=value ...]   (key=value: TensegrityVecEnv kwargs, e.g. solver_tolerance=1e-3)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from oracle import oracle as O
 from gpu_common import oracle_to_gpu_state, qfix, rel_env
-from tensegrity_rl_amd import TensegrityVecEnv
-from tensegrity_rl_amd.vec_env import heights_from_image
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-O.build()
-img = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "terrain_100.npy"))
-for kind, uneven in (("tensegrity_env", False), ("tr_env", False), ("tensegrity_env", True), ("tr_env", True)):
+
+
+def oracle_trace(ob):
+    return np.array([np.ctypeslib.as_array(ob.env(i).data.trace)[:20].copy() for i in range(ob.n)], dtype=np.uint32)
+
+
+def classify(trg, tro):
+    """per env: (flip, capped) from the device trace [n, 24] and the oracle trace [n, 20] of the same env-step"""
+    trg = np.asarray(trg).astype(np.uint32)[:, :20]
+    flip = ((trg & 0x3fffff) != (np.asarray(tro, dtype=np.uint32)[:, :20] & 0x3fffff)).any(axis=1)
+    capped = ((trg >> 30) & 1).astype(bool).any(axis=1)
+    return flip, capped
+
+
+def run_case(kind, uneven, n, steps, img, **kw):
+    from tensegrity_rl_amd import TensegrityVecEnv
+    from tensegrity_rl_amd.vec_env import heights_from_image
     okw = dict(heights=heights_from_image(img), model_kind=1) if uneven else {}
     gkw = dict(model="uneven", terrain=img) if uneven else {}
     ob = O.OracleBatch(O.make_cfg(kind, "straight", **okw), n, seed=1234); ob.reset()
-    env = TensegrityVecEnv(n, kind + "-v0", precision="f32", auto_reset=False, seed=1234, **gkw)
+    env = TensegrityVecEnv(n, kind + "-v0", precision="f32", auto_reset=False, seed=1234, **gkw, **kw)
+    trace = env.bind_substep_trace()
     rng = np.random.default_rng(0)
-    eq, ev = [], []
+    eq, ev, fl, cp = [], [], [], []
     for t in range(steps):
         oracle_to_gpu_state(ob, env)
         a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
@@ -28,9 +45,41 @@ for kind, uneven in (("tensegrity_env", False), ("tr_env", False), ("tensegrity_
         st = env.get_state()
         q2, v2 = ob.get_state()[:2]
         eq.append(rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3)); ev.append(rel_env(st["qvel"] - v2, v2, 1e-2))
-    eq, ev = np.concatenate(eq), np.concatenate(ev)
+        f, c = classify(trace.cpu().numpy(), oracle_trace(ob))
+        fl.append(f); cp.append(c)
     s = env.stats()
-    print(f"{kind:15s} {'uneven' if uneven else 'flat  '} n={n} x {steps} steps: qpos<1e-4 {100*(eq<1e-4).mean():.2f} %  qvel<1e-4 {100*(ev<1e-4).mean():.2f} %  "
-          f"median qpos {np.median(eq):.1e} qvel {np.median(ev):.1e}  p99 qvel {np.percentile(ev,99):.1e}  "
-          f"wave iterations/sub-step {s['newton_iters_per_substep']:.2f}  unconverged {100*s['unconverged_lane_substeps']/max(1,s['lane_substeps']):.2f} %", flush=True)
     env.close(); ob.close()
+    return dict(eq=np.concatenate(eq), ev=np.concatenate(ev), flip=np.concatenate(fl), capped=np.concatenate(cp), stats=s)
+
+
+def summary(r):
+    eq, ev, fl, cp, s = r["eq"], r["ev"], r["flip"], r["capped"], r["stats"]
+    finite = np.isfinite(eq) & np.isfinite(ev)
+    bad = ~finite | (eq >= 1e-4) | (ev >= 1e-4)
+    nf = bad & ~fl
+    worst = lambda m: float(max(np.nanmax(eq[m]), np.nanmax(ev[m]))) if m.any() else 0.0
+    return dict(n=int(eq.size), qpos_in=float((eq < 1e-4).mean()), qvel_in=float((ev < 1e-4).mean()), both_in=float((~bad).mean()),
+                outliers=int(bad.sum()), flip=int((bad & fl).sum()), capped=int((nf & cp).sum()), neither=int((nf & ~cp).sum()),
+                nonfinite=int((~finite).sum()), worst_flip=worst(bad & fl), worst_nonflip=worst(nf), flips_inside_bound=int((~bad & fl).sum()),
+                median_qpos=float(np.median(eq)), median_qvel=float(np.median(ev)), p99_qvel=float(np.percentile(ev, 99)), p999_qvel=float(np.percentile(ev, 99.9)),
+                wave_iters_per_substep=s["newton_iters_per_substep"], unconverged_fraction=s["unconverged_lane_substeps"] / max(1, s["lane_substeps"]))
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if "=" not in a]
+    kw = {}
+    for a in sys.argv[1:]:
+        if "=" in a:
+            k_, v_ = a.split("=")
+            kw[k_] = float(v_) if "." in v_ or "e" in v_ else int(v_)
+    n = int(args[0]) if len(args) > 0 else 2048
+    steps = int(args[1]) if len(args) > 1 else 8
+    O.build()
+    img = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "terrain_100.npy"))
+    print(f"# fp32 handles vs the oracle on identical (state, action): {n} envs x {steps} steps per case, kwargs {kw}")
+    print("# case | qpos<1e-4 | qvel<1e-4 | outliers: flip / capped / neither | worst flip / non-flip | median qvel | p99.9 qvel | wave it/sub-step | unconverged")
+    for kind, uneven in (("tensegrity_env", False), ("tr_env", False), ("tensegrity_env", True), ("tr_env", True)):
+        u = summary(run_case(kind, uneven, n, steps, img, **kw))
+        print(f"{kind:15s} {'uneven' if uneven else 'flat  '} | {100*u['qpos_in']:.3f} % | {100*u['qvel_in']:.3f} % | {u['outliers']:4d}: {u['flip']:4d} / {u['capped']:3d} / {u['neither']:3d} "
+              f"(non-finite {u['nonfinite']}) | {u['worst_flip']:.1e} / {u['worst_nonflip']:.1e} | {u['median_qvel']:.1e} | {u['p999_qvel']:.1e} | "
+              f"{u['wave_iters_per_substep']:.2f} | {100*u['unconverged_fraction']:.3f} %", flush=True)

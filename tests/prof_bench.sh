@@ -1,8 +1,10 @@
 #!/bin/bash
 # rocprofv3 passes over the default bench command (kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in separate passes)
+# the library is built (if stale) BEFORE any profiled process starts: a profiled bench never spawns a compiler, all passes measure one build
+(cd $GRAFT_REPO_ROOT && python3 -c "from tensegrity_rl_amd import build; build.build()" > /dev/null) || exit 1
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $OUT
-ARGS="--steps 100 --warmup 30 --no-cpu-baseline"
+ARGS="--steps 100 --warmup 30 --no-cpu-baseline --no-vecenv"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/write.json 2> $OUT/write.err

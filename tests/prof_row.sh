@@ -1,5 +1,6 @@
 #!/bin/bash
 # SQ counters of the row kernels under the quick bench (development aid): usage prof_row.sh <tag> <lib.so> <env-id> [extra quickbench args]
+(cd $GRAFT_REPO_ROOT && python3 -c "from tensegrity_rl_amd import build; build.build()" > /dev/null) || exit 1
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $OUT
 export TGR_LIB=$GRAFT_REPO_ROOT/$2

@@ -68,17 +68,38 @@ def test_fp64_contact_cost_matches_oracle(oracle):
 @pytest.mark.parametrize("kind,action", [("tensegrity_env", "straight"), ("tr_env", "straight")])
 def test_fp32_within_stated_tolerance(oracle, kind, action):
     """BASELINE.json: per-step qpos / qvel within 1e-4 relative of the reference engine on identical (state, action).  The production
-    path (fp32 handle, row kernels: pose / kinematics / tendon geometry / axial torques in fp64 inside the kernel, stopping rule
-    sqrt(g^T M^-1 g) < 1e-3) on 512 envs x 6 control periods: at least 99 % of the env-steps inside the bound, for qpos AND qvel.
-    What is left outside are contact-timing flips (a cap whose distance to the floor changes sign within rounding of zero)."""
+    path (fp32 handle, row kernels: pose in fp64 in HBM and inside the kernel, kinematics / tendon geometry / axial torques in fp64,
+    stopping rule sqrt(g^T M^-1 g) < max(5e-4, 2e-5 sqrt(d^T M d))) on 512 envs x 6 control periods of the five-mode harness; the
+    2048 x 8 sample with the classification of every outlier is test_fp32_every_outlier_is_a_classified_contact_flip below."""
     rows, stats = _run(oracle, kind, action, "f32", 512, 6)
     qpos = np.concatenate([r["qpos"] for r in rows]); qvel = np.concatenate([r["qvel"] for r in rows])
-    assert np.mean(qpos < 1e-4) >= 0.99 and np.mean(qvel < 1e-4) >= 0.99, (np.mean(qpos < 1e-4), np.mean(qvel < 1e-4))
+    assert np.isfinite(qpos).all() and np.isfinite(qvel).all()
+    assert np.mean(qpos < 1e-4) >= 0.997 and np.mean(qvel < 1e-4) >= 0.997, (np.mean(qpos < 1e-4), np.mean(qvel < 1e-4))
     assert np.median(qpos) < 1e-6 and np.median(qvel) < 2e-5
     assert np.median(np.concatenate([r["rew"] for r in rows])) < 1e-4
     assert np.mean(np.concatenate([r["term"] for r in rows])) < 0.01
-    # the solver reaches its tolerance: lane-sub-steps that hit the iteration cap stay a small minority
-    assert stats["unconverged_lane_substeps"] <= 0.03 * stats["lane_substeps"], stats
+    assert stats["unconverged_lane_substeps"] <= 0.002 * stats["lane_substeps"], stats
+
+
+@pytest.mark.parametrize("kind", ["tensegrity_env", "tr_env"])
+def test_fp32_every_outlier_is_a_classified_contact_flip(oracle, golden_dir, kind):
+    """The stated tolerance on the flat-floor model at 2048 envs x 8 control periods, with every env-step outside it explained by flags the
+    device records itself (tgr_bind_substep_trace) next to the oracle's trace of the same step (tests/gpu_accuracy_report.py):
+      * >= 99.9 % of env-steps inside 1e-4 for qpos AND qvel;
+      * what is outside is a contact-activation flip -- some sub-step instantiated a different set of contacts than the oracle's (a cap
+        crossing dist = 0 a sub-step earlier or later) -- except for at most 0.02 % of env-steps (a fourth simultaneous contact of one bar
+        pair: counted in dropped_contacts), and those stay below 5e-2;
+      * a flip changes the velocity by what one sub-step of a contact's damping force does: bounded by 5 (relative to max(|qvel|, 1e-2));
+      * no flip hides inside the bound by luck more than rarely, nothing is non-finite, < 0.1 % of lane-sub-steps leave the solver unconverged."""
+    import os
+    from gpu_accuracy_report import run_case, summary
+    img = np.load(os.path.join(golden_dir, "terrain_100.npy"))
+    u = summary(run_case(kind, False, 2048, 8, img))
+    assert u["nonfinite"] == 0
+    assert u["qpos_in"] >= 0.999 and u["qvel_in"] >= 0.999, u
+    assert u["capped"] + u["neither"] <= 0.0002 * u["n"] and u["worst_nonflip"] < 5e-2, u
+    assert u["worst_flip"] < 5.0, u
+    assert u["unconverged_fraction"] < 1e-3, u
 
 
 def test_block_kernels_remain_a_cross_check(oracle):
@@ -214,8 +235,8 @@ def test_fp64_clamped_actuator_derivative_option_matches_oracle(oracle):
 def test_full_size_rollout_counters_stay_inside_their_bounds():
     """BASELINE size, production settings (4096 envs, fp32, auto-reset through donor lanes, random actions): what the solver and the
     contact slots leave unresolved is counted on the device and bounded here --
-      * bar-bar contacts beyond the two slots per bar pair (the deepest are kept): < 3 per 1000 env-steps,
-      * lane-sub-steps that left the Newton solver at its iteration cap: < 3 %,
+      * bar-bar contacts beyond the three slots per bar pair (the deepest are kept): < 3 per 10000 env-steps,
+      * lane-sub-steps that left the Newton solver unconverged (iteration cap, or stalled at working precision): < 0.2 %,
       * no env ever waited for a synchronous settle (donor lanes always had an episode ready), every observation finite."""
     import torch
     from tensegrity_rl_amd import TensegrityVecEnv
@@ -230,7 +251,7 @@ def test_full_size_rollout_counters_stay_inside_their_bounds():
         bad += int((~torch.isfinite(o).all(dim=1)).sum().item()) if t % 8 == 0 else 0
     s1 = env.stats()
     assert bad == 0
-    assert s1["dropped_contacts"] - s0["dropped_contacts"] < 3e-3 * n * steps, s1
-    assert s1["unconverged_lane_substeps"] - s0["unconverged_lane_substeps"] < 0.03 * (s1["lane_substeps"] - s0["lane_substeps"]), s1
+    assert s1["dropped_contacts"] - s0["dropped_contacts"] < 3e-4 * n * steps, s1   # (three slots per bar pair since round 3)
+    assert s1["unconverged_lane_substeps"] - s0["unconverged_lane_substeps"] < 0.002 * (s1["lane_substeps"] - s0["lane_substeps"]), s1
     assert s1["settle_kernel_resets"] == s0["settle_kernel_resets"] and s1["donor_resets"] > 0, s1
     env.close()

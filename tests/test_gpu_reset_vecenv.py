@@ -274,3 +274,70 @@ def test_edge_cases_ragged_sizes_masks_and_bad_inputs(oracle):
     out = e2.step_tensors(torch.zeros((3, 6), device="cuda", dtype=torch.float64))  # wrong dtype is converted, not rejected
     assert torch.isfinite(out[0]).all()
     e2.close()
+
+
+def test_paced_donor_rows_settle_the_same_episodes(oracle, monkeypatch):
+    """Paced donor rows (the donor rows beyond the first round of wave slots run HALF a control period per launch) against
+    the oracle.  Which rows are paced normally depends on n and on the device's CU count; TGR_PACE_FROM (a test hook read by tgr_create)
+    pins it: here donor lanes 32..47 of a 16-env fp64 handle.  With a 3-step time limit the sixteen envs finish together every third step:
+    step 3 takes the (unpaced) lanes 16..31, step 6 the lanes 32..47 -- both settled by tgr_reset's settle kernel -- steps 9..51 find nothing
+    ready, step 54 and 105 take 16..31 again, and step 108 takes what lanes 32..47 settled over 100 half-period launches (their episode 1) -- the I_HALF state
+    machine, the mid-period store / reload of the state and the solver's cold start at sub-step 11 included -- and every one of them must
+    be reset_model() under that lane's RNG key, to the tolerance the unpaced donors meet in test_vecenv_contract_autoreset_truncation_and_donors."""
+    from tensegrity_rl_amd import TensegrityVecEnv
+    O = oracle
+    n = 16
+    monkeypatch.setenv("TGR_PACE_FROM", "32")
+    env = TensegrityVecEnv(n, "tensegrity_env-v0", precision="f64", max_episode_steps=3, seed=21, n_donors=32)
+    monkeypatch.delenv("TGR_PACE_FROM")
+    env.reset()
+    rng = np.random.default_rng(0)
+    for t in range(108):
+        a = (-0.2 + 0.02 * rng.standard_normal((n, 6))).astype(np.float32)
+        obs, rew, dones, infos = env.step(a)
+    assert dones.all()
+    st = env.get_state()
+    src = st["aux"][:, AUX["src"]].astype(int); ep = st["aux"][:, AUX["episode"]].astype(int)
+    assert (src >= 32).all() and (ep == 1).all(), (src, ep)      # the paced lanes' first episodes settled inside the step launches
+    cfg = O.make_cfg("tensegrity_env", "straight")
+    for i in range(n):
+        oe = O.OracleEnv(cfg)
+        oobs = oe.reset_seeded(21, env.lib.tgr_lane_key(env.handle, int(src[i])), int(ep[i]))
+        assert np.abs(qfix(st["qpos"][i], O.arr(oe.data.qpos)) - O.arr(oe.data.qpos)).max() < 2e-4, i
+        assert np.abs(obs[i] - oobs).max() < 2e-3, i
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,model", [("tensegrity_env-v0", "flat"), ("tr_env-v0", "flat"), ("tr_env-v0", "uneven")])
+def test_step_and_step_tensors_return_the_same_values(golden_dir, env_id, model):
+    """The numpy-facing SB3 surface (step_async / step_wait: one packed device-to-host copy into a pinned mirror) against the device
+    tensors of the same step: observations, rewards, dones, and for every finished env terminal_observation, TimeLimit.truncated and
+    Monitor's episode record."""
+    import os
+    import torch
+    from tensegrity_rl_amd import TensegrityVecEnv
+    n = 256
+    kw = dict(model="uneven", terrain=np.load(os.path.join(golden_dir, "terrain_100.npy"))) if model == "uneven" else {}
+    envs = [TensegrityVecEnv(n, env_id, seed=5, max_episode_steps=7, **kw) for _ in range(2)]
+    o0 = envs[0].reset(); o1 = envs[1].reset_tensors().cpu().numpy()
+    assert np.array_equal(o0.astype(np.float32), o1)
+    rng = np.random.default_rng(1)
+    finished = 0
+    for t in range(16):
+        a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+        obs, rew, dones, infos = envs[0].step(a)
+        tobs_, trew, tterm, ttrunc, ttobs, tinfo = [x.cpu().numpy() for x in envs[1].step_tensors(torch.as_tensor(a, device="cuda"))]
+        assert obs.dtype == np.float64 and rew.dtype == np.float32 and dones.dtype == bool and len(infos) == n
+        assert np.array_equal(obs.astype(np.float32), tobs_) and np.array_equal(rew, trew)
+        assert np.array_equal(dones, (tterm | ttrunc).astype(bool))
+        for i in range(n):
+            if dones[i]:
+                finished += 1
+                assert np.array_equal(infos[i]["terminal_observation"].astype(np.float32), ttobs[i])
+                assert infos[i]["TimeLimit.truncated"] == bool(ttrunc[i] and not tterm[i])
+                assert infos[i]["episode"]["l"] == int(tinfo[i, 15]) and infos[i]["episode"]["r"] == float(tinfo[i, 14])
+            else:
+                assert infos[i] == {}
+    assert finished >= n   # the 7-step time limit alone ends every episode twice
+    for e in envs:
+        e.close()

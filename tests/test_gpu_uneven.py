@@ -82,10 +82,9 @@ def test_uneven_full_size_rollout_fp32(golden_dir):
 
 
 def test_uneven_fp32_close_to_oracle(oracle, golden_dir):
-    """the fp32 handle (row kernels, MODEL = 1: pose / kinematics / tendons / activations in fp64, stopping rule 3e-4) on identical
-    (state, action): BASELINE.json's 1e-4 on qpos and qvel.  The bar is 98 % of env-steps rather than the flat model's 99 %: rounding the
-    state to fp32 between env-steps alone flips a facet choice in ~1 % of them (an fp64 run from the rounded state has the same outliers,
-    tests/test_row_emulation.py)."""
+    """the fp32 handle (row kernels, MODEL = 1: pose in fp64 in HBM; pose / kinematics / tendons / activations / facet-plane distances /
+    implicitfast in fp64 inside the kernel) on identical (state, action): BASELINE.json's 1e-4 on qpos and qvel, small sample; the
+    classified 2048 x 8 sample is the next test."""
     from tensegrity_rl_amd import TensegrityVecEnv
     from tensegrity_rl_amd.vec_env import heights_from_image
     O = oracle
@@ -106,9 +105,25 @@ def test_uneven_fp32_close_to_oracle(oracle, golden_dir):
         eq.append(rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3)); ev.append(rel_env(st["qvel"] - v2, v2, 1e-2))
     eq, ev = np.concatenate(eq), np.concatenate(ev)
     print("uneven fp32: qpos median %.1e frac<1e-4 %.3f ; qvel median %.1e frac<1e-4 %.3f" % (np.median(eq), (eq < 1e-4).mean(), np.median(ev), (ev < 1e-4).mean()))
-    assert (eq < 1e-4).mean() >= 0.98 and (ev < 1e-4).mean() >= 0.98
+    assert np.isfinite(eq).all() and np.isfinite(ev).all()
+    assert (eq < 1e-4).mean() >= 0.99 and (ev < 1e-4).mean() >= 0.985
     assert np.median(eq) < 1e-6 and np.median(ev) < 2e-5
     env.close(); ob.close()
+
+
+@pytest.mark.parametrize("kind,qv_min,nonflip_max", [("tensegrity_env", 0.997, 0.0005), ("tr_env", 0.993, 0.004)])
+def test_fp32_uneven_outliers_are_classified_and_bounded(oracle, golden_dir, kind, qv_min, nonflip_max):
+    """2048 envs x 8 control periods on the heightfield, every env-step outside 1e-4 classified on the device's own sub-step trace
+    (tests/gpu_accuracy_report.py).  The heightfield has more discrete choices than the flat floor (facet, second facet, grid edge under a
+    bar), so flips are more frequent; what is NOT a flip is bounded in number and in size: tr_env's quasi-static robots (velocities of
+    mm/s against the 1e-2 floor of the relative error) keep ~0.4 % of env-steps between 1e-4 and 1e-3."""
+    from gpu_accuracy_report import run_case, summary
+    u = summary(run_case(kind, True, 2048, 8, terrain(golden_dir)))
+    assert u["nonfinite"] == 0
+    assert u["qpos_in"] >= 0.997 and u["qvel_in"] >= qv_min, u
+    assert u["capped"] + u["neither"] <= nonflip_max * u["n"] and u["worst_nonflip"] < 5e-3, u
+    assert u["worst_flip"] < 10.0, u
+    assert u["unconverged_fraction"] < 2e-2, u
 
 
 def test_gym_wrapper_selects_the_model_from_xml_file(golden_dir):

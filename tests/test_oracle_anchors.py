@@ -226,3 +226,70 @@ def test_uneven_model_settles_on_the_heightfield_and_carries_its_weight(oracle, 
             fzs.append(fz)
         assert abs(np.mean(fzs) - 12 * 9.81) < 0.05 * 12 * 9.81, (np.mean(fzs), fzs[:5])
         assert np.abs(O.arr(d.act) - np.clip(a, -0.45, 0.15)).max() < 0.1   # activations have followed the targets (tau = 1 s, 3 s)
+
+
+# ------------------------------------------------------------------ exact inverse-kinematics checks on MuJoCo-made numbers
+# `_last_original_obs` of best_models_pretrained/forward/SAC_5500000.zip -- a 39-dim tensegrity_env observation
+# (tensegrity_env.py:412-430) written by real MuJoCo mid-gait: three geom-frame quaternions (x, y, z, w) and nine tendon lengths, six
+# decimals each.  Three orientations + nine lengths over-determine the six relative bar coordinates by three.
+MJ_GEOM_QUATS = np.array([[-.180353, -.613728, .764173, .082762], [.243167, .726228, -.642295, -.030328], [-.358620, -.622310, .679296, .150597]])
+MJ_TENDONS = np.array([.223362, .222672, .236712, .218046, .159673, .181029, 1.290653, 1.290078, 1.291460])
+
+
+def _body_quat_from_obs(g):
+    """invert what _get_obs does: the observation holds scipy's (x, y, z, w) of the r-cylinder's GEOM frame = body frame * quat(0,0,0,1)
+    (flat xml:72): geom (x, y, z, w) = body (y, -x, w, -z)  ->  body (w, x, y, z) = (gz, -gy, gx, -gw)"""
+    q = np.array([g[2], -g[1], g[0], -g[3]])
+    return q / np.linalg.norm(q)
+
+
+def _fit_relative_positions(O, m, quats, tendons, starts=24):
+    from scipy.optimize import least_squares
+    L = O.lib(); d = O.new_data(m)
+
+    def res(x):
+        q = np.zeros(21)
+        for b in range(3):
+            q[7 * b + 3:7 * b + 7] = quats[b]
+        q[0:3] = (0, 0, 5.0); q[7:10] = x[:3] + (0, 0, 5.0); q[14:17] = x[3:] + (0, 0, 5.0)  # far above any floor: kinematics only
+        O.arr(d.qpos)[:] = q
+        L.tgo_forward(C.byref(m), C.byref(d))   # the oracle's own kinematics + tendon routine
+        return O.arr(d.ten_length) - tendons
+    rng = np.random.default_rng(0)
+    best = None
+    for _ in range(starts):
+        r = least_squares(res, rng.normal(0, 0.4, 6), xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        if best is None or r.cost < best.cost:
+            best = r
+    return best
+
+
+def test_mujoco_recorded_pose_fits_the_uneven_models_tendon_table_exactly(oracle):
+    """The recorded quaternions and tendon lengths are one rigid configuration of the UNEVEN-ground XML's robot (sites 0.05 m off the axis
+    in the permuted layout of uneven xml:76-81,122-158 -- the model these checkpoints were trained on, which is also why their action box
+    is the stale [-0.45, -0.15]): solving the six relative coordinates by least squares on the oracle's own forward
+    kinematics leaves 2.3e-7 m rms -- the truncation of the six-decimal record -- on nine equations.  That pins, against MuJoCo's own
+    output at a non-trivial state: the site table and tendon connectivity of model_kind 1, site_z = 0.668, the geom-frame convention
+    (body * 180 deg about z), scipy's scalar-last order and the tendon routine.  (Any wrong pairing, offset or convention misses by
+    centimetres: see the next test.)"""
+    O = oracle
+    quats = [_body_quat_from_obs(g) for g in MJ_GEOM_QUATS]
+    r = _fit_relative_positions(O, O.uneven_model(None), quats, MJ_TENDONS)
+    assert np.sqrt(np.mean(r.fun ** 2)) < 1e-6 and np.abs(r.fun).max() < 2e-6, r.fun
+    # and it is a sensible robot: bar centres 0.05 .. 0.5 m apart, no two bars through each other's axis
+    p = [np.zeros(3), r.x[:3], r.x[3:]]
+    dist = [np.linalg.norm(p[a] - p[b]) for a, b in ((0, 1), (0, 2), (1, 2))]
+    assert 0.05 < min(dist) and max(dist) < 0.5, dist
+
+
+def test_mujoco_recorded_pose_rejects_wrong_tables_and_conventions(oracle):
+    """the same fit is not forgiving: with the FLAT model's table (sites at 0.0675 in the other layout -- the checkpoint predates it), a
+    vector-first reading of the quaternions, or without the geom frame's half turn, nine tendon lengths cannot be matched to better than
+    centimetres"""
+    O = oracle
+    good = [_body_quat_from_obs(g) for g in MJ_GEOM_QUATS]
+    no_half_turn = [np.array([g[3], g[0], g[1], g[2]]) for g in MJ_GEOM_QUATS]          # geom frame taken for the body frame
+    scalar_first = [_body_quat_from_obs(np.roll(g, -1)) for g in MJ_GEOM_QUATS]         # (w, x, y, z) reading of the record
+    for model, quats in ((O.default_model(), good), (O.uneven_model(None), no_half_turn), (O.uneven_model(None), scalar_first)):
+        r = _fit_relative_positions(O, model, quats, MJ_TENDONS, starts=8)
+        assert np.sqrt(np.mean(r.fun ** 2)) > 3e-3, r.fun
