@@ -341,3 +341,70 @@ def test_step_and_step_tensors_return_the_same_values(golden_dir, env_id, model)
     assert finished >= n   # the 7-step time limit alone ends every episode twice
     for e in envs:
         e.close()
+
+
+def test_reset_streams_hand_out_a_class_stream_in_order(oracle):
+    """reset_stream_envs = B (results independent of the sharding): the k-th reset of a class of B consecutive global env ids
+    gets episode k of the class's stream, keyed (class key, k) -- whichever donor lane settled it, or the env itself when it was not ready.
+    fp64, 32 envs in two classes with 16 donor lanes each and a 3-step time limit: step 3 hands episodes 0..15 of each class to its envs in
+    env order (from donors), step 6 episodes 16..31 (nothing is ready: the envs settle them themselves); both are reset_model() under
+    (class key, episode) in the oracle."""
+    from tensegrity_rl_amd import TensegrityVecEnv
+    O = oracle
+    n, B = 32, 16
+    env = TensegrityVecEnv(n, "tensegrity_env-v0", precision="f64", max_episode_steps=3, seed=31, n_donors=32, reset_stream_envs=B, first_env_id=64)
+    env.reset()
+    cfg = O.make_cfg("tensegrity_env", "straight")
+    rng = np.random.default_rng(0)
+    for rnd in range(2):
+        for t in range(3):
+            obs, rew, dones, infos = env.step((-0.2 + 0.02 * rng.standard_normal((n, 6))).astype(np.float32))
+        assert dones.all()
+        st = env.get_state()
+        src = st["aux"][:, AUX["src"]].astype(int); ep = st["aux"][:, AUX["episode"]].astype(int)
+        assert (ep == np.tile(np.arange(B), n // B) + rnd * B).all(), ep          # in order within each class
+        assert (src >= n).all() and ((src - n) // 16 == np.arange(n) // B).all()   # keyed by a lane of the env's own class
+        keys = [env.lib.tgr_lane_key(env.handle, int(s)) for s in src]
+        assert len(set(keys)) == n // B and keys[0] != keys[-1]
+        for i in (0, 5, 15, 16, 31):
+            oe = O.OracleEnv(cfg)
+            oobs = oe.reset_seeded(31, keys[i], int(ep[i]))
+            assert np.abs(qfix(st["qpos"][i], O.arr(oe.data.qpos)) - O.arr(oe.data.qpos)).max() < 2e-4, (rnd, i)
+            assert np.abs(obs[i] - oobs).max() < 2e-3, (rnd, i)
+    s = env.stats()
+    assert s["donor_resets"] == n and s["settle_kernel_resets"] == n + 32 + n   # reset: envs + donors; second round: every env starved
+    env.close()
+
+
+@pytest.mark.parametrize("donors_per_env,limit", [(1.25, 5000), (0.25, 20)])
+def test_reset_streams_make_auto_reset_shard_invariant(donors_per_env, limit):
+    """the same 512 global envs stepped as part of a 1024-env handle and as a 512-env shard (first_env_id = 512), auto-reset on, random
+    actions, 150 steps across many resets: observations, rewards and done flags are bitwise equal at every step -- with plenty of donor
+    lanes, and with so few (and a 20-step time limit) that most resets are settled by the envs themselves."""
+    import torch
+    from tensegrity_rl_amd import TensegrityVecEnv
+    B, steps = 256, 150
+
+    def rollout(first, count):
+        env = TensegrityVecEnv(count, "tensegrity_env-v0", seed=42, first_env_id=first, reset_stream_envs=B, n_donors=int(donors_per_env * count),
+                               max_episode_steps=limit)
+        env.reset_tensors()
+        g = torch.Generator(device="cuda"); g.manual_seed(9)
+        outs = []
+        for t in range(steps):
+            a = (torch.rand((1024, 6), device="cuda", generator=g) * 0.6 - 0.45)[first:first + count].contiguous()
+            o, r, te, tr, tobs, _ = env.step_tensors(a)
+            outs.append((o.clone(), r.clone(), (te | tr).clone(), tobs.clone()))
+        s = env.stats(); env.close()
+        return outs, s
+
+    full, s_full = rollout(0, 1024)
+    part, s_part = rollout(512, 512)
+    resets = 0
+    for (o1, r1, d1, t1), (o2, r2, d2, t2) in zip(full, part):
+        assert torch.equal(o1[512:], o2) and torch.equal(r1[512:], r2) and torch.equal(d1[512:], d2)
+        assert torch.equal(t1[512:][d2.bool()], t2[d2.bool()])
+        resets += int(d2.sum())
+    assert resets > 512 and s_part["donor_resets"] > 0
+    if donors_per_env < 1:
+        assert s_part["settle_kernel_resets"] > 512 + int(donors_per_env * 512)   # starved resets did happen

@@ -293,3 +293,42 @@ def test_mujoco_recorded_pose_rejects_wrong_tables_and_conventions(oracle):
     for model, quats in ((O.default_model(), good), (O.uneven_model(None), no_half_turn), (O.uneven_model(None), scalar_first)):
         r = _fit_relative_positions(O, model, quats, MJ_TENDONS, starts=8)
         assert np.sqrt(np.mean(r.fun ** 2)) > 3e-3, r.fun
+
+
+def test_forward_policy_belongs_to_the_uneven_xml_robot(oracle, golden_dir):
+    """Why best_models_pretrained/forward trips the 1500 N rule (tensegrity_env.py:371) after ~40 steps on the CURRENT flat XML although its
+    training log shows ~1600-step episodes: it was trained on the robot of the uneven-ground XML (the inverse-kinematics test above pins
+    that from its recorded observation; its action box is that model's [-0.45, -0.15]).  Rolled out deterministically in this restatement,
+      * on the current flat XML (700 N/m passive tendons, affine actuators) every one of 16 rollouts trips within 150 steps -- cap-on-floor
+        impacts of 2.3 .. 2.9 kN at 1 .. 1.4 mm depth and r-cylinder crossings, bars spinning at 13 .. 34 rad/s: the policy's commands throw
+        the softer robot about;
+      * on the uneven XML's robot (1e4 N/m tendons, gain-15000 filter actuators, 5 cm caps) standing on a flat floor, at most 2 of 16 trip
+        within 400 steps and the robots travel ~2 m in 8 s.
+    So the short episodes are a property of pairing that checkpoint with the newer XML, not a sign of inflated contact forces here; and the
+    uneven model's tendon / actuator constants carry a MuJoCo-trained gait for 8 s."""
+    import os
+    O = oracle
+    g = np.load(os.path.join(golden_dir, "policy_forward.npz"))
+    W = [g[k].astype(np.float64) for k in ("latent_pi_0_weight", "latent_pi_2_weight", "mu_weight")]
+    B = [g[k].astype(np.float64) for k in ("latent_pi_0_bias", "latent_pi_2_bias", "mu_bias")]
+    lo, hi = float(g["low"]), float(g["high"])
+    n = 16
+    out = {}
+    for name, kw, steps in (("flat", {}, 150), ("uneven-robot", dict(model_kind=1), 400)):
+        ob = O.OracleBatch(O.make_cfg("tensegrity_env", "straight", **kw), n, seed=1234)
+        obs = ob.reset()
+        x0 = np.array([O.arr(ob.env(i).data.xpos)[:, :2].mean(axis=0) for i in range(n)])
+        tripped = np.zeros(n, bool)
+        for t in range(steps):
+            h = obs
+            for i in range(2):
+                h = np.maximum(h @ W[i].T + B[i], 0)
+            a = (lo + 0.5 * (np.tanh(h @ W[2].T + B[2]) + 1) * (hi - lo)).astype(np.float32)
+            obs = ob.step(a, auto_reset=False)[0]
+            for i in range(n):
+                tripped[i] |= bool(np.abs(O.arr(ob.env(i).data.cfrc_ext)).max() > 1500)
+        travel = np.linalg.norm(np.array([O.arr(ob.env(i).data.xpos)[:, :2].mean(axis=0) for i in range(n)]) - x0, axis=1)
+        out[name] = (int(tripped.sum()), float(travel.mean()))
+        ob.close()
+    assert out["flat"][0] == n, out
+    assert out["uneven-robot"][0] <= 2 and out["uneven-robot"][1] > 1.0, out
