@@ -142,6 +142,12 @@ typedef struct tgr_config {
    * ... handed out strictly in order: the k-th reset of a class gets episode k.  Any sharding whose shards are whole classes (n_envs and
    * first_env_id multiples of B) then gives every env the same trajectory, resets included.  Costs the paced donor rows */
   int32_t reset_stream_envs;
+  /* donor stream: 0 (default) = auto, 1 = off, 2 = required.  On: the donor lanes (episodes being settled for the next resets) are stepped
+   * by their own launches on a second, lower-priority HIP stream the handle owns, one per tgr_step, concurrently with the launch that steps
+   * the live envs on the caller's stream; hand-over is ordered by HIP events and launch indices, so results do not depend on how the two
+   * streams overlap.  Off: one launch steps live and donor rows together (round-2 behaviour, paced donor rows).  Auto = on
+   * whenever the handle has donor lanes, is stepped by the row kernels and n_envs is a multiple of 4 */
+  int32_t donor_stream;
 } tgr_config;
 
 typedef struct tgr_handle tgr_handle;

@@ -38,7 +38,7 @@ class Config(C.Structure):
         ("waypt_reward_amplitude", f64), ("waypt_reward_stdev", f64), ("yaw_reward_weight", f64), ("solver_warm_start", i32),
         ("use_obs_noise", i32), ("obs_noise_tendon_stdev", f64), ("obs_noise_cap_pos_stdev", f64),
         ("model_kind", i32), ("site_offset", f64), ("act_tau", f64), ("hf_size", f64 * 4), ("hf_pos", f64 * 3),
-        ("reset_noise_scale", f64), ("kernel_layout", i32), ("solver_rel_tolerance", f64), ("reset_stream_envs", i32),
+        ("reset_noise_scale", f64), ("kernel_layout", i32), ("solver_rel_tolerance", f64), ("reset_stream_envs", i32), ("donor_stream", i32),
     ]
 
 

@@ -65,6 +65,17 @@ template <typename T> struct KArgs {
   int* cls;       // reset streams: per class {next episode to start settling, next episode to hand out}
   int* holder;    // reset streams: per class, which donor lane holds episode (ep % stream_table)
   int stream_table;
+  // donor stream (tgr_config.donor_stream): the donor lanes are stepped by their own launches on a second, lower-priority HIP stream, one
+  // per tgr_step, concurrently with the live launch -- no launch boundary is shared.  The two sides never write the same word:
+  //   dready[lane]   (donor side)  launch index at which the lane's episode became ready, 0 while it is settling
+  //   dapplied[lane] (donor side)  tag of the last command the lane has carried out
+  //   dcmd[lane]     (match side)  episode << 32 | tag: "start a new episode" (tag = index of the step whose match kernel issued it)
+  //   consumed[lane] (match side)  the dready value of the episode that was handed out last
+  // Step i's match kernel waits (HIP event) for donor launch i - 1 and only trusts dready <= i - 1; donor launch j waits for the match kernel of
+  // step j - 1 and only carries out commands with tag <= j - 1.  What either side sees is thus a function of launch indices alone -- results
+  // do not depend on how the two streams happen to overlap.
+  int async, launch_idx, lane_base, lane_limit;
+  unsigned long long* dcmd; int* dapplied; int* dready; int* consumed;
   uint8_t* doneflag;
   T* dobs;  // reset observations of the donors [m-n][D]
   unsigned long long* counters;
@@ -644,6 +655,7 @@ TGR_DEV void finish_lane(const KArgs<T>& k, Sim<T>& S, const Lag<T>& lag, int e,
         if (E.use_obs_noise) apply_obs_noise<T, ZEXT>(E, lane_key(E, n, e), (unsigned)k.ist[I_SRCEP * m + e], 0, orow, zext);
         T* op = k.dobs + (size_t)(e - n) * D;
         for (int i = 0; i < D; i++) op[i] = orow[i];
+        if (k.async) k.dready[e] = k.launch_idx;  // (donor stream: ready as of this donor launch)
       }
     }
   }
@@ -924,13 +936,19 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   // field they share is fetched into one L2 instead of eight (19 -> 5 MB fetched per launch).  The launch pads the grid to a multiple of 64.
   const int bx = (int)blockIdx.x;
   const int lb = (bx & ~63) | ((bx & 7) << 3) | ((bx >> 3) & 7);
-  const int gid = lb * ROW_ENVS + slot;
+  const int gid = k.lane_base + lb * ROW_ENVS + slot;
   const int n = k.n, m = k.m;
-  const bool valid = gid < m;
+  const bool valid = gid < k.lane_limit;
   const int e = valid ? gid : m - 1;
   const EnvCfg<T>& E = k.E;
   const bool live = valid && e < n;  // (rows past the end do nothing at all)
   int phase = k.ist[I_PHASE * m + e];
+  unsigned long long cmd = 0ull;
+  if (k.async && valid && e >= n) {  // donor stream: a command of an earlier step's match kernel that this lane has not carried out yet
+    cmd = k.dcmd[e];
+    const int tag = (int)(unsigned)(cmd & 0xffffffffull);
+    if (tag != 0 && tag != k.dapplied[e] && tag < k.launch_idx) phase = PH_INIT;
+  }
   const bool donor_run = valid && e >= n && (phase > 0 || phase == PH_INIT);
   const bool active = live || donor_run;
   const int total = settle_total(E);
@@ -939,13 +957,14 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   // then run a whole period.  Those are the highest-indexed busy donors.  The donor rows from slow_e on therefore advance HALF a
   // control period per launch (same sub-steps in the same order, over two launches; I_HALF says which half is due): half as long,
   // they end before the longest first-round wavefront does.  Wavefront-uniform: slow_e and the rows of a wavefront are multiples of 4.
-  const bool slow = lb * ROW_ENVS >= k.slow_e;
+  const bool slow = k.lane_base + lb * ROW_ENVS >= k.slow_e;
   const int nsub = slow ? E.frame_skip / 2 : E.frame_skip;
   row::RLag<TK, T> rl;
   row_lag_init<T, TK>(rl);
   if (__any(active)) {  // (a wavefront of idle donor rows has nothing to do)
     const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r, (k.dbg && live) ? k.dbg + (size_t)e * row::TRACE_WORDS : nullptr);
     int episode = k.ist[I_EPISODE * m + e];
+    if (k.async && E.stream_envs > 0 && cmd != 0ull) episode = (int)(unsigned)(cmd >> 32);  // reset streams: the command names the episode
     if (donor_run && phase == PH_INIT) {
       Sim<T> S0;
       init_episode(E, lane_key(E, n, e), (unsigned long long)(unsigned)episode, S0, (double*)(sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16)));
@@ -976,20 +995,26 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   {
     const int r = (int)(tx2 & 15u), slot = (int)(tx2 >> 4);
     const int lb = (int)((bx2 & ~63u) | ((bx2 & 7u) << 3) | ((bx2 >> 3) & 7u));
-    const int gid = lb * ROW_ENVS + slot;
+    const int gid = k.lane_base + lb * ROW_ENVS + slot;
     const int n = k.n, m = k.m;
-    const bool valid = gid < m;
+    const bool valid = gid < k.lane_limit;
     const int e = valid ? gid : m - 1;
     const EnvCfg<T>& E = k.E;
     const bool live = valid && e < n;
     int phase = k.ist[I_PHASE * m + e];  // (only written below)
+    int cmd_tag = 0;
+    if (k.async && valid && e >= n) {
+      const int tag = (int)(unsigned)(k.dcmd[e] & 0xffffffffull);
+      if (tag != 0 && tag != k.dapplied[e] && tag < k.launch_idx) { phase = PH_INIT; cmd_tag = tag; }
+    }
     const bool donor_run = valid && e >= n && (phase > 0 || phase == PH_INIT);
     const bool active = live || donor_run;
     const int total = settle_total(E);
     const int D = E.obs_dim;
     if (!__any(active)) return;
-    const bool slow = lb * ROW_ENVS >= k.slow_e;
+    const bool slow = k.lane_base + lb * ROW_ENVS >= k.slow_e;
     const int nsub = slow ? E.frame_skip / 2 : E.frame_skip;
+    if (cmd_tag && (tx2 & 15u) == 0) { k.dapplied[e] = cmd_tag; k.dready[e] = 0; }  // (the command is carried out; the episode is not ready)
     // a paced row that has just been set up, or whose half flag is clear, has run the FIRST half of its period
     const bool first_half = slow && donor_run && (phase == PH_INIT || k.ist[I_HALF * m + e] == 0);
     if (donor_run && phase == PH_INIT) phase = total;  // (the episode was set up at the top)
@@ -1099,6 +1124,7 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   k.ist[I_SRCEP * m + e] = episode;
   if (sep < 0) k.ist[I_EPISODE * m + e] = episode + 1;  // (a stream episode does not advance the env's own counter of explicit resets)
   k.ist[I_PHASE * m + e] = e < n ? PH_LIVE : PH_READY;
+  if (k.async && e >= n) { k.dready[e] = k.launch_idx; k.consumed[e] = 0; k.dcmd[e] = 0ull; k.dapplied[e] = 0; }  // (full reset: the streams are idle)
   atomicAdd(&k.counters[1], 1ull);
   if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
   const int D = E.obs_dim;
@@ -1203,8 +1229,15 @@ template <typename T> __global__ __launch_bounds__(1024) void match_kernel(KArgs
     if (tid == NT - 1) *total_out = cnt[tid];
     __syncthreads();
   };
+  // a donor lane whose settled episode can be handed out: phase READY -- or, with the donor stream, ready as of a donor launch that has
+  // completed (dready < this step's index) and not handed out yet
+  auto donor_ready = [&](int lane) {
+    if (!k.async) return k.ist[I_PHASE * m + lane] == PH_READY;
+    const int rd = k.dready[lane];
+    return rd != 0 && rd < k.launch_idx && rd != k.consumed[lane];
+  };
   compact(n, [&](int i) { return k.doneflag[i] != 0; }, k.list, &nd_s);
-  compact(nd_lanes, [&](int i) { return k.ist[I_PHASE * m + n + i] == PH_READY; }, k.rlist, &nr_s);
+  compact(nd_lanes, [&](int i) { return donor_ready(n + i); }, k.rlist, &nr_s);
   const int nd = nd_s, nr = nr_s;
   const int pairs = min(nd, nr);
   const int D = k.E.obs_dim;
@@ -1228,8 +1261,8 @@ template <typename T> __global__ __launch_bounds__(1024) void match_kernel(KArgs
     k.ist[I_RINGHEAD * m + slot] = k.ist[I_RINGHEAD * m + donor];
     k.ist[I_SRC * m + slot] = donor;
     k.ist[I_SRCEP * m + slot] = k.ist[I_SRCEP * m + donor];
-    k.ist[I_PHASE * m + donor] = PH_INIT;
-    k.ist[I_HALF * m + donor] = 0;
+    if (k.async) { k.consumed[donor] = k.dready[donor]; k.dcmd[donor] = (unsigned long long)(unsigned)k.launch_idx; }
+    else { k.ist[I_PHASE * m + donor] = PH_INIT; k.ist[I_HALF * m + donor] = 0; }
     k.doneflag[slot] = 0;
   }
   __syncthreads();
@@ -1282,11 +1315,15 @@ template <typename T> __global__ __launch_bounds__(256) void match_kernel_stream
   if (tid == 0) nr_s = 0;
   for (int j = tid; j < Dc; j += NT) rl[j] = -1;
   __syncthreads();
-  for (int j = tid; j < Dc; j += NT)
-    if (k.ist[I_PHASE * m + d0 + j] == PH_READY) {
+  for (int j = tid; j < Dc; j += NT) {
+    bool ready;
+    if (k.async) { const int rd = k.dready[d0 + j]; ready = rd != 0 && rd < k.launch_idx && rd != k.consumed[d0 + j]; }
+    else ready = k.ist[I_PHASE * m + d0 + j] == PH_READY;
+    if (ready) {
       const int off = k.ist[I_SRCEP * m + d0 + j] - next_hand;
       if (off >= 0 && off < Dc) { rl[off] = d0 + j; atomicAdd(&nr_s, 1); }
     }
+  }
   __syncthreads();
   const int nd = nd_s;
   if (nd == 0) return;
@@ -1320,9 +1357,14 @@ template <typename T> __global__ __launch_bounds__(256) void match_kernel_stream
     k.ist[I_SRC * m + slot] = donor;
     k.ist[I_SRCEP * m + slot] = k.ist[I_SRCEP * m + donor];
     // the donor starts the next episode nobody has started yet
-    k.ist[I_PHASE * m + donor] = PH_INIT;
-    k.ist[I_EPISODE * m + donor] = next_start + p;
-    k.ist[I_HALF * m + donor] = 0;
+    if (k.async) {
+      k.consumed[donor] = k.dready[donor];
+      k.dcmd[donor] = ((unsigned long long)(unsigned)(next_start + p) << 32) | (unsigned long long)(unsigned)k.launch_idx;
+    } else {
+      k.ist[I_PHASE * m + donor] = PH_INIT;
+      k.ist[I_EPISODE * m + donor] = next_start + p;
+      k.ist[I_HALF * m + donor] = 0;
+    }
     hold[(next_start + p) & (TB - 1)] = donor;
     k.doneflag[slot] = 0;
   }
@@ -1340,9 +1382,8 @@ template <typename T> __global__ __launch_bounds__(256) void match_kernel_stream
         k.doneflag[env] = 0;
         if (ep < next_start) {  // somebody is settling it (or holds it behind a gap): re-arm that donor
           const int donor = hold[ep & (TB - 1)];
-          k.ist[I_PHASE * m + donor] = PH_INIT;
-          k.ist[I_EPISODE * m + donor] = fresh;
-          k.ist[I_HALF * m + donor] = 0;
+          if (k.async) k.dcmd[donor] = ((unsigned long long)(unsigned)fresh << 32) | (unsigned long long)(unsigned)k.launch_idx;
+          else { k.ist[I_PHASE * m + donor] = PH_INIT; k.ist[I_EPISODE * m + donor] = fresh; k.ist[I_HALF * m + donor] = 0; }
           hold[fresh & (TB - 1)] = donor;
           fresh++;
         }
@@ -1404,6 +1445,12 @@ struct tgr_handle {
   int* cls = nullptr;
   int* holder = nullptr;
   int n_classes = 0, stream_donors = 0, stream_table = 0;
+  // donor stream (see KArgs)
+  bool async = false;
+  int launch = 1;  // index of the last tgr_step (donor launches and match kernels are numbered by it)
+  hipStream_t sb = nullptr;
+  hipEvent_t ev_donor[2] = {nullptr, nullptr}, ev_match = nullptr;
+  unsigned long long* dcmd = nullptr; int* dapplied = nullptr; int* dready = nullptr; int* consumed = nullptr;
   uint8_t* doneflag = nullptr;
   unsigned long long* counters = nullptr;
   float* hf = nullptr;  // heightfield elevations (model_kind 1)
@@ -1429,6 +1476,10 @@ static void free_handle(tgr_handle* h) {
   (void)hipFree(h->st); (void)hipFree(h->ist); (void)hipFree(h->ring); (void)hipFree(h->dobs); (void)hipFree(h->list_count);
   (void)hipFree(h->list); (void)hipFree(h->rlist); (void)hipFree(h->doneflag); (void)hipFree(h->counters);
   (void)hipFree(h->list_ep); (void)hipFree(h->cls); (void)hipFree(h->holder);
+  (void)hipFree(h->dcmd); (void)hipFree(h->dapplied); (void)hipFree(h->dready); (void)hipFree(h->consumed);
+  if (h->sb) (void)hipStreamDestroy(h->sb);
+  for (int i = 0; i < 2; i++) if (h->ev_donor[i]) (void)hipEventDestroy(h->ev_donor[i]);
+  if (h->ev_match) (void)hipEventDestroy(h->ev_match);
   delete h;
 }
 
@@ -1599,16 +1650,18 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
     int from = round_rows > h->n + donors / 2 ? round_rows : h->n + donors / 2;
     from = ((from + 3) / 4) * 4;
     // (reset streams hand episodes out in the order they were started: every donor must need the same number of launches)
-    bool pace = c.auto_reset && donors >= 64 && (c.frame_skip % 2) == 0 && h->n < round_rows && from < h->m && h->n_classes == 0;
+    bool pace = c.auto_reset && donors >= 64 && (c.frame_skip % 2) == 0 && h->n < round_rows && from < h->m && h->n_classes == 0 && !h->async;
     if (h->pace_from >= 0) {  // test hook (tests/test_gpu_reset_vecenv.py): which rows are paced no longer depends on n or the CU count
       from = ((h->pace_from > h->n ? h->pace_from : h->n) + 3) / 4 * 4;
-      pace = c.auto_reset && donors > 0 && (c.frame_skip % 2) == 0 && from < h->m && h->n_classes == 0;
+      pace = c.auto_reset && donors > 0 && (c.frame_skip % 2) == 0 && from < h->m && h->n_classes == 0 && !h->async;
     }
     k.slow_e = pace ? from : h->m + 4;
   }
   k.st = (T*)h->st; k.ist = h->ist; k.ring = (T*)h->ring; k.dobs = (T*)h->dobs; k.hp = h->hp;
   k.list_count = h->list_count; k.list = h->list; k.rlist = h->rlist; k.doneflag = h->doneflag; k.counters = h->counters;
   k.list_ep = h->list_ep; k.cls = h->cls; k.holder = h->holder; k.stream_table = h->stream_table;
+  k.async = h->async ? 1 : 0; k.launch_idx = h->launch; k.lane_base = 0; k.lane_limit = h->m;
+  k.dcmd = h->dcmd; k.dapplied = h->dapplied; k.dready = h->dready; k.consumed = h->consumed;
   k.auto_reset = c.auto_reset;
   k.actions = nullptr; k.obs = nullptr; k.reward = nullptr; k.terminated = nullptr; k.truncated = nullptr;
   k.terminal_obs = nullptr; k.info = nullptr; k.obs_reset = nullptr; k.obs_clean = nullptr; k.dbg = nullptr;
@@ -1637,6 +1690,17 @@ static int alloc_handle(tgr_handle* h, int n_envs, int donors) {
   HIP_TRY(h, hipMemset(h->list_count, 0, sizeof(int)));
   HIP_TRY(h, hipMalloc((void**)&h->list, sizeof(int) * m));
   HIP_TRY(h, hipMalloc((void**)&h->rlist, sizeof(int) * 2 * m));
+  if (h->async) {
+    int least = 0, greatest = 0;
+    HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(h, hipStreamCreateWithPriority(&h->sb, hipStreamNonBlocking, least));
+    for (int i = 0; i < 2; i++) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_donor[i], hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_match, hipEventDisableTiming));
+    HIP_TRY(h, hipMalloc((void**)&h->dcmd, sizeof(unsigned long long) * m)); HIP_TRY(h, hipMemset(h->dcmd, 0, sizeof(unsigned long long) * m));
+    HIP_TRY(h, hipMalloc((void**)&h->dapplied, sizeof(int) * m)); HIP_TRY(h, hipMemset(h->dapplied, 0, sizeof(int) * m));
+    HIP_TRY(h, hipMalloc((void**)&h->dready, sizeof(int) * m)); HIP_TRY(h, hipMemset(h->dready, 0, sizeof(int) * m));
+    HIP_TRY(h, hipMalloc((void**)&h->consumed, sizeof(int) * m)); HIP_TRY(h, hipMemset(h->consumed, 0, sizeof(int) * m));
+  }
   if (h->n_classes > 0) {
     HIP_TRY(h, hipMalloc((void**)&h->list_ep, sizeof(int) * m));
     HIP_TRY(h, hipMemset(h->list_ep, 0xff, sizeof(int) * m));
@@ -1726,6 +1790,14 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
     while (h->stream_table < 2 * h->stream_donors) h->stream_table <<= 1;
   }
   h->m = n_envs + donors;
+  // donor stream: 0 = auto (on whenever the handle has donor lanes, is stepped by the row kernels and n_envs is a multiple of the four rows
+  // of a wavefront), 1 = off (one launch steps live and donor rows, paced donor rows), 2 = required
+  {
+    const bool can = donors > 0 && use_row_kernels(h) && n_envs % 4 == 0;
+    if (cfg->donor_stream == 2 && !can) { g_err = "tgr_create: donor_stream needs donor lanes, the row kernels and n_envs % 4 == 0"; delete h; return TGR_ERR_INVALID; }
+    h->async = cfg->donor_stream != 1 && can;
+    if (const char* v = getenv("TGR_DONOR_STREAM")) { if (atoi(v) == 0) h->async = false; }  // (A/B measurements)
+  }
   *out = nullptr;
   const int rc = alloc_handle(h, n_envs, donors);
   if (rc != TGR_OK) {  // nothing half-built leaves this function: the message moves to the thread's slot, the handle is freed
@@ -1836,6 +1908,7 @@ template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, 
     for (int i = h->n; i < h->m; i++) idx.push_back(i);
   int cnt = (int)idx.size();
   if (cnt == 0) return TGR_OK;
+  if (h->async && !mask) HIP_TRY(h, hipStreamSynchronize(h->sb));  // (a full reset rewrites the donor lanes: their stream must be idle)
   if (h->n_classes > 0) {
     // reset streams: explicit resets of live envs run under the env's own key; a full reset also deals each class's donors the next
     // stream_donors episodes of its stream (donor j of the class: episode next_start + j), ready to be handed out in that order
@@ -1877,6 +1950,11 @@ template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, 
   }
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->list_count, 0, sizeof(int), s));
+  if (h->async && !mask) {
+    // the next donor launch waits for this settle kernel; the next match kernel finds "the previous donor launch" complete
+    HIP_TRY(h, hipEventRecord(h->ev_match, s));
+    for (int i = 0; i < 2; i++) HIP_TRY(h, hipEventRecord(h->ev_donor[i], h->sb));
+  }
   return TGR_OK;
 }
 
@@ -1907,14 +1985,36 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
   constexpr int LW = LaneW<T>::value;
   const bool rowk = use_row_kernels(h);
   RowArgs<T, double> ra;
+  if (h->async) h->launch += 1;  // this step's index: its donor launch and its match kernel carry it
+  k.launch_idx = h->launch;
   if (rowk) {
     fill_row_args<T>(h, k, ra);
-    if (h->cfg.model_kind) {
-      constexpr int NE = row_envs<T, 1>();
-      hipLaunchKernelGGL((step_kernel_row<T, double, 1>), dim3((((h->m + NE - 1) / NE + 63) / 64) * 64), dim3(16 * NE), 0, s, k, ra);
+    auto launch_rows = [&](const KArgs<T>& kk, int lanes, hipStream_t st) {
+      if (h->cfg.model_kind) {
+        constexpr int NE = row_envs<T, 1>();
+        hipLaunchKernelGGL((step_kernel_row<T, double, 1>), dim3((((lanes + NE - 1) / NE + 63) / 64) * 64), dim3(16 * NE), 0, st, kk, ra);
+      } else {
+        constexpr int NE = row_envs<T, 0>();
+        hipLaunchKernelGGL((step_kernel_row<T, double, 0>), dim3((((lanes + NE - 1) / NE + 63) / 64) * 64), dim3(16 * NE), 0, st, kk, ra);
+      }
+    };
+    if (h->async) {
+      // live rows on the caller's stream; the donor rows advance one control period on their own low-priority stream, concurrently --
+      // after the match kernel of the previous step (whose commands this launch carries out)
+      k.lane_base = 0; k.lane_limit = h->n;
+      launch_rows(k, h->n, s);
+      HIP_TRY(h, hipGetLastError());
+      KArgs<T> kd = k;
+      kd.lane_base = h->n; kd.lane_limit = h->m; kd.dbg = nullptr;
+      HIP_TRY(h, hipStreamWaitEvent(h->sb, h->ev_match, 0));
+      launch_rows(kd, h->m - h->n, h->sb);
+      HIP_TRY(h, hipGetLastError());
+      HIP_TRY(h, hipEventRecord(h->ev_donor[h->launch & 1], h->sb));
+      // this step's match kernel reads the donor lanes as the PREVIOUS donor launch left them
+      HIP_TRY(h, hipStreamWaitEvent(s, h->ev_donor[(h->launch - 1) & 1], 0));
+      k.lane_base = 0; k.lane_limit = h->m;
     } else {
-      constexpr int NE = row_envs<T, 0>();
-      hipLaunchKernelGGL((step_kernel_row<T, double, 0>), dim3((((h->m + NE - 1) / NE + 63) / 64) * 64), dim3(16 * NE), 0, s, k, ra);
+      launch_rows(k, h->m, s);
     }
   } else {
 #ifndef TGR_FAST_BUILD
@@ -1946,6 +2046,7 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
 #endif
     }
     HIP_TRY(h, hipGetLastError());
+    if (h->async) HIP_TRY(h, hipEventRecord(h->ev_match, s));
   }
   return TGR_OK;
 }

@@ -100,7 +100,7 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
     if "kernel_layout" in kwargs:
         cfg.kernel_layout = N.KERNEL_LAYOUT[kwargs.pop("kernel_layout")]
     for k in ("actuator_deriv_skip_clamped", "solver_tolerance", "solver_rel_tolerance", "solver_iterations", "n_donors", "solver_warm_start",
-              "reset_stream_envs"):
+              "reset_stream_envs", "donor_stream"):
         if k in kwargs:
             setattr(cfg, k, type(getattr(cfg, k))(kwargs.pop(k)))
     if kwargs:

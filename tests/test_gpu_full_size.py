@@ -1,0 +1,68 @@
+"""-m gpu: BASELINE-size rollouts of the env run.py actually drives (tr_env-v0, run.py:8), with auto-reset, as size-independent properties:
+bitwise determinism, finite outputs, unit quaternions, device counters inside their bounds, resets served by donor lanes."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rollout(n, steps, env_id="tr_env-v0", seed=7, **kw):
+    import torch
+    from tensegrity_rl_amd import TensegrityVecEnv
+    env = TensegrityVecEnv(n, env_id, seed=seed, **kw)
+    env.reset_tensors()
+    s0 = env.stats()
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    outs, bad, dones = [], 0, 0
+    for t in range(steps):
+        o, r, te, tr, tobs, info = env.step_tensors(torch.rand((n, 6), device="cuda", generator=g) * 0.6 - 0.45)
+        if t % 16 == 15 or t == steps - 1:
+            outs.append((o.clone(), r.clone(), (te | tr).clone()))
+            bad += int((~torch.isfinite(o).all(dim=1)).sum().item()) + int((~torch.isfinite(r)).sum().item())
+        dones += int((te | tr).sum().item())
+    s1 = env.stats()
+    st = env.get_state()
+    env.close()
+    return outs, bad, dones, s0, s1, st
+
+
+def test_full_size_tr_env_flat_auto_reset_rollout():
+    """4096 envs of tr_env-v0 (45-dim observations, action filter) on the flat floor, 160 steps of random actions with a 40-step time limit
+    so that every env restarts four times from donor lanes: twice the same bits, everything finite, counters bounded, (almost) nobody starved."""
+    n, steps = 4096, 160
+    a = _rollout(n, steps, max_episode_steps=40)
+    b = _rollout(n, steps, max_episode_steps=40)
+    import torch
+    for (o1, r1, d1), (o2, r2, d2) in zip(a[0], b[0]):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    outs, bad, dones, s0, s1, st = a
+    assert bad == 0 and dones >= 4 * n
+    lane = s1["lane_substeps"] - s0["lane_substeps"]
+    assert s1["unconverged_lane_substeps"] - s0["unconverged_lane_substeps"] < 0.002 * lane, s1
+    assert s1["dropped_contacts"] - s0["dropped_contacts"] < 3e-4 * n * steps, s1
+    # (four synchronised TimeLimit waves of 4096 against 8192 donor lanes: all but a handful are served by a donor)
+    assert s1["donor_resets"] - s0["donor_resets"] >= 3 * n and s1["settle_kernel_resets"] - s0["settle_kernel_resets"] <= 16, s1
+    q = st["qpos"].reshape(n, 3, 7)[:, :, 3:]
+    assert np.abs(np.linalg.norm(q, axis=2) - 1).max() < 1e-5 and np.isfinite(st["qvel"]).all()
+    assert st["aux"][:, 6].max() < 40   # TimeLimit clock (elapsed) restarted with every reset
+
+
+def test_full_size_tr_env_uneven_rollout_crosses_resets(golden_dir):
+    """BASELINE config #4's size: 8192 envs of tr_env-v0 on the heightfield, 100 steps with a 30-step time limit (three waves of resets):
+    deterministic, finite, on the terrain, counters bounded."""
+    import torch
+    n, steps = 8192, 100
+    kw = dict(model="uneven", terrain=np.load(os.path.join(golden_dir, "terrain_100.npy")), max_episode_steps=30)
+    a = _rollout(n, steps, **kw)
+    b = _rollout(n, steps, **kw)
+    for (o1, r1, d1), (o2, r2, d2) in zip(a[0], b[0]):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    outs, bad, dones, s0, s1, st = a
+    assert bad == 0 and dones >= 3 * n
+    lane = s1["lane_substeps"] - s0["lane_substeps"]
+    assert s1["unconverged_lane_substeps"] - s0["unconverged_lane_substeps"] < 0.02 * lane, s1
+    assert s1["donor_resets"] - s0["donor_resets"] >= 2 * n, s1
+    z = st["qpos"].reshape(n, 3, 7)[:, :, 2]
+    assert z.max() < 0.6 and z.min() > -1.3 and np.isfinite(st["qpos"]).all()   # standing on the terrain (z in [-1, 0]), not on a z = 0 plane

@@ -288,7 +288,7 @@ def test_paced_donor_rows_settle_the_same_episodes(oracle, monkeypatch):
     O = oracle
     n = 16
     monkeypatch.setenv("TGR_PACE_FROM", "32")
-    env = TensegrityVecEnv(n, "tensegrity_env-v0", precision="f64", max_episode_steps=3, seed=21, n_donors=32)
+    env = TensegrityVecEnv(n, "tensegrity_env-v0", precision="f64", max_episode_steps=3, seed=21, n_donors=32, donor_stream=1)  # (one fused launch)
     monkeypatch.delenv("TGR_PACE_FROM")
     env.reset()
     rng = np.random.default_rng(0)
