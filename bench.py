@@ -30,7 +30,7 @@ def profiled():
     WRITE_SIZE in separate passes, KB per dispatch, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note; SQ_INSTS_VALU).  They are
     NOT measured by this run: the line says where they come from, and they are dropped (null) when the kernel sources have changed
     since the profile was taken (hash of csrc/ + build flags stored with the profile)."""
-    out = {"traffic": None, "valu_per_launch": None, "source": None}
+    out = {"traffic": None, "valu_per_launch": None, "source": None, "launches": None}
     try:
         from tensegrity_rl_amd import build as _b
         d = json.load(open(PROFILE))
@@ -39,9 +39,13 @@ def profiled():
             return out
         kn = d["dominant_kernel"]
         fe, wr, sq = d["fetch"][kn], d["write"][kn], d["sq"][kn]
-        out["traffic"] = (2.0 * fe["FETCH_SIZE"] / fe["dispatches"] + wr["WRITE_SIZE"] / wr["dispatches"]) * 1024.0
-        out["valu_per_launch"] = sq["SQ_INSTS_VALU"] / sq["dispatches"]
-        out["source"] = f"{os.path.relpath(PROFILE, ROOT)} ({kn}, src_hash {d['src_hash'][:12]})"
+        # with the donor stream a step is TWO dispatches of this kernel (live rows, donor rows): the counters are summed over both, per step
+        per_step = 2 if len(d.get("step_kernel_row_by_grid_threads", {})) > 1 else 1
+        out["traffic"] = (2.0 * fe["FETCH_SIZE"] / fe["dispatches"] + wr["WRITE_SIZE"] / wr["dispatches"]) * 1024.0 * per_step
+        out["valu_per_launch"] = sq["SQ_INSTS_VALU"] / sq["dispatches"] * per_step
+        out["launches"] = d.get("step_kernel_row_by_grid_threads")
+        out["source"] = (f"{os.path.relpath(PROFILE, ROOT)} ({kn}, src_hash {d['src_hash'][:12]}; per step = {per_step} dispatch(es) of the kernel: "
+                         "live rows on the caller's stream + donor rows on the donor stream)")
     except Exception as e:
         out["source"] = f"no profile ({type(e).__name__})"
     return out
@@ -283,7 +287,7 @@ def main():
         resets = stats1["donor_resets"] - stats0["donor_resets"] + stats1["settle_kernel_resets"] - stats0["settle_kernel_resets"]
         # the committed counters belong to the default command: attach them to that workload only
         default_workload = args.model == "flat" and args.env_id == "tensegrity_env-v0" and n_local == 4096 and row_layout and args.donors is None
-        prof = profiled() if default_workload else {"traffic": None, "valu_per_launch": None, "source": "not the profiled (default) workload"}
+        prof = profiled() if default_workload else {"traffic": None, "valu_per_launch": None, "launches": None, "source": "not the profiled (default) workload"}
         lane_sub = max(stats1["lane_substeps"] - stats0["lane_substeps"], 1)
         ulf = useful_lane_fraction()
         valu_rate = (prof["valu_per_launch"] * 64 / (kern_ms * 1e-3)) if prof["valu_per_launch"] else None
@@ -305,10 +309,12 @@ def main():
                        "starved_resets_rank0": stats1["settle_kernel_resets"] - stats0["settle_kernel_resets"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": prof["traffic"], "traffic_source": prof["source"],
-                         "note": "step kernel: 674 algorithmic B per env-step x envs per launch / mean launch duration (HIP events around "
-                                 "the step+match+settle launches of one step); the path is VALU-issue bound (~1e6 flop per env-step), "
-                                 "not HBM bound: see DESIGN.md",
+                         "note": "step kernel: 674 algorithmic B per env-step x envs per launch / mean duration of one step's work on the caller's "
+                                 "stream (HIP events around the live-row launch + match + settle launches; the donor rows run concurrently on the "
+                                 "handle's own stream); the path is VALU-issue bound (~1e6 flop per env-step), not HBM bound: see DESIGN.md",
                          "kernel_ms": kern_ms, "kernel_ms_p50": step_ms[len(step_ms) // 2],
+                         # rocprofv3 --kernel-trace of the same command: the two dispatches of the kernel per step, by grid size (threads)
+                         "profiled_launches_by_grid_threads": prof["launches"],
                          # the practical bound is VALU issue of the resident waves, so report those too
                          "resident_waves": ((n_local + donors + 3) // 4) if row_layout else 4 * ((n_local + donors + 63) // 64),
                          # 78.6e12 = 1024 SIMDs x 32 lanes x 2.4 GHz: one wave64 VALU instruction per SIMD every 2 cycles (MI355X_MICROARCH.md)

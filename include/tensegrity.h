@@ -136,11 +136,13 @@ typedef struct tgr_config {
    * acceleration: what the arithmetic resolves of the gradient when contact forces are large.  0: default for the precision (fp32 handles
    * 2e-5 on the flat floor and 5e-6 on the heightfield, fp64 handles off), < 0: off */
   double solver_rel_tolerance;
-  /* auto-reset that does not depend on the sharding.  0 (default): one donor pool per handle, a finished env takes the
-   * lowest-indexed ready donor -- which episode that is depends on the other envs of the handle.  B > 0: envs are grouped in classes of B
+  /* auto-reset that does not depend on the sharding.  < 0: one donor pool per handle, a finished env takes the
+   * lowest-indexed ready donor -- which episode that is depends on the other envs of the handle.  0 (default): B = 512 when the donor
+   * stream is on and n_envs, first_env_id and n_donors divide accordingly, else one pool.  B > 0: envs are grouped in classes of B
    * consecutive GLOBAL env ids, each with its own n_donors / (n_envs / B) donor lanes and ONE stream of episodes keyed (class, 0), (class, 1),
    * ... handed out strictly in order: the k-th reset of a class gets episode k.  Any sharding whose shards are whole classes (n_envs and
-   * first_env_id multiples of B) then gives every env the same trajectory, resets included.  Costs the paced donor rows */
+   * first_env_id multiples of B) then gives every env the same trajectory, resets included.  (Without the donor stream it costs the paced
+   * donor rows) */
   int32_t reset_stream_envs;
   /* donor stream: 0 (default) = auto, 1 = off, 2 = required.  On: the donor lanes (episodes being settled for the next resets) are stepped
    * by their own launches on a second, lower-priority HIP stream the handle owns, one per tgr_step, concurrently with the launch that steps

@@ -1036,7 +1036,9 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       contact_params(P, dist, S(1), cc, dn);
       const auto is_floor = MODEL ? (Ro.is_cap | Ro.is_rod) : Ro.is_cap;
       // bar pairs (every lane runs the routine; only pair lanes keep the outcome)
-      const V3<F> pxA = cvt3<F>(ld3(M.kd, KX + 3 * ja_)), pzA = ld3(M.fd, FEZ + 3 * ja_), pxB = cvt3<F>(kxc), pzB = cvt3<F>(kzc);
+      // (positions relative to bar A's centre, the difference formed in K: a robot that has walked 30 m resolves a 0.5 mm bar-bar
+      // penetration as well as one at the origin -- in absolute F coordinates it would carry 2e-6 m of rounding)
+      const V3<F> pxA = z3, pzA = ld3(M.fd, FEZ + 3 * ja_), pxB = cvt3<F>(kxc - ld3(M.kd, KX + 3 * ja_)), pzB = cvt3<F>(kzc);
       RContact<F> p0, p1, p2;
       TGR_SCHED();
       bar_pair_contacts(P, pxA, pzA, pxB, pzB, Ro.is_pair | Ro.is_pair2, p0, p1, p2, dropped);

@@ -941,6 +941,9 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   const bool valid = gid < k.lane_limit;
   const int e = valid ? gid : m - 1;
   const EnvCfg<T>& E = k.E;
+  // reset streams: the classes of this step's match kernel append their starved envs to list[] -- the count starts from zero (the settle
+  // kernel of the previous step, the list's last reader, precedes this launch on the stream)
+  if (E.stream_envs > 0 && k.lane_base == 0 && bx == 0 && threadIdx.x == 0) *k.list_count = 0;
   const bool live = valid && e < n;  // (rows past the end do nothing at all)
   int phase = k.ist[I_PHASE * m + e];
   unsigned long long cmd = 0ull;
@@ -1290,8 +1293,8 @@ template <typename T> __global__ __launch_bounds__(256) void match_kernel_stream
   const int tid = threadIdx.x, NT = blockDim.x, c = blockIdx.x;
   const int n = k.n, m = k.m, B = k.E.stream_envs, Dc = k.E.stream_donors, TB = k.stream_table;
   const int e0 = c * B, d0 = n + c * Dc;
-  int* const list = k.list + e0;      // this class's finished envs, ascending
-  int* const rl = k.rlist + c * Dc;   // donor lane holding episode next_hand + i, or -1
+  int* const list = k.rlist + m + e0;  // this class's finished envs, ascending (scratch: the second half of rlist)
+  int* const rl = k.rlist + c * Dc;    // donor lane holding episode next_hand + i, or -1
   int* const hold = k.holder + c * TB;
   const int next_start = k.cls[2 * c], next_hand = k.cls[2 * c + 1];
   {  // ordered compaction of the class's done flags
@@ -1378,7 +1381,7 @@ template <typename T> __global__ __launch_bounds__(256) void match_kernel_stream
       for (int s_ = 0; s_ < starved; s_++) {
         const int env = list[pairs + s_], ep = next_hand + pairs + s_;
         k.list_ep[base + s_] = ep;
-        k.rlist[k.m + base + s_] = env;  // (staged: the global list is filled below, after every class has read its own part of it)
+        k.list[base + s_] = env;
         k.doneflag[env] = 0;
         if (ep < next_start) {  // somebody is settling it (or holds it behind a gap): re-arm that donor
           const int donor = hold[ep & (TB - 1)];
@@ -1395,12 +1398,6 @@ template <typename T> __global__ __launch_bounds__(256) void match_kernel_stream
     if (pairs) atomicAdd(&k.counters[2], (unsigned long long)pairs);
   }
 }
-// the starved envs the classes staged -> the list the settle kernel reads (a class's own part of list[] was its scratch space above)
-template <typename T> __global__ void stream_starved_kernel(KArgs<T> k) {
-  const int cntv = *k.list_count;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cntv; i += gridDim.x * blockDim.x) k.list[i] = k.rlist[k.m + i];
-}
-
 // set_state: recompute the derived (lagged) fields from qpos the way mj_forward would
 template <typename T> __global__ void refresh_lag_kernel(KArgs<T> k) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1444,7 +1441,7 @@ struct tgr_handle {
   int* list_ep = nullptr;  // reset streams (tgr_config.reset_stream_envs > 0): see KArgs
   int* cls = nullptr;
   int* holder = nullptr;
-  int n_classes = 0, stream_donors = 0, stream_table = 0;
+  int n_classes = 0, stream_envs = 0, stream_donors = 0, stream_table = 0;
   // donor stream (see KArgs)
   bool async = false;
   int launch = 1;  // index of the last tgr_step (donor launches and match kernels are numbered by it)
@@ -1639,7 +1636,7 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   E.min_heading = c.min_reset_heading; E.max_heading = c.max_reset_heading;
   E.ten_mean = c.tendon_reset_mean; E.ten_std = c.tendon_reset_stdev; E.ten_max = c.tendon_max_length; E.ten_min = c.tendon_min_length;
   E.seed = c.seed; E.first_env_id = c.first_env_id; E.reset_noise = c.reset_noise_scale;
-  E.stream_envs = h->n_classes > 0 ? c.reset_stream_envs : 0; E.stream_donors = h->stream_donors;
+  E.stream_envs = h->n_classes > 0 ? h->stream_envs : 0; E.stream_donors = h->stream_donors;
   k.n = h->n; k.m = h->m;
   {
     // Paced donor rows (step_kernel_row): the rows that do not fit the first round of wave slots -- one round holds 4 rows per wavefront,
@@ -1776,20 +1773,6 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   if (const char* v = getenv("TGR_PACE_FROM")) h->pace_from = atoi(v);
   int donors = cfg->n_donors < 0 ? 2 * n_envs : cfg->n_donors;
   if (!cfg->auto_reset) donors = 0;
-  if (cfg->reset_stream_envs > 0 && donors > 0) {
-    const int B = cfg->reset_stream_envs;
-    const bool ok = use_row_kernels(h) && n_envs % B == 0 && cfg->first_env_id % (uint64_t)B == 0 && donors % (n_envs / B) == 0;
-    if (!ok) {
-      g_err = "tgr_create: reset_stream_envs needs the row kernels, n_envs and first_env_id multiples of it, and n_donors a multiple of the number of classes";
-      delete h;
-      return TGR_ERR_INVALID;
-    }
-    h->n_classes = n_envs / B;
-    h->stream_donors = donors / h->n_classes;
-    h->stream_table = 1;
-    while (h->stream_table < 2 * h->stream_donors) h->stream_table <<= 1;
-  }
-  h->m = n_envs + donors;
   // donor stream: 0 = auto (on whenever the handle has donor lanes, is stepped by the row kernels and n_envs is a multiple of the four rows
   // of a wavefront), 1 = off (one launch steps live and donor rows, paced donor rows), 2 = required
   {
@@ -1798,6 +1781,25 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
     h->async = cfg->donor_stream != 1 && can;
     if (const char* v = getenv("TGR_DONOR_STREAM")) { if (atoi(v) == 0) h->async = false; }  // (A/B measurements)
   }
+  // reset streams: 0 = auto (classes of 512 envs when the donor stream is on and the sizes divide), < 0 = off, B > 0 = classes of B envs
+  {
+    int B = cfg->reset_stream_envs;
+    auto fits = [&](int b) { return donors > 0 && use_row_kernels(h) && n_envs % b == 0 && cfg->first_env_id % (uint64_t)b == 0 && donors % (n_envs / b) == 0; };
+    if (B == 0) B = (h->async && fits(512)) ? 512 : -1;
+    if (B > 0 && donors > 0) {
+      if (!fits(B)) {
+        g_err = "tgr_create: reset_stream_envs needs the row kernels, n_envs and first_env_id multiples of it, and n_donors a multiple of the number of classes";
+        delete h;
+        return TGR_ERR_INVALID;
+      }
+      h->stream_envs = B;
+      h->n_classes = n_envs / B;
+      h->stream_donors = donors / h->n_classes;
+      h->stream_table = 1;
+      while (h->stream_table < 2 * h->stream_donors) h->stream_table <<= 1;
+    }
+  }
+  h->m = n_envs + donors;
   *out = nullptr;
   const int rc = alloc_handle(h, n_envs, donors);
   if (rc != TGR_OK) {  // nothing half-built leaves this function: the message moves to the thread's slot, the handle is freed
@@ -1848,7 +1850,7 @@ extern "C" uint64_t tgr_lane_key(const tgr_handle* h, int lane) {
   if (!h) return 0;
   if (lane < h->n) return h->cfg.first_env_id + (uint64_t)lane;
   if (h->n_classes > 0)  // reset streams: the key of the donor lane's class (tgr_sim.hip lane_key)
-    return (1ull << 62) + (1ull << 40) + h->cfg.first_env_id / (uint64_t)h->cfg.reset_stream_envs + (uint64_t)((lane - h->n) / h->stream_donors);
+    return (1ull << 62) + (1ull << 40) + h->cfg.first_env_id / (uint64_t)h->stream_envs + (uint64_t)((lane - h->n) / h->stream_donors);
   return (1ull << 62) + h->cfg.first_env_id * 8ull + (uint64_t)(lane - h->n);
 }
 extern "C" int tgr_set_seed(tgr_handle* h, uint64_t seed) {
@@ -2028,9 +2030,7 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
   HIP_TRY(h, hipGetLastError());
   if (h->cfg.auto_reset) {
     if (h->n_classes > 0) {
-      HIP_TRY(h, hipMemsetAsync(h->list_count, 0, sizeof(int), s));
-      hipLaunchKernelGGL((match_kernel_stream<T>), dim3(h->n_classes), dim3(256), 0, s, k);
-      hipLaunchKernelGGL((stream_starved_kernel<T>), dim3(8), dim3(256), 0, s, k);
+      hipLaunchKernelGGL((match_kernel_stream<T>), dim3(h->n_classes), dim3(256), 0, s, k);  // (list_count was zeroed by the step kernel)
     } else {
       hipLaunchKernelGGL((match_kernel<T>), dim3(1), dim3(1024), 0, s, k);
     }

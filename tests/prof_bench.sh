@@ -16,6 +16,14 @@ res = {}
 for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     res["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows if "tgr::" in r["Name"]]
+# with the donor stream one tgr_step launches step_kernel_row twice -- live rows (grid = n / 4 blocks) and donor rows (grid = donors / 4 blocks):
+# the per-dispatch trace tells them apart by grid size
+by_grid = collections.defaultdict(list)
+for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "step_kernel_row" in r["Kernel_Name"]:
+            by_grid[int(r["Grid_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+res["step_kernel_row_by_grid_threads"] = {str(g): {"calls": len(v), "avg_ns": sum(v) / len(v), "min_ns": min(v), "max_ns": max(v)} for g, v in sorted(by_grid.items())}
 for tag in ("fetch", "write", "sq"):
     for f in glob.glob(out + f"/{tag}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)

@@ -68,3 +68,149 @@ def test_free_bars_lying_flat_rest_at_the_closed_form_penetration(prec, layout):
     want = 5e-4 * 3 * (M_BAR * G) ** 2
     assert np.abs(cc - want).max() < (1e-6 if prec == "f64" else 2e-3) * want, (cc.min(), cc.max(), want)
     env.close()
+
+
+# ------------------------------------------------------------------ bar against bar, one sub-step, closed form (no oracle involved)
+R_CYL, R_BCYL = 0.0381, 0.035
+
+
+def _imp(p):
+    d0, dmax, width, mid = 0.9, 0.95, 0.001, 0.5
+    x = min(p / width, 1.0)
+    y = x * x / mid if x <= mid else 1 - (1 - x) ** 2 / (1 - mid)
+    return d0 + y * (dmax - d0)
+
+
+def _quat_z_to(axis):
+    """unit quaternion (w, x, y, z) turning the local z axis (the bar's axis) into `axis`"""
+    a = np.asarray(axis, float) / np.linalg.norm(axis)
+    c = np.cross([0, 0, 1.0], a); w = 1.0 + a[2]
+    q = np.concatenate([[w], c]) if w > 1e-9 else np.array([0.0, 1.0, 0.0, 0.0])
+    return q / np.linalg.norm(q)
+
+
+def _free_env(prec, n=4):
+    from tensegrity_rl_amd import TensegrityVecEnv
+    free = dict(gain=0.0, bias=[0.0, 0.0, 0.0], ten_stiffness=[0.0] * 9, ten_damping=[0.0] * 9, gravity=0.0, frame_skip=1)
+    return TensegrityVecEnv(n, "tensegrity_env-v0", precision=prec, auto_reset=False, terminate_when_unhealthy=0, config_overrides=free)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("case", ["cap on a bar's side", "two bars crossing"])
+def test_one_substep_of_a_central_bar_bar_contact_in_closed_form(prec, case):
+    """Two free bars (no gravity, tendons and actuators off, frame_skip = 1) at rest, touching so that the contact point lies on the line
+    through both centres of mass along the contact normal: no torque, no tangential motion, and mujoco's soft-contact problem for the one
+    normal row is a scalar quadratic --
+        aref = K imp p,  R = (1 - imp) / imp * (1/m + 1/m),  f = aref / (R + 2/m),  bar B gains +h f / m along the normal, bar A loses it
+    (K = 5000 / 0.95^2, imp = solimp sigmoid at penetration p; flat xml:30).  Checked after ONE sub-step for
+      * a cap sphere of bar B resting on the SIDE of bar A's r-cylinder above A's centre (the sphere-cylinder routine: "a bar end resting on
+        another bar's side"), penetration 0.5 mm;
+      * the r-cylinders of two perpendicular bars crossing above each other's centres (cylinder-cylinder side to side), 0.3 mm."""
+    env = _free_env(prec)
+    n = env.num_envs
+    h = 1e-3
+    K = 5000.0 / 0.95 ** 2
+    if case == "cap on a bar's side":
+        p = 5e-4
+        qA, xA = _quat_z_to([1, 0, 0]), np.array([0.0, 0.0, 5.0])
+        qB = _quat_z_to([0, 0, 1])
+        cap = xA + np.array([0, 0, R_CYL + R_CAP - p])            # B's lower cap (-z end) centre, straight above A's centre
+        xB = cap + np.array([0, 0, HALF])
+    else:
+        p = 3e-4
+        qA, xA = _quat_z_to([1, 0, 0]), np.array([0.0, 0.0, 5.0])
+        qB, xB = _quat_z_to([0, 1, 0]), np.array([0.0, 0.0, 5.0 + 2 * R_CYL - p])
+    imp = _imp(p)
+    f = K * imp * p / ((1 - imp) / imp * (2.0 / M_BAR) + 2.0 / M_BAR)
+    qpos = np.zeros((n, 21)); qvel = np.zeros((n, 18))
+    for e in range(n):
+        qpos[e, 0:3], qpos[e, 3:7] = xA, qA
+        qpos[e, 7:10], qpos[e, 10:14] = xB, qB
+        qpos[e, 14:17], qpos[e, 17:21] = [0.0, 7.0, 5.0], [1, 0, 0, 0]      # the third bar: far away
+    env.set_state(qpos, qvel)
+    env.step_tensors(np.zeros((n, 6), dtype=np.float32))
+    st = env.get_state()
+    v = st["qvel"].reshape(n, 3, 6)
+    want = h * f / M_BAR
+    # fp32: the bar-bar routine works on fp32 coordinates RELATIVE to bar A's centre (the difference is formed in fp64): a cap 0.8 m from
+    # that centre is placed to 6e-8 m, i.e. to 1e-4 of a 0.5 mm penetration
+    tol = 1e-10 if prec == "f64" else 2e-4 * want
+    assert abs(f - (4.7403 if case.startswith("cap") else 2.7466)) < 2e-3        # (N; the numbers the docstring's formula gives)
+    assert np.abs(v[:, 1, 2] - want).max() < tol and np.abs(v[:, 0, 2] + want).max() < tol, (v[0, :2, 2], want)
+    rest = v.copy(); rest[:, 0, 2] = 0; rest[:, 1, 2] = 0
+    assert np.abs(rest).max() < tol                                               # nothing else moves: no torque, no friction force
+    z = st["qpos"].reshape(n, 3, 7)[:, :2, 2]
+    assert np.abs(z[:, 1] - (xB[2] + h * want)).max() < (1e-12 if prec == "f64" else 1e-6)
+    assert env.stats()["dropped_contacts"] == 0
+    env.close()
+
+
+def test_a_deep_bar_crossing_carries_the_three_contacts_mujoco_would_keep():
+    """r-cylinders crossing 4 mm deep at 0.4 m from both centres, where both bars also carry a b-cylinder (r = 0.035 inside r = 0.0381,
+    flat xml:77): mujoco instantiates r-r (4 mm), r-b and b-r (0.9 mm each) -- b-b would need 6.2 mm.  All three share the normal and the
+    point; the row kernels keep them in the pair's three slots (lanes 6/7 and 12).  Contacts are unilateral: the deep one alone pushes the
+    bars apart harder (relative normal acceleration 20 m/s^2) than the two shallow ones ask for (aref = K imp 0.9 mm = 4.7 m/s^2), so those
+    stay force-free, and with the deep contact's rows in the quadratic zone of its cone the sub-step is the linear problem
+    (M + J^T D J) a = J^T D aref, solved here with numpy from the geometry alone (six rows: normal, two tangents, torsion, two rolling;
+    R = (1 - imp) / imp * (1/m + 1/m) for the normal and tangential rows, R mu0^2 / mu_j^2 for torsion and rolling: SURVEY.md App. B.5) and
+    compared with the velocities after one sub-step (fp64): off-centre, so bars translate AND rotate, and friction rows carry force."""
+    env = _free_env("f64")
+    n = env.num_envs
+    h, K = 1e-3, 5000.0 / 0.95 ** 2
+    Ixx = 1.0 * (3 * R_CYL ** 2 + (2 * HALF) ** 2) / 12 + 2 * (0.4 * 0.5 * R_CAP ** 2 + 0.5 * HALF ** 2) + 2 * (1.0 * (3 * R_BCYL ** 2 + 0.45 ** 2) / 12 + 0.463 ** 2)
+    Izz = 1.0 * R_CYL ** 2 / 2 + 2 * 0.4 * 0.5 * R_CAP ** 2 + 2 * 1.0 * R_BCYL ** 2 / 2
+    s0 = 0.4
+    pen = 4e-3
+    xA, aA = np.array([0.0, 0.0, 5.0]), np.array([1.0, 0, 0])
+    xB, aB = np.array([s0, -s0, 5.0 + 2 * R_CYL - pen]), np.array([0, 1.0, 0])      # B's axis passes over A's at A's s = 0.4, B's t = 0.4
+    nrm = np.array([0, 0, 1.0])
+    pa = xA + s0 * aA
+    contacts = []   # (dist, position): r-r, r(A)-b(B), b(A)-r(B); position = pa + (r_A + dist / 2) n
+    for ra, rb in ((R_CYL, R_CYL), (R_CYL, R_BCYL), (R_BCYL, R_CYL)):
+        dist = (2 * R_CYL - pen) - (ra + rb)
+        assert dist < 0
+        contacts.append((dist, pa + (ra + 0.5 * dist) * nrm))
+    assert (2 * R_CYL - pen) - 2 * R_BCYL > 0   # b-b does not touch
+    # generalised coordinates: (v_A, w_A, v_B, w_B) in the world frame; M = diag(m, I_A, m, I_B) with I = Ixx 1 + (Izz - Ixx) a a^T
+    inert = lambda a: Ixx * np.eye(3) + (Izz - Ixx) * np.outer(a, a)
+    Mm = np.zeros((12, 12)); Mm[:3, :3] = M_BAR * np.eye(3); Mm[3:6, 3:6] = inert(aA); Mm[6:9, 6:9] = M_BAR * np.eye(3); Mm[9:, 9:] = inert(aB)
+    t1, t2 = np.array([1.0, 0, 0]), np.array([0, 1.0, 0])
+    mu = [1.0, 1.0, 0.005, 1e-4, 1e-4]
+    skew = lambda r: np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+
+    def rows_of(pos):
+        rA_, rB_ = pos - xA, pos - xB
+        Jp = np.hstack([-np.eye(3), skew(rA_), np.eye(3), -skew(rB_)])     # velocity of the contact point on B minus on A
+        Jr = np.hstack([np.zeros((3, 3)), -np.eye(3), np.zeros((3, 3)), np.eye(3)])
+        return [nrm @ Jp, t1 @ Jp, t2 @ Jp, nrm @ Jr, t1 @ Jr, t2 @ Jr]
+    dist, pos = contacts[0]
+    imp = _imp(-dist)
+    R0 = (1 - imp) / imp * (0.25 + 0.25)
+    R = [R0, R0, R0, R0 * mu[0] ** 2 / mu[2] ** 2, R0 * mu[0] ** 2 / mu[3] ** 2, R0 * mu[0] ** 2 / mu[4] ** 2]   # elliptic cone: R_j = R_1 mu_0^2 / mu_j^2
+    H, g = Mm.copy(), np.zeros(12)
+    for J, Rj, ar in zip(rows_of(pos), R, [-K * imp * dist, 0, 0, 0, 0, 0]):
+        H += np.outer(J, J) / Rj; g += J * ar / Rj
+    a = np.linalg.solve(H, g)
+    jar = [J @ a - ar for J, ar in zip(rows_of(pos), [-K * imp * dist, 0, 0, 0, 0, 0])]
+    assert mu[0] * jar[0] + np.sqrt(sum((j * f) ** 2 for j, f in zip(jar[1:], mu))) <= 0     # the deep contact sits in the quadratic zone
+    for dist2, pos2 in contacts[1:]:                                                       # the shallow ones are satisfied: no force
+        assert rows_of(pos2)[0] @ a - (-K * _imp(-dist2) * dist2) > 1.0
+    qpos = np.zeros((n, 21)); qvel = np.zeros((n, 18))
+    for e in range(n):
+        qpos[e, 0:3], qpos[e, 3:7] = xA, _quat_z_to(aA)
+        qpos[e, 7:10], qpos[e, 10:14] = xB, _quat_z_to(aB)
+        qpos[e, 14:17], qpos[e, 17:21] = [0.0, 7.0, 5.0], [1, 0, 0, 0]
+    env.set_state(qpos, qvel)
+    trace = env.bind_substep_trace()
+    env.step_tensors(np.zeros((n, 6), dtype=np.float32))
+    st = env.get_state()
+    assert ((trace.cpu().numpy()[:, 0] & 0xffff) == ((1 << 6) | (1 << 7) | (1 << 12))).all()      # pair (0, 1): both sub-slots and the third slot
+    v = st["qvel"].reshape(n, 3, 6)
+    # qvel: world-frame linear velocity, BODY-frame angular velocity
+    from scipy.spatial.transform import Rotation as Rot
+    Ra = Rot.from_quat(np.roll(_quat_z_to(aA), -1)).as_matrix(); Rb = Rot.from_quat(np.roll(_quat_z_to(aB), -1)).as_matrix()
+    want = np.concatenate([h * a[:3], Ra.T @ (h * a[3:6]), h * a[6:9], Rb.T @ (h * a[9:])])
+    got = np.concatenate([v[0, 0], v[0, 1]])
+    assert np.abs(got - want).max() < 1e-8, (got, want)
+    assert abs(want[8] - 6.435e-3) < 1e-5 and abs(want[4]) > 5e-3 and env.stats()["dropped_contacts"] == 0   # translation and rotation
+    env.close()

@@ -146,8 +146,8 @@ def test_full_size_properties():
     from tensegrity_rl_amd import TensegrityVecEnv
     n = 4096
 
-    def rollout(first, count, steps=12):
-        env = TensegrityVecEnv(count, "tensegrity_env-v0", seed=42, first_env_id=first, auto_reset=False)
+    def rollout(first, count, steps=12, **kw):
+        env = TensegrityVecEnv(count, "tensegrity_env-v0", seed=42, first_env_id=first, **(kw or dict(auto_reset=False)))
         env.reset_tensors()
         g = torch.Generator(device="cuda"); g.manual_seed(9)
         acts = [torch.rand((n, 6), device="cuda", generator=g) * 0.6 - 0.45 for _ in range(steps)]
@@ -165,6 +165,11 @@ def test_full_size_properties():
     part, st_part = rollout(1024, 512)
     for (o1, r1, t1), (o2, r2, t2) in zip(full, part):
         assert torch.equal(o1[1024:1536], o2) and torch.equal(r1[1024:1536], r2)  # results do not depend on the sharding
+    # ... and with auto-reset on (the default: reset streams in classes of 512 envs) across two waves of resets
+    full_r, _ = rollout(0, n, steps=14, max_episode_steps=6)
+    part_r, _ = rollout(1024, 512, steps=14, max_episode_steps=6)
+    for (o1, r1, t1), (o2, r2, t2) in zip(full_r, part_r):
+        assert torch.equal(o1[1024:1536], o2) and torch.equal(r1[1024:1536], r2)
     o, r, t = full[-1]
     assert torch.isfinite(o).all() and torch.isfinite(r).all()
     q = st_full["qpos"].reshape(n, 3, 7)[:, :, 3:]
