@@ -413,3 +413,43 @@ def test_reset_streams_make_auto_reset_shard_invariant(donors_per_env, limit):
     assert resets > 512 and s_part["donor_resets"] > 0
     if donors_per_env < 1:
         assert s_part["settle_kernel_resets"] > 512 + int(donors_per_env * 512)   # starved resets did happen
+
+
+def test_sb3_adapter_forwards_everything_under_a_stand_in_base_class(monkeypatch):
+    """stable_baselines3 is not installable here or on the GPU box, so `TensegrityVecEnv.to_sb3()` (tensegrity_rl_amd/sb3.py) cannot run against
+    the real `VecEnv` base class.  This executes it against a STAND-IN with the base class's constructor signature and its `step()` =
+    `step_async()` + `step_wait()` (SB3 2.2.1 [ext]): the adapter must construct, and forward reset / step / attribute access to the
+    native VecEnv unchanged.  (What SB3 itself does with the object stays untested until SB3 is importable somewhere.)"""
+    import sys
+    import types
+    from tensegrity_rl_amd import TensegrityVecEnv
+
+    class VecEnv:   # stand-in for stable_baselines3.common.vec_env.base_vec_env.VecEnv
+        def __init__(self, num_envs, observation_space, action_space):
+            self.num_envs, self.observation_space, self.action_space = num_envs, observation_space, action_space
+            self.reset_infos = [{} for _ in range(num_envs)]
+
+        def step(self, actions):
+            self.step_async(actions)
+            return self.step_wait()
+    mods = {}
+    for name in ("stable_baselines3", "stable_baselines3.common", "stable_baselines3.common.vec_env", "stable_baselines3.common.vec_env.base_vec_env"):
+        mods[name] = types.ModuleType(name)
+    mods["stable_baselines3.common.vec_env.base_vec_env"].VecEnv = VecEnv
+    for name, m in mods.items():
+        monkeypatch.setitem(sys.modules, name, m)
+    n = 64
+    a_env = TensegrityVecEnv(n, "tr_env-v0", seed=3, max_episode_steps=4)
+    b_env = TensegrityVecEnv(n, "tr_env-v0", seed=3, max_episode_steps=4)
+    sb3 = a_env.to_sb3()
+    assert isinstance(sb3, VecEnv) and sb3.num_envs == n and sb3.observation_space.shape == (45,)
+    assert np.array_equal(sb3.reset(), b_env.reset())
+    rng = np.random.default_rng(0)
+    for t in range(5):
+        act = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+        o1, r1, d1, i1 = sb3.step(act)
+        o2, r2, d2, i2 = b_env.step(act)
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
+        assert [sorted(x) for x in i1] == [sorted(x) for x in i2]
+    assert d1.all() is not None and sb3.get_attr("dt")[0] == 0.02 and sb3.env_is_wrapped(object) == [False] * n
+    sb3.close(); b_env.close()
