@@ -59,8 +59,10 @@ def test_gym_env_info_carries_reference_keys():
     env.close()
 
 
-def test_tracking_policy_whole_episode_statistics(golden_dir):
-    """The MuJoCo-trained tracking policy rolled for whole episodes (`_step_num > 1000`, tr_env.py:458) on all six reset poses,
+def test_tracking_policy_whole_episode_statistics_regression(golden_dir):
+    """REGRESSION test, not parity: the reference statistics were recorded by THIS simulator (tests/gpu_tracking_stats.py on MI355X), so this
+    guards against drift of the HIP path's behaviour between builds -- it says nothing about MuJoCo.  What it measures:
+    the MuJoCo-trained tracking policy rolled for whole episodes (`_step_num > 1000`, tr_env.py:458) on all six reset poses,
     deterministic and stochastic, against the statistics recorded at 4096 robots (tests/golden/tracking_policy_stats.json, written by
     tests/gpu_tracking_stats.py on MI355X).  Quantities: arrival within 0.5 m of the way-point 3 m ahead, progress of more than a metre,
     and how episodes end (1500 N rule / robot at rest = "unhealthy" / step limit).  This quantifies the behavioural anchor -- it does
@@ -82,3 +84,56 @@ def test_tracking_policy_whole_episode_statistics(golden_dir):
     # (as in training) keeps moving to the step limit in > 80 % of the episodes, and the 1500 N rule ends < 10 %
     s = ref["stochastic"]["all"]
     assert s["ended_by_step_limit"] > 0.8 and s["ended_by_contact_force"] < 0.1
+
+
+
+def test_on_device_ppo_learner_loop_runs_on_the_rollout_buffers():
+    """BASELINE configs #3/#4's shape (a learner fed by the batched env) at the level this repository owns: stable_baselines3 is not
+    installable here, so a plain-torch PPO update stands in for the learner (the same loop tests/gpu_ppo_demo.py trains with).  Two
+    iterations of policy -> step_tensors -> DeviceRolloutBuffer -> GAE -> clipped-surrogate minibatch updates, everything on the device:
+    the buffers stay finite, returns follow from rewards, the parameters move, the observation carried from one collect() to the next is the
+    env's current one."""
+    import torch
+    import torch.nn as nn
+    from tensegrity_rl_amd import TensegrityVecEnv
+    from tensegrity_rl_amd.rollout import DeviceRolloutBuffer, collect
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    n, T = 1024, 16
+    env = TensegrityVecEnv(n, "tr_env-v0", desired_action="straight", desired_direction=1, seed=1)
+    D = env.obs_dim
+    pi = nn.Sequential(nn.Linear(D, 64), nn.Tanh(), nn.Linear(64, 6)).to(dev)
+    vf = nn.Sequential(nn.Linear(D, 64), nn.Tanh(), nn.Linear(64, 1)).to(dev)
+    log_std = nn.Parameter(torch.full((6,), -0.5, device=dev))
+    opt = torch.optim.Adam(list(pi.parameters()) + list(vf.parameters()) + [log_std], lr=3e-4)
+    raw = torch.zeros(T, n, 6, device=dev)
+    buf = DeviceRolloutBuffer(T, n, D, device=dev, gamma=0.99, gae_lambda=0.95)
+    obs = env.reset_tensors().clone()
+    w0 = pi[0].weight.detach().clone()
+    for it in range(2):
+        buf.reset()
+        k = [0]
+
+        @torch.no_grad()
+        def pol(o):
+            x = o.float(); mu = pi(x); std = log_std.exp()
+            u = mu + std * torch.randn_like(mu)
+            raw[k[0]] = u; k[0] += 1
+            lp = (-0.5 * ((u - mu) / std) ** 2 - log_std - 0.9189385).sum(1)
+            return -0.45 + 0.3 * (u.clamp(-1, 1) + 1), vf(x).squeeze(1), lp
+        obs, stats = collect(env, pol, buf, T, obs=obs, value_fn=lambda o: vf(o.float()).squeeze(1).detach())
+        assert torch.equal(obs, env.obs)
+        assert torch.isfinite(buf.obs).all() and torch.isfinite(buf.rewards).all() and torch.isfinite(buf.advantages).all()
+        adv = buf.advantages.reshape(-1); ret = buf.returns.reshape(-1)
+        adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        X, U, LP0 = buf.obs.reshape(-1, D).float(), raw.reshape(-1, 6), buf.log_probs.reshape(-1)
+        for s_ in range(0, X.shape[0], 4096):
+            idx = slice(s_, s_ + 4096)
+            mu = pi(X[idx]); std = log_std.exp()
+            lp = (-0.5 * ((U[idx] - mu) / std) ** 2 - log_std - 0.9189385).sum(1)
+            ratio = (lp - LP0[idx]).exp()
+            loss = -torch.min(ratio * adv[idx], ratio.clamp(0.8, 1.2) * adv[idx]).mean() + 0.25 * (vf(X[idx]).squeeze(1) - ret[idx]).pow(2).mean()
+            assert torch.isfinite(loss)
+            opt.zero_grad(); loss.backward(); opt.step()
+    assert (pi[0].weight.detach() - w0).abs().max() > 0
+    env.close()
