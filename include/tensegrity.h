@@ -150,6 +150,12 @@ typedef struct tgr_config {
    * streams overlap.  Off: one launch steps live and donor rows together (round-2 behaviour, paced donor rows).  Auto = on
    * whenever the handle has donor lanes, is stepped by the row kernels and n_envs is a multiple of 4 */
   int32_t donor_stream;
+  /* tr_env.py:143,163,685-706,712-713: use_cap_size_noise -- reset_model() starts with _reset_cap_size(cap_size_noise_range): one radius ~
+   * U(range) for the six cap spheres of the episode (collision radius only: masses, inertias, tendon sites stay).  The reference's own code
+   * path raises on the mujoco 2.3.7 bindings it pins (model.geom_names / geom_name2id are mujoco-py names); this builds its evident intent.
+   * The uniform comes from philox counter 5 of (seed; lane key, episode).  tr_env + row kernels only */
+  int32_t use_cap_size_noise;
+  double cap_size_noise_range[2];
 } tgr_config;
 
 typedef struct tgr_handle tgr_handle;
@@ -192,7 +198,7 @@ int tgr_step_f64(tgr_handle* h, const float* actions, double* obs, double* rewar
 /* HOST arrays, any may be NULL: qpos[N][21], qvel[N][18] (MuJoCo convention: world linear,
  * body-frame angular), ctrl[N][6], qacc_warmstart[N][18], aux[N][TGR_AUX_K].
  * replaces: reads of env.data.qpos/qvel/ctrl/qacc_warmstart and MujocoEnv.set_state (tensegrity_env.py:448,484; tr_env.py:744,763,800) */
-#define TGR_AUX_K 55
+#define TGR_AUX_K 56
 enum {
   TGR_AUX_XY_LAG_X = 0, TGR_AUX_XY_LAG_Y, TGR_AUX_PSI_LAG, TGR_AUX_RESET_PSI, TGR_AUX_EP_RETURN,
   TGR_AUX_STEP_NUM, TGR_AUX_ELAPSED, TGR_AUX_EPISODE, TGR_AUX_RING_LEN, TGR_AUX_WAYPT_X, TGR_AUX_WAYPT_Y,
@@ -201,7 +207,10 @@ enum {
   TGR_AUX_ACT = 17, /* ..22: actuator activations (model_kind 1) */
   /* 23..54: the heading deque self._heading_buffer (tensegrity_env.py:242-243,326-345; tr_env.py:278,376-378,430-432), oldest entry
    * first, TGR_AUX_RING_LEN valid entries.  tgr_set_state with aux replaces the deque (TGR_AUX_RING_LEN entries) */
-  TGR_AUX_RING = 23
+  TGR_AUX_RING = 23,
+  /* 55: the radius of the env's six cap spheres (tr_env.py:685-706 use_cap_size_noise: redrawn per episode; else the model's).  tgr_set_state:
+   * a value > 0 replaces it, 0 keeps the lane's */
+  TGR_AUX_CAP_RADIUS = 55
 };
 #define TGR_RING_CAPACITY 32
 int tgr_get_state(tgr_handle* h, double* qpos, double* qvel, double* ctrl, double* qacc_warmstart, double* aux);

@@ -62,7 +62,8 @@ class EnvCfg(C.Structure):
                 ("waypt_reward_amplitude", d), ("waypt_reward_stdev", d), ("yaw_reward_weight", d),
                 ("frame_skip", C.c_int), ("max_episode_steps", C.c_int), ("use_obs_noise", C.c_int),
                 ("obs_noise_tendon_stdev", d), ("obs_noise_cap_pos_stdev", d), ("model_kind", C.c_int), ("hf_nrow", C.c_int),
-                ("hf_ncol", C.c_int), ("hf_data", C.c_void_p), ("reset_noise_scale", d)]
+                ("hf_ncol", C.c_int), ("hf_data", C.c_void_p), ("reset_noise_scale", d), ("use_cap_size_noise", C.c_int),
+                ("cap_size_noise_range", d * 2)]
 
 
 class Env(C.Structure):

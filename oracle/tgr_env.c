@@ -109,6 +109,7 @@ void tgo_env_default_cfg(tgo_env_cfg* c, int env_kind, int desired_action) {
   c->use_contact_forces = 0;
   c->use_cap_velocity = 1;
   c->use_obs_noise = 0;
+  c->use_cap_size_noise = 0; c->cap_size_noise_range[0] = 0.04; c->cap_size_noise_range[1] = 0.09; /* tr_env.py:143,163 */
   c->obs_noise_tendon_stdev = 0.02;
   c->obs_noise_cap_pos_stdev = 0.05;
   c->is_test = 0;
@@ -528,9 +529,19 @@ void tgo_env_reset_noise(tgo_env* e, int pose_idx, double theta, const double te
   if (obs) tgo_env_get_obs(e, obs);
 }
 
+double tgo_cap_size_draw(uint64_t seed, uint64_t env_id, uint64_t episode, double lo, double hi) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)episode, 5};
+  uint32_t o[4];
+  tgo_philox4x32(ctr, key, o);
+  return lo + u53(o[0], o[1]) * (hi - lo);
+}
+
 void tgo_env_reset_seeded(tgo_env* e, uint64_t seed, uint64_t env_id, uint64_t episode, double* obs) {
   const tgo_env_cfg* c = &e->cfg;
   int pose; double theta, tendons[6], uw[2];
+  /* tr_env.py:712-713: the cap size is drawn first, before the pose */
+  if (c->use_cap_size_noise) e->model.cap_radius = tgo_cap_size_draw(seed, env_id, episode, c->cap_size_noise_range[0], c->cap_size_noise_range[1]);
   tgo_rng_draws(seed, env_id, episode, c->env_kind, c->tendon_reset_mean, c->tendon_reset_stdev, c->tendon_min_length,
                 c->tendon_max_length, c->min_reset_heading, c->max_reset_heading, &pose, &theta, tendons, uw);
   e->rng_seed = seed; e->rng_key = env_id; e->rng_episode = episode;

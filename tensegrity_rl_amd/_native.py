@@ -11,7 +11,7 @@ ENV_TENSEGRITY, ENV_TR = 0, 1
 ACTIONS = {"straight": 0, "turn": 1, "aiming": 2, "tracking": 3, "vel_track": 4}
 PRECISION = {"f32": 0, "f64": 1, "float32": 0, "float64": 1}
 KERNEL_LAYOUT = {"auto": 0, "block": 1, "row": 2}
-INFO_K, AUX_K, NQ, NV, NU = 26, 55, 21, 18, 6
+INFO_K, AUX_K, NQ, NV, NU = 26, 56, 21, 18, 6
 AUX_RING, RING_CAPACITY = 23, 32
 TRACE_WORDS = 24
 INFO_TENDON_LENGTH, INFO_BAR_CONTACT = 16, 25
@@ -19,7 +19,7 @@ INFO_KEYS = ["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y
              "distance_from_origin", "x_velocity", "y_velocity", "forward_reward"]
 AUX_KEYS = ["xy_lag_x", "xy_lag_y", "psi_lag", "reset_psi", "ep_return", "step_num", "elapsed", "episode", "ring_len",
             "waypt_x", "waypt_y", "ori_x", "ori_y", "vcmd_x", "vcmd_y", "vcmd_w", "src"] + [f"act_{i}" for i in range(6)] + \
-           [f"ring_{i}" for i in range(32)]
+           [f"ring_{i}" for i in range(32)] + ["cap_radius"]
 
 
 class Config(C.Structure):
@@ -38,7 +38,7 @@ class Config(C.Structure):
         ("waypt_reward_amplitude", f64), ("waypt_reward_stdev", f64), ("yaw_reward_weight", f64), ("solver_warm_start", i32),
         ("use_obs_noise", i32), ("obs_noise_tendon_stdev", f64), ("obs_noise_cap_pos_stdev", f64),
         ("model_kind", i32), ("site_offset", f64), ("act_tau", f64), ("hf_size", f64 * 4), ("hf_pos", f64 * 3),
-        ("reset_noise_scale", f64), ("kernel_layout", i32), ("solver_rel_tolerance", f64), ("reset_stream_envs", i32), ("donor_stream", i32),
+        ("reset_noise_scale", f64), ("kernel_layout", i32), ("solver_rel_tolerance", f64), ("reset_stream_envs", i32), ("donor_stream", i32), ("use_cap_size_noise", i32), ("cap_size_noise_range", f64 * 2),
     ]
 
 

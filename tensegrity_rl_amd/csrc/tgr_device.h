@@ -134,6 +134,7 @@ template <typename T> struct Sim {
   V3<T> aa[3];  // warm-start acceleration, angular (world frame)
   T ctrl[6];
   T act[6];     // actuator activations (MODEL = 1: dyntype filter)
+  T capd;       // this episode's cap radius minus the model's (cap-size noise, row kernels only; 0 otherwise)
 };
 
 // quantities of the forward pass of the LAST sub-step (what the reference reads after mj_step: one sub-step old)

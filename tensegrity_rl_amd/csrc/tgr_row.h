@@ -267,7 +267,7 @@ template <typename F, typename B> TGR_RDEV void keep_deeper(RCand<F>& best, RCan
   best.ok = best.ok | hit;
 }
 template <typename F, typename S, typename B>
-TGR_RDEV void sphere_vs_bar(const RParams<S>& P, V3<F> c, V3<F> xo, V3<F> zo, bool flip, B enable, RCand<F>& best, RCand<F>& second, F& count) {
+TGR_RDEV void sphere_vs_bar(const RParams<S>& P, F capr, V3<F> c, V3<F> xo, V3<F> zo, bool flip, B enable, RCand<F>& best, RCand<F>& second, F& count) {
   V3<F> wv = c - xo;
   F t = dot(wv, zo);
   V3<F> rad = wv - t * zo;
@@ -285,9 +285,9 @@ TGR_RDEV void sphere_vs_bar(const RParams<S>& P, V3<F> c, V3<F> xo, V3<F> zo, bo
     V3<F> dif = q - c;
     F dd = sqrt_(dot(dif, dif));
     F idd = rcp_(max_(dd, F(S(1e-30))));
-    F dist = sel(inside, rho - rc - P.cap_r, dd - P.cap_r);
+    F dist = sel(inside, rho - rc - capr, dd - capr);
     V3<F> n = sel3(inside, -irho * rad, idd * dif);
-    V3<F> pos = c + (P.cap_r + S(0.5) * dist) * n;
+    V3<F> pos = c + (capr + S(0.5) * dist) * n;
     auto valid = enable & sel(inside, rho > S(1e-12), dd > S(1e-12));
     V3<F> nn = flip ? -n : n;
     keep_deeper(best, second, count, dist, nn, pos, valid);
@@ -296,7 +296,7 @@ TGR_RDEV void sphere_vs_bar(const RParams<S>& P, V3<F> c, V3<F> xo, V3<F> zo, bo
 // c0: r-cylinder against r-cylinder (side-side); c1, c2: the deepest and the second deepest of everything else; dropped: further hits that
 // found no slot
 template <typename F, typename S>
-TGR_RDEV void bar_pair_contacts(const RParams<S>& P, V3<F> xA, V3<F> zA, V3<F> xB, V3<F> zB, typename LaneTraits<F>::B lanes,
+TGR_RDEV void bar_pair_contacts(const RParams<S>& P, F capr, V3<F> xA, V3<F> zA, V3<F> xB, V3<F> zB, typename LaneTraits<F>::B lanes,
                                 RContact<F>& c0, RContact<F>& c1, RContact<F>& c2, F& dropped) {
   typedef typename LaneTraits<F>::B B;
   const F zero = F(S(0));
@@ -323,7 +323,7 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, V3<F> xA, V3<F> zA, V3<F> x
     F tc = clamp_(dB + b * sc, F(-P.bar_half), F(P.bar_half));
     sc = clamp_(b * tc - dA, F(-P.bar_half), F(P.bar_half));
     V3<F> dv = (xB + tc * zB) - (xA + sc * zA);
-    const S reach = S(2) * P.cap_r + S(1e-6);
+    const F reach = S(2) * capr + S(1e-6);
     near_ = lanes & (dot(dv, dv) <= reach * reach);
   }
   if (!any_lane(near_)) return;
@@ -342,7 +342,7 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, V3<F> xA, V3<F> zA, V3<F> x
   auto deep = near_ & okdir & (dd - S(2) * P.rcyl_r < -(P.rcyl_r - P.bcyl_r));
   B ends = B(false);
   {
-    const S reach2 = (S(2) * P.cap_r + S(1e-6)) * (S(2) * P.cap_r + S(1e-6));
+    const F reach2 = (S(2) * capr + S(1e-6)) * (S(2) * capr + S(1e-6));
     for (int e = 0; e < 2; e++) {
       const S sg = e == 0 ? P.bar_half : -P.bar_half;
       V3<F> ea = (xA + sg * zA) - xB;
@@ -372,20 +372,20 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, V3<F> xA, V3<F> zA, V3<F> x
     }
   for (int ea = 0; ea < 2; ea++) {
     V3<F> ca = xA + (ea == 0 ? P.bar_half : -P.bar_half) * zA;
-    sphere_vs_bar(P, ca, xB, zB, false, near_, best, second, count);
+    sphere_vs_bar(P, capr, ca, xB, zB, false, near_, best, second, count);
     for (int eb = 0; eb < 2; eb++) {
       V3<F> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
       V3<F> dv = cb - ca;
       F cd = sqrt_(dot(dv, dv));
-      F dist = cd - S(2) * P.cap_r;
+      F dist = cd - S(2) * capr;
       V3<F> nn = rcp_(max_(cd, F(S(1e-30)))) * dv;
-      V3<F> pos = ca + (P.cap_r + S(0.5) * dist) * nn;
+      V3<F> pos = ca + (capr + S(0.5) * dist) * nn;
       keep_deeper(best, second, count, dist, nn, pos, near_ & (cd > S(1e-12)));
     }
   }
   for (int eb = 0; eb < 2; eb++) {
     V3<F> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
-    sphere_vs_bar(P, cb, xA, zA, true, near_, best, second, count);
+    sphere_vs_bar(P, capr, cb, xA, zA, true, near_, best, second, count);
   }
   {
     auto hit = best.ok;
@@ -439,9 +439,8 @@ template <typename F, typename I, typename S> TGR_RDEV F hf_at(const RParams<S>&
 // cells under it.  dist >= 0: no contact.  Same rules as tgr_device.h hfield_cap; coordinates are taken relative to the corner of the first
 // cell before they become F, so that a robot 30 m from the origin resolves its contact distance as well as one at the origin.
 template <typename K, typename F, typename SK, typename S>
-TGR_RDEV void hfield_cap(const RParams<SK>& PK, const RParams<S>& P, V3<K> pk, F* dist_out, V3<F>* n_out) {
+TGR_RDEV void hfield_cap(const RParams<SK>& PK, const RParams<S>& P, F rad, V3<K> pk, F* dist_out, V3<F>* n_out) {
   typedef typename LaneTraits<F>::I I;
-  const S rad = P.cap_r;
   const F zero = F(S(0));
   const F px = cvt<F>(pk.x), py = cvt<F>(pk.y), pz = cvt<F>(pk.z);
   const auto inb = !((px < -P.hf_rx - rad) | (px > P.hf_rx + rad) | (py < -P.hf_ry - rad) | (py > P.hf_ry + rad) | (pz > P.hf_ez + rad));
@@ -481,7 +480,7 @@ TGR_RDEV void hfield_cap(const RParams<SK>& PK, const RParams<S>& P, V3<K> pk, F
           const SK sg = tri == 0 ? SK(1) : SK(-1);  // tri 1: the corner is (c+1, r+1), its edges run towards -x and -y
           const K nx = -(PK.hf_dy * (he - h0)) * sg, ny = -(PK.hf_dx * (hn - h0)) * sg, nz = K(PK.hf_dx * PK.hf_dy);
           const K rx = pxk - SK(tri == 0 ? i : i + 1) * PK.hf_dx, ry = pyk - SK(tri == 0 ? j : j + 1) * PK.hf_dy, rz = pk.z - h0;
-          const K dpl = (nx * rx + ny * ry + nz * rz) * rsqrt_(nx * nx + ny * ny + nz * nz) - PK.cap_r;
+          const K dpl = (nx * rx + ny * ry + nz * rz) * rsqrt_(nx * nx + ny * ny + nz * nz) - cvt<K>(rad);
           dist = sel(interior, cvt<F>(dpl), dist);
         }
         const auto hit = cell & (dist < S(0));
@@ -853,7 +852,7 @@ TGR_RDEV void bar_sum(int b, V3<F> PfB, V3<F> PtB, V3<F> PtA, K PkB, K PkA, V3<F
 //   kd (K, replicated): pose x, q; unconstrained acceleration l0, a0; bar axes ez       fd (F, replicated): v, w, ctrl, act
 //   td (F, per lane):   tendon-role results u, ra x u, rb x u, damping                  rd (K, per lane, per block): tendon-role constants
 constexpr int KX = 0, KQ = 9, KL0 = 21, KA0 = 30, KEZ = 39, KTAX = 48, KACT = 51, K_SLAB = 57;
-constexpr int FV = 0, FW = 9, FCTRL = 18, FDL = 30, FDA = 39, FEZ = 48, FFCL = 57, FFCA = 66, F_SLAB = 75;  // FDL / FDA: d = a - a0
+constexpr int FV = 0, FW = 9, FCTRL = 18, FDL = 30, FDA = 39, FEZ = 48, FFCL = 57, FFCA = 66, FCAPD = 75, F_SLAB = 76;  // FDL / FDA: d = a - a0; FCAPD: cap radius minus the model's
 constexpr int TU = 0, TMA = 3, TMB = 6, TDAMP = 9, T_SLAB = 10;
 constexpr int CN = 0, CRA = 3, CRB = 6, CC0 = 9, CDN = 10, CACT = 11, CJL0 = 12, CJA0 = 15, CDLA = 18, CDAA = 21, CDLB = 24, CDAB = 27, C_SLAB = 30;  // cd (F, per lane): my contact slot
 constexpr int AMB = 0, AMA = 3, AZB = 6, AZA = 9, A_SLAB = 12;  // ad (K, per lane): my slot's axial levers z x r and axes z of its two bars
@@ -992,6 +991,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       // caps on the floor: the distance is a small difference of pose quantities -> K
       const V3<K> kzc = ld3(M.kd, KEZ + 3 * jb), kxc = ld3(M.kd, KX + 3 * jb);
       const V3<F> arm = (Ro.cap_sign * P.bar_half) * cvt3<F>(kzc);
+      // this environment's cap radius: the model's, plus the episode's cap-size noise (tr_env.py:685-706; zero unless use_cap_size_noise)
+      const F capr = P.cap_r + M.fd.ld(FCAPD);
       F dist, cc, dn;
       V3<F> fn = mk<F>(zero, zero, F(S(1))), frB;  // normal and arm of my floor contact (cap, or MODEL 1: rod)
       auto fhit = Ro.is_cap;
@@ -1000,7 +1001,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
         const V3<K> org = mk<K>(K(PK.hf_x0), K(PK.hf_y0), K(PK.hf_z0));
         F d2[2]; V3<F> n2[2];
         V3<F> rn, rarm;
-        hfield_cap<K, F>(PK, P, (kxc + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc) - org, d2, n2);
+        hfield_cap<K, F>(PK, P, capr, (kxc + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc) - org, d2, n2);
         F rd = F(S(1));
         rn = mk<F>(zero, zero, F(S(1))); rarm = z3;
         static_for<3>([&](auto bc_) {  // (every bar's cylinder: the whole row works on it, lane 12 + b keeps the outcome)
@@ -1013,14 +1014,14 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
         const auto hit0 = sel(Ro.is_cap, d2[0] < S(0), sel(Ro.is_rod, rd < S(0), false));
         dist = sel(hit0, sel(Ro.is_cap, d2[0], rd), zero);
         fn = sel3(Ro.is_cap, n2[0], rn);
-        frB = sel3(Ro.is_cap, arm - (P.cap_r + S(0.5) * dist) * n2[0], rarm);
+        frB = sel3(Ro.is_cap, arm - (capr + S(0.5) * dist) * n2[0], rarm);
         fhit = hit0;
         // page 1: the cap's second terrain contact
         const auto hit1 = Ro.is_cap & (d2[1] < S(0));
         const F dist1 = sel(hit1, d2[1], zero);
         F cc1, dn1;
         contact_params(P, dist1, S(1), cc1, dn1);
-        const V3<F> rB1 = arm - (P.cap_r + S(0.5) * dist1) * n2[1];
+        const V3<F> rB1 = arm - (capr + S(0.5) * dist1) * n2[1];
         st3(M.cd, C_SLAB + CN, n2[1]); st3(M.cd, C_SLAB + CRA, z3); st3(M.cd, C_SLAB + CRB, rB1);
         M.cd.st(C_SLAB + CC0, cc1); M.cd.st(C_SLAB + CDN, dn1); M.cd.st(C_SLAB + CACT, sel(hit1, F(S(1)), zero));
         st3(M.ad, A_SLAB + AMB, cross(kzc, cvt3<K>(rB1 - arm))); st3(M.ad, A_SLAB + AZB, kzc);
@@ -1028,9 +1029,9 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
         st3(M.cd, C_SLAB + CJL0, (ylB1 + cross(yaB1, rB1)) + cc1 * n2[1]); st3(M.cd, C_SLAB + CJA0, yaB1);
         any1 = hit1;
       } else {
-        const K kdist = kxc.z + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc.z - PK.cap_r;
+        const K kdist = kxc.z + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc.z - (PK.cap_r + cvt<K>(M.fd.ld(FCAPD)));
         dist = cvt<F>(kdist);
-        frB = mk<F>(arm.x, arm.y, arm.z - (P.cap_r + S(0.5) * dist));
+        frB = mk<F>(arm.x, arm.y, arm.z - (capr + S(0.5) * dist));
         fhit = Ro.is_cap & (dist < S(0));
       }
       contact_params(P, dist, S(1), cc, dn);
@@ -1041,7 +1042,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       const V3<F> pxA = z3, pzA = ld3(M.fd, FEZ + 3 * ja_), pxB = cvt3<F>(kxc - ld3(M.kd, KX + 3 * ja_)), pzB = cvt3<F>(kzc);
       RContact<F> p0, p1, p2;
       TGR_SCHED();
-      bar_pair_contacts(P, pxA, pzA, pxB, pzB, Ro.is_pair | Ro.is_pair2, p0, p1, p2, dropped);
+      bar_pair_contacts(P, capr, pxA, pzA, pxB, pzB, Ro.is_pair | Ro.is_pair2, p0, p1, p2, dropped);
       TGR_SCHED();
       const auto s0 = Ro.sub == 0;
       const auto s2 = Ro.is_pair2;

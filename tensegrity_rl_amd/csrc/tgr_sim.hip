@@ -30,11 +30,11 @@ namespace tgr {
 // ------------------------------------------------------------------ state layout
 enum : int {
   F_QPOS = 0, F_QVEL = 21, F_WARM = 39, F_CTRL = 57, F_XYLAG = 63, F_PSILAG = 65, F_RESETPSI = 66,
-  F_EPRET = 67, F_WAYPT = 68, F_ORI = 70, F_VCMD = 72, F_ACT = 75, NF = 81
+  F_EPRET = 67, F_WAYPT = 68, F_ORI = 70, F_VCMD = 72, F_ACT = 75, F_CAPD = 81, NF = 82
 };
 enum : int { I_STEPNUM = 0, I_ELAPSED, I_RINGLEN, I_RINGHEAD, I_EPISODE, I_PHASE, I_SRC, I_SRCEP, I_HALF, NI };  // I_HALF: row kernels, paced donor rows
 constexpr int RING = 32;
-static_assert(RING == TGR_RING_CAPACITY && TGR_AUX_K == TGR_AUX_RING + RING, "aux layout of tgr_get_state / tgr_set_state");
+static_assert(RING == TGR_RING_CAPACITY && TGR_AUX_K == TGR_AUX_RING + RING + 1, "aux layout of tgr_get_state / tgr_set_state");
 constexpr double PI = 3.14159265358979323846;
 
 template <typename T> struct EnvCfg {
@@ -48,6 +48,8 @@ template <typename T> struct EnvCfg {
   unsigned long long seed, first_env_id;
   // reset streams (tgr_config.reset_stream_envs): envs per class (0: one pool per handle), donor lanes per class
   int stream_envs, stream_donors;
+  // cap-size noise (tr_env.py:143,163,685-706): per episode one radius ~ U(cap_lo, cap_hi) for the six cap spheres; cap_nominal = the model's
+  int cap_noise; double cap_lo, cap_hi, cap_nominal;
 };
 
 template <typename T> struct KArgs {
@@ -113,7 +115,7 @@ __device__ inline void philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3
 }
 __device__ inline double u53(unsigned a, unsigned b) { return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0; }
 
-struct Draws { int pose; double theta; double tendons[6]; double u_way[2]; };
+struct Draws { int pose; double theta; double tendons[6]; double u_way[2]; double u_cap; };
 template <typename T> __device__ inline Draws reset_draws(const EnvCfg<T>& E, unsigned long long env_id, unsigned long long episode) {
   Draws d;
   unsigned k0 = (unsigned)E.seed, k1 = (unsigned)(E.seed >> 32);
@@ -135,6 +137,11 @@ template <typename T> __device__ inline Draws reset_draws(const EnvCfg<T>& E, un
   philox(c0, c1, c2, 4, k0, k1, o);
   d.u_way[0] = u53(o[0], o[1]);
   d.u_way[1] = u53(o[2], o[3]);
+  d.u_cap = 0.0;
+  if (E.cap_noise) {
+    philox(c0, c1, c2, 5, k0, k1, o);
+    d.u_cap = u53(o[0], o[1]);
+  }
   return d;
 }
 
@@ -156,6 +163,7 @@ template <typename T> TGR_DEV void load_sim(const T* st, int n, int e, Sim<T>& S
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) { S.ctrl[i] = st[(F_CTRL + i) * n + e]; S.act[i] = st[(F_ACT + i) * n + e]; }
+  S.capd = st[F_CAPD * n + e];
 }
 // wb_out: body-frame angular velocity (what qvel stores), needed by the tr_env observation
 template <typename T> TGR_DEV void store_sim(T* st, int n, int e, Sim<T>& S, const Lag<T>& lag, V3<T>* wb_out) {
@@ -178,6 +186,7 @@ template <typename T> TGR_DEV void store_sim(T* st, int n, int e, Sim<T>& S, con
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) { st[(F_CTRL + i) * n + e] = S.ctrl[i]; st[(F_ACT + i) * n + e] = S.act[i]; }
+  st[F_CAPD * n + e] = S.capd;
 }
 
 template <typename T> TGR_DEV T atan2_(T y, T x) { return sizeof(T) == 4 ? T(atan2f(float(y), float(x))) : T(atan2(double(y), double(x))); }
@@ -507,6 +516,7 @@ template <typename T> TGR_DEV void init_episode(const EnvCfg<T>& E, unsigned lon
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) { S.ctrl[i] = T(dr.tendons[i]); S.act[i] = T(0); }  // mj_resetData zeroes the activations
+  S.capd = E.cap_noise ? T(E.cap_lo + dr.u_cap * (E.cap_hi - E.cap_lo) - E.cap_nominal) : T(0);  // _reset_cap_size (tr_env.py:685-706,712-713)
 }
 
 template <typename T> TGR_DEV int settle_total(const EnvCfg<T>& E) {
@@ -849,6 +859,7 @@ template <typename T, typename TK, int MODEL> TGR_DEV void row_import(const Sim<
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, S.ctrl[i]); if (MODEL) M.kd.st(row::KACT + i, TK(S.act[i])); }
+  M.fd.st(row::FCAPD, S.capd);
 #pragma unroll
   for (int i = 0; i < 18; i++) M.fd.st(row::FDL + i, T(0));
 #pragma unroll
@@ -873,6 +884,7 @@ template <typename T, typename TK, int MODEL> TGR_DEV void row_load(const T* st,
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) { M.fd.st(row::FCTRL + i, st[(F_CTRL + i) * m + e]); if (MODEL) M.kd.st(row::KACT + i, TK(st[(F_ACT + i) * m + e])); }
+  M.fd.st(row::FCAPD, st[F_CAPD * m + e]);
 #pragma unroll
   for (int i = 0; i < 18; i++) M.fd.st(row::FDL + i, T(0));
 #pragma unroll
@@ -898,6 +910,7 @@ TGR_DEV void row_export(const row::RMem<TK, T>& M, const row::RLag<TK, T>& rl, S
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) { S.ctrl[i] = M.fd.ld(row::FCTRL + i); S.act[i] = MODEL ? T(M.kd.ld(row::KACT + i)) : T(0); }
+  S.capd = M.fd.ld(row::FCAPD);
 #pragma unroll
   for (int i = 0; i < 9; i++) lag.tenL[i] = M.lp.ld(row::lidx(row::LPT + i));
   lag.cfrc_absmax = rl.cfrc_absmax; lag.cfrc_clip_sq = rl.cfrc_clip_sq; lag.bar_contact = rl.bar_contact;
@@ -1554,6 +1567,7 @@ extern "C" int tgr_default_config(tgr_config* c, int env_kind, int desired_actio
   c->reset_noise_scale = 0.0;
   c->kernel_layout = TGR_KERNEL_AUTO;
   c->solver_rel_tolerance = 0;
+  c->use_cap_size_noise = 0; c->cap_size_noise_range[0] = 0.04; c->cap_size_noise_range[1] = 0.09;  // tr_env.py:143,163
   return TGR_OK;
 }
 
@@ -1637,6 +1651,8 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   E.ten_mean = c.tendon_reset_mean; E.ten_std = c.tendon_reset_stdev; E.ten_max = c.tendon_max_length; E.ten_min = c.tendon_min_length;
   E.seed = c.seed; E.first_env_id = c.first_env_id; E.reset_noise = c.reset_noise_scale;
   E.stream_envs = h->n_classes > 0 ? h->stream_envs : 0; E.stream_donors = h->stream_donors;
+  E.cap_noise = (c.use_cap_size_noise && c.env_kind == TGR_ENV_TR) ? 1 : 0; E.cap_lo = c.cap_size_noise_range[0]; E.cap_hi = c.cap_size_noise_range[1];
+  E.cap_nominal = c.cap_radius;
   k.n = h->n; k.m = h->m;
   {
     // Paced donor rows (step_kernel_row): the rows that do not fit the first round of wave slots -- one round holds 4 rows per wavefront,
@@ -1758,6 +1774,9 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   }
   if (cfg->model_kind < 0 || cfg->model_kind > 1) { g_err = "tgr_create: model_kind must be 0 (flat) or 1 (uneven ground)"; return TGR_ERR_UNSUPPORTED; }
   if (cfg->solimp[4] != 2.0 || cfg->solref[0] >= 0) { g_err = "tgr_create: only direct solref and power-2 solimp"; return TGR_ERR_UNSUPPORTED; }
+  if (cfg->use_cap_size_noise && cfg->env_kind == TGR_ENV_TR && cfg->kernel_layout == TGR_KERNEL_BLOCK) {
+    g_err = "tgr_create: use_cap_size_noise needs the row kernels"; return TGR_ERR_UNSUPPORTED;
+  }
   if (cfg->n_donors > 8 * n_envs) { g_err = "tgr_create: n_donors must be <= 8 * n_envs"; return TGR_ERR_INVALID; }
   if (cfg->reward_delay_steps >= RING - 1 || cfg->reward_delay_steps < 0) { g_err = "tgr_create: reward_delay_steps too large"; return TGR_ERR_INVALID; }
   int ndev = 0;
@@ -2105,6 +2124,7 @@ template <typename T> static int get_state_impl(tgr_handle* h, double* qpos, dou
       a[TGR_AUX_VCMD_X] = (double)st[(F_VCMD + 0) * n + e]; a[TGR_AUX_VCMD_Y] = (double)st[(F_VCMD + 1) * n + e];
       a[TGR_AUX_VCMD_W] = (double)st[(F_VCMD + 2) * n + e];
       for (int i = 0; i < 6; i++) a[TGR_AUX_ACT + i] = (double)st[(F_ACT + i) * n + e];
+      a[TGR_AUX_CAP_RADIUS] = h->cfg.cap_radius + (double)st[F_CAPD * n + e];
       const int len = ist[I_RINGLEN * n + e], head = ist[I_RINGHEAD * n + e];
       for (int i = 0; i < RING; i++) a[TGR_AUX_RING + i] = i < len ? (double)ring[(size_t)((head + i) % RING) * n + e] : 0.0;
     }
@@ -2153,6 +2173,7 @@ static int set_state_impl(tgr_handle* h, const double* qpos, const double* qvel,
       st[(F_VCMD + 0) * n + e] = (T)a[TGR_AUX_VCMD_X]; st[(F_VCMD + 1) * n + e] = (T)a[TGR_AUX_VCMD_Y];
       st[(F_VCMD + 2) * n + e] = (T)a[TGR_AUX_VCMD_W];
       for (int i = 0; i < 6; i++) st[(F_ACT + i) * n + e] = (T)a[TGR_AUX_ACT + i];
+      if (a[TGR_AUX_CAP_RADIUS] > 0.0) st[F_CAPD * n + e] = (T)(a[TGR_AUX_CAP_RADIUS] - h->cfg.cap_radius);  // (0: keep the lane's radius)
     }
     // the heading deque: replaced by the caller's (oldest first)
     std::vector<T> ring(RING * n);

@@ -21,10 +21,9 @@ _DIRECT = ["use_contact_forces", "use_cap_velocity", "terminate_when_unhealthy",
            "ctrl_cost_weight", "contact_cost_weight", "healthy_reward", "min_reset_heading", "max_reset_heading",
            "tendon_reset_mean", "tendon_reset_stdev", "tendon_max_length", "tendon_min_length", "ditch_reward_max",
            "ditch_reward_stdev", "waypt_reward_amplitude", "waypt_reward_stdev", "yaw_reward_weight", "use_obs_noise",
-           "obs_noise_tendon_stdev", "obs_noise_cap_pos_stdev", "reset_noise_scale"]
+           "obs_noise_tendon_stdev", "obs_noise_cap_pos_stdev", "reset_noise_scale", "use_cap_size_noise"]
 # accepted for signature compatibility, no effect on the built path (reference defaults)
 _IGNORED = ["xml_file", "render_mode", "contact_with_self_penalty",
-            "use_cap_size_noise", "cap_size_noise_range",
             "threshold_waypt", "width", "height", "camera_id", "camera_name"]
 
 
@@ -74,16 +73,13 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
         if k in _DIRECT:
             setattr(cfg, k, type(getattr(cfg, k))(kwargs.pop(k)))
         elif k in _IGNORED:
-            v = kwargs.pop(k)
-            if k == "use_cap_size_noise" and v:
-                # tr_env.py:685-706 calls model.geom_names, which the mujoco bindings do not have: it raises in the reference too
-                raise NotImplementedError("use_cap_size_noise=True is dead code in the reference (AttributeError) and is not built")
+            kwargs.pop(k)
     if "contact_force_range" in kwargs:
         lo, hi = kwargs.pop("contact_force_range")
         cfg.contact_force_lo, cfg.contact_force_hi = float(lo), float(hi)
         if desired_action == "turn":  # tensegrity_env.py:224-225
             cfg.contact_force_lo, cfg.contact_force_hi = -1000.0, 1000.0
-    for src, dst in (("way_pts_range", "waypt_range"), ("way_pts_angle_range", "waypt_angle_range")):
+    for src, dst in (("way_pts_range", "waypt_range"), ("way_pts_angle_range", "waypt_angle_range"), ("cap_size_noise_range", "cap_size_noise_range")):
         if src in kwargs:
             lo, hi = kwargs.pop(src)
             getattr(cfg, dst)[0], getattr(cfg, dst)[1] = float(lo), float(hi)

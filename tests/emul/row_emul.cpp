@@ -42,7 +42,7 @@ template <typename T> static int check_rep(const Ln<T>& x, const char* what, int
 
 template <typename TK, typename T, int MODEL>
 static int run(const double* params, const float* hf, int nrow, int ncol, int n, int nsub, double* qpos, double* qvel, const double* ctrl, double* act,
-               double* out /* [n][32] */, unsigned* trace /* [n][TRACE_WORDS] or null */) {
+               double* out /* [n][32] */, unsigned* trace /* [n][TRACE_WORDS] or null */, const double* capd /* [n] or null */) {
   typedef Ln<T> F;
   typedef Ln<TK> K;
   RParams<T> P;
@@ -75,6 +75,7 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
     }
     for (int i = 0; i < 6; i++) { fd[FCTRL + i] = F(T(ctrl[6 * e + i])); kd[KACT + i] = K(TK(act[6 * e + i])); }
     for (int i = 0; i < 18; i++) fd[FDL + i] = F(T(0));
+    fd[FCAPD] = F(T(capd ? capd[e] : 0.0));
     for (int i = 0; i < H_SLAB; i++) hd[i] = F(T(0));
     lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = F(T(0)); lag.n_own = F(T(0)); lag.cfrc_absmax = F(T(0)); lag.cfrc_clip_sq = F(T(0)); lag.bar_contact = F(T(0)); lag.overflow = F(T(0));
     for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, M, lag, s);
@@ -111,13 +112,13 @@ extern "C" void tgr_row_opcount(long long* out /* [2][16] */, int reset) {
 #endif
 // precision: 0 = fp32 throughout, 1 = fp64 throughout, 2 = mixed (pose / kinematics / tendons fp64, the rest fp32)
 extern "C" int tgr_row_emul(int precision, int model, const double* params, const float* hf, int nrow, int ncol, int n, int nsub, double* qpos,
-                            double* qvel, const double* ctrl, double* act, double* out, unsigned* trace) {
+                            double* qvel, const double* ctrl, double* act, double* out, unsigned* trace, const double* capd) {
   if (model == 0) {
-    if (precision == 1) return run<double, double, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
-    if (precision == 2) return run<double, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
-    return run<float, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
+    if (precision == 1) return run<double, double, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace, capd);
+    if (precision == 2) return run<double, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace, capd);
+    return run<float, float, 0>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace, capd);
   }
-  if (precision == 1) return run<double, double, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
-  if (precision == 2) return run<double, float, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
-  return run<float, float, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace);
+  if (precision == 1) return run<double, double, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace, capd);
+  if (precision == 2) return run<double, float, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace, capd);
+  return run<float, float, 1>(params, hf, nrow, ncol, n, nsub, qpos, qvel, ctrl, act, out, trace, capd);
 }

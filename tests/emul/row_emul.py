@@ -39,9 +39,10 @@ def params_from_oracle_model(m, tol, max_iter, ls_iter=50, ls_tol=0.01, cf=(-1.0
     return np.ascontiguousarray(p, dtype=np.float64)
 
 
-def step(params, qpos, qvel, ctrl, act=None, nsub=20, f64=True, model=0, heights=None, precision=None, trace=None):
+def step(params, qpos, qvel, ctrl, act=None, nsub=20, f64=True, model=0, heights=None, precision=None, trace=None, capd=None):
     """nsub sub-steps for n envs; returns (qpos, qvel, act, out[n, 32]) -- out: tenL[9], lag x[9], cfrc_absmax, cfrc_clip_sq, bar_contact,
-    overflow, n_unconv, n_it, n_ls, n_own.  trace: optional uint32 [n, 24] array that receives the sub-step trace (tgr_row.h RMem::dbg)"""
+    overflow, n_unconv, n_it, n_ls, n_own.  trace: optional uint32 [n, 24] array that receives the sub-step trace (tgr_row.h RMem::dbg); capd: optional per-env cap radius minus the
+    model's (cap-size noise)"""
     n = qpos.shape[0]
     qpos = np.ascontiguousarray(qpos, dtype=np.float64).copy(); qvel = np.ascontiguousarray(qvel, dtype=np.float64).copy()
     ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
@@ -52,7 +53,8 @@ def step(params, qpos, qvel, ctrl, act=None, nsub=20, f64=True, model=0, heights
     bad = lib().tgr_row_emul(int(f64) if precision is None else {'f32': 0, 'f64': 1, 'mixed': 2}[precision], int(model), params.ctypes.data_as(P), None if hf is None else hf.ctypes.data_as(C.c_void_p),
                              0 if hf is None else hf.shape[0], 0 if hf is None else hf.shape[1], n, nsub, qpos.ctypes.data_as(P),
                              qvel.ctypes.data_as(P), ctrl.ctypes.data_as(P), act.ctypes.data_as(P), out.ctypes.data_as(P),
-                             None if trace is None else trace.ctypes.data_as(C.c_void_p))
+                             None if trace is None else trace.ctypes.data_as(C.c_void_p),
+                             None if capd is None else np.ascontiguousarray(capd, dtype=np.float64).ctypes.data_as(P))
     if bad != 0:
         raise RuntimeError(f"row emulation: {bad} replicated values differed across the lanes of a row (or unsupported model)")
     return qpos, qvel, act, out

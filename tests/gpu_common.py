@@ -3,8 +3,8 @@ import numpy as np
 
 AUX = {"xy_lag_x": 0, "xy_lag_y": 1, "psi_lag": 2, "reset_psi": 3, "ep_return": 4, "step_num": 5, "elapsed": 6, "episode": 7,
        "ring_len": 8, "waypt_x": 9, "waypt_y": 10, "ori_x": 11, "ori_y": 12, "vcmd_x": 13, "vcmd_y": 14, "vcmd_w": 15, "src": 16,
-       "act": 17, "ring": 23}  # act: 17..22, ring: 23..54 (heading deque, oldest first)
-AUX_K = 55
+       "act": 17, "ring": 23, "cap_radius": 55}  # act: 17..22, ring: 23..54 (heading deque, oldest first)
+AUX_K = 56
 
 
 def qfix(a, b):
@@ -29,6 +29,7 @@ def oracle_to_gpu_state(ob, env):
         A[:, AUX[k]] = aux[k]
     A[:, AUX["act"]:AUX["act"] + 6] = ob.last_act  # actuator activations (uneven-ground model; zero otherwise)
     A[:, AUX["ring_len"]] = aux["ring_len"]; A[:, AUX["ring"]:AUX["ring"] + 32] = aux["ring"]  # self._heading_buffer
+    A[:, AUX["cap_radius"]] = [ob.env(i).model.cap_radius for i in range(n)]                   # cap-size noise (tr_env.py:685-706)
     env.set_state(qpos, qvel, ctrl, warm, A)
     return qpos, qvel
 

@@ -69,8 +69,9 @@ def test_make_config_kwargs_follow_reference_signatures():
     assert c.model_kind == 1 and c.cap_radius == 0.05 and c.site_offset == 0.05 and c.gain == 15000 and list(c.bias) == [0, 0, 0]
     assert list(c.ten_stiffness) == [10000.0] * 9 and list(c.ten_springlength) == [0.5] * 6 + [0.8] * 3 and list(c.hf_size) == [50, 50, 1, 0.1]
     assert make_config("tr_env-v0", xml_file="/somewhere/3prism_jonathan_steady_side.xml").model_kind == 0
-    with pytest.raises(NotImplementedError):
-        make_config("tr_env-v0", use_cap_size_noise=True)
+    c = make_config("tr_env-v0", use_cap_size_noise=True, cap_size_noise_range=(0.05, 0.08))   # tr_env.py:143,163
+    assert c.use_cap_size_noise == 1 and list(c.cap_size_noise_range) == [0.05, 0.08]
+    assert list(make_config("tr_env-v0").cap_size_noise_range) == [0.04, 0.09] and make_config("tr_env-v0").use_cap_size_noise == 0
 
 
 def test_product_package_never_imports_the_oracle():

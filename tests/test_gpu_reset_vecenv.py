@@ -453,3 +453,62 @@ def test_sb3_adapter_forwards_everything_under_a_stand_in_base_class(monkeypatch
         assert [sorted(x) for x in i1] == [sorted(x) for x in i2]
     assert d1.all() is not None and sb3.get_attr("dt")[0] == 0.02 and sb3.env_is_wrapped(object) == [False] * n
     sb3.close(); b_env.close()
+
+
+def test_cap_size_noise_matches_oracle_fp64(oracle):
+    """tr_env's use_cap_size_noise (tr_env.py:143,163,685-706,712-713): reset_model() first draws ONE radius ~ U(cap_size_noise_range) for the
+    episode's six cap spheres (collision radius only).  The reference's own code raises on the mujoco bindings it pins (`model.geom_names`);
+    oracle and HIP path build its evident intent with the draw taken from philox counter 5.  fp64: the radii agree, they cover the range,
+    the settled reset states agree (robots rest on caps of different sizes: cap heights above the floor follow the radius), and steps on
+    identical (state, action) agree like the other modes."""
+    from tensegrity_rl_amd import TensegrityVecEnv
+    from gpu_common import rel_env
+    O = oracle
+    n = 64
+    kw = dict(use_cap_size_noise=1)
+    env = TensegrityVecEnv(n, "tr_env-v0", precision="f64", auto_reset=False, seed=13, use_cap_size_noise=True)
+    obs = env.reset()
+    ob = O.OracleBatch(O.make_cfg("tr_env", "straight", **kw), n, seed=13)
+    oobs = ob.reset()
+    st = env.get_state()
+    r_o = np.array([ob.env(i).model.cap_radius for i in range(n)])
+    r_g = st["aux"][:, AUX["cap_radius"]]
+    assert np.abs(r_g - r_o).max() < 1e-12 and r_o.min() > 0.04 and r_o.max() < 0.09 and r_o.max() - r_o.min() > 0.03
+    q = ob.get_state()[0]
+    assert np.abs(qfix(st["qpos"], q) - q).max() < 2e-4 and np.abs(obs - oobs).max() < 2e-3
+    # the lowest cap of every robot sits one (its own) radius above the floor, minus a fraction of a millimetre of penetration
+    caps = []
+    for i in range(n):
+        caps.append(O.arr(ob.env(i).data.cap_xpos)[:, 2].min())
+    assert np.abs(np.array(caps) - r_o).max() < 1e-3
+    rng = np.random.default_rng(4)
+    for t in range(4):
+        oracle_to_gpu_state(ob, env)
+        a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
+        o_obs, o_rew = ob.step(a, auto_reset=False)[:2]
+        g_obs, g_rew = env.step(a)[:2]
+        st = env.get_state(); q2, v2 = ob.get_state()[:2]
+        assert rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3).max() < 1e-7 and rel_env(st["qvel"] - v2, v2, 1e-2).max() < 1e-5
+        assert np.abs(g_obs - o_obs).max() < 1e-5 and np.abs(g_rew - o_rew).max() < 1e-6
+    env.close(); ob.close()
+
+
+def test_cap_size_noise_with_auto_reset_redraws_per_episode():
+    """production precision, auto-reset: every episode an env receives from a donor lane carries its own radius inside the range, the
+    rollout stays finite, and a handle without the option keeps the model's 0.0675 m"""
+    from tensegrity_rl_amd import TensegrityVecEnv
+    n = 256
+    env = TensegrityVecEnv(n, "tr_env-v0", seed=2, max_episode_steps=5, use_cap_size_noise=True, cap_size_noise_range=(0.05, 0.08))
+    env.reset()
+    r0 = env.get_state()["aux"][:, AUX["cap_radius"]].copy()
+    a = np.full((n, 6), -0.1, dtype=np.float32)
+    for t in range(5):
+        obs, rew, dones, infos = env.step(a)
+    assert dones.all() and np.isfinite(obs).all()
+    r1 = env.get_state()["aux"][:, AUX["cap_radius"]]
+    assert (r1 > 0.05).all() and (r1 < 0.08).all() and np.mean(np.abs(r1 - r0) > 1e-4) > 0.9
+    env.close()
+    plain = TensegrityVecEnv(8, "tr_env-v0", seed=2, auto_reset=False)
+    plain.reset()
+    assert np.abs(plain.get_state()["aux"][:, AUX["cap_radius"]] - 0.0675).max() < 1e-9
+    plain.close()
