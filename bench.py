@@ -278,7 +278,15 @@ def main():
         dt = float(tmax.item())
     stats1 = env.stats()
     step_ms = sorted(a.elapsed_time(b) for a, b in evs)
-    kern_ms = sum(step_ms) / len(step_ms)
+    chain_ms = sum(step_ms) / len(step_ms)   # one step's work on the caller's stream: step kernel over the live rows + match + settle + gaps
+    # the dominant kernel alone -- the step kernel over the live rows -- with HIP events the library records around exactly that launch, on the
+    # stream it is launched on; measured AFTER the timed region (the events would add two packets per step to it), same workload, same state
+    env.time_kernels(128)
+    for i in range(128):
+        one_step(args.warmup + args.steps + i)
+    kt = sorted(env.kernel_times_ms(128))
+    env.time_kernels(0)
+    kern_ms = sum(kt) / len(kt) if kt else chain_ms
 
     if rank == 0:
         value = n_total * args.steps / dt
@@ -290,7 +298,8 @@ def main():
         prof = profiled() if default_workload else {"traffic": None, "valu_per_launch": None, "launches": None, "source": "not the profiled (default) workload"}
         lane_sub = max(stats1["lane_substeps"] - stats0["lane_substeps"], 1)
         ulf = useful_lane_fraction()
-        valu_rate = (prof["valu_per_launch"] * 64 / (kern_ms * 1e-3)) if prof["valu_per_launch"] else None
+        # (the profile's VALU count is per STEP -- both launches of the kernel, which overlap -- so the rate is over the step's wall time)
+        valu_rate = (prof["valu_per_launch"] * 64 / (dt / args.steps)) if prof["valu_per_launch"] else None
         out = {
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -309,10 +318,13 @@ def main():
                        "starved_resets_rank0": stats1["settle_kernel_resets"] - stats0["settle_kernel_resets"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": prof["traffic"], "traffic_source": prof["source"],
-                         "note": "step kernel: 674 algorithmic B per env-step x envs per launch / mean duration of one step's work on the caller's "
-                                 "stream (HIP events around the live-row launch + match + settle launches; the donor rows run concurrently on the "
-                                 "handle's own stream); the path is VALU-issue bound (~1e6 flop per env-step), not HBM bound: see DESIGN.md",
-                         "kernel_ms": kern_ms, "kernel_ms_p50": step_ms[len(step_ms) // 2],
+                         "note": "step kernel: 674 algorithmic B per env-step x envs per launch / mean duration of the launch that steps the live "
+                                 "rows (HIP events the library records around exactly that launch, on the caller's stream: tgr_time_kernels; "
+                                 "step_chain_ms = that launch + match + settle launches + gaps, from events around tgr_step; the donor rows run "
+                                 "concurrently in their own launch on the handle's low-priority stream); the path is VALU-issue bound (~1e6 flop "
+                                 "per env-step), not HBM bound: see DESIGN.md",
+                         "kernel_ms": kern_ms, "kernel_ms_p50": kt[len(kt) // 2] if kt else None,
+                         "step_chain_ms": chain_ms,
                          # rocprofv3 --kernel-trace of the same command: the two dispatches of the kernel per step, by grid size (threads)
                          "profiled_launches_by_grid_threads": prof["launches"],
                          # the practical bound is VALU issue of the resident waves, so report those too

@@ -241,6 +241,12 @@ int tgr_bind_real_observation(tgr_handle* h, void* real_obs_dev);
  * replaces: reads of env.data.contact / data.solver_iter after mj_step (run.py:154-161 reads data.contact the same way) */
 #define TGR_TRACE_WORDS 24
 int tgr_bind_substep_trace(tgr_handle* h, uint32_t* trace_dev);
+/* measurement (bench.py's roofline): keep HIP events around the launch of the dominant kernel -- the step kernel over the live rows (with
+ * the donor stream) or over all rows (fused launch) -- in a ring of n_slots pairs, recorded on the stream the kernel is launched on;
+ * n_slots = 0 switches it off.  tgr_kernel_times_ms synchronises and returns the durations [ms] of the last min(n, recorded) such launches,
+ * oldest first (its return value is their number, or a negative error code).  No reference counterpart */
+int tgr_time_kernels(tgr_handle* h, int n_slots);
+int tgr_kernel_times_ms(tgr_handle* h, float* out_ms, int n);
 int tgr_synchronize(tgr_handle* h);
 const char* tgr_last_error(const tgr_handle* h);
 const char* tgr_version(void);

@@ -1461,6 +1461,9 @@ struct tgr_handle {
   hipStream_t sb = nullptr;
   hipEvent_t ev_donor[2] = {nullptr, nullptr}, ev_match = nullptr;
   unsigned long long* dcmd = nullptr; int* dapplied = nullptr; int* dready = nullptr; int* consumed = nullptr;
+  // tgr_time_kernels: HIP events around the launch that steps the live rows (the dominant kernel), a ring of tm_n pairs
+  std::vector<hipEvent_t> tm_start, tm_stop;
+  int tm_n = 0; long long tm_count = 0;
   uint8_t* doneflag = nullptr;
   unsigned long long* counters = nullptr;
   float* hf = nullptr;  // heightfield elevations (model_kind 1)
@@ -1490,6 +1493,8 @@ static void free_handle(tgr_handle* h) {
   if (h->sb) (void)hipStreamDestroy(h->sb);
   for (int i = 0; i < 2; i++) if (h->ev_donor[i]) (void)hipEventDestroy(h->ev_donor[i]);
   if (h->ev_match) (void)hipEventDestroy(h->ev_match);
+  for (hipEvent_t e : h->tm_start) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->tm_stop) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -1893,6 +1898,30 @@ extern "C" int tgr_bind_substep_trace(tgr_handle* h, uint32_t* trace_dev) {
   h->trace = trace_dev;
   return TGR_OK;
 }
+extern "C" int tgr_time_kernels(tgr_handle* h, int n_slots) {
+  if (!h || n_slots < 0) return TGR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipDeviceSynchronize());
+  for (hipEvent_t e : h->tm_start) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->tm_stop) (void)hipEventDestroy(e);
+  h->tm_start.assign(n_slots, nullptr); h->tm_stop.assign(n_slots, nullptr);
+  h->tm_n = 0; h->tm_count = 0;
+  for (int i = 0; i < n_slots; i++) { HIP_TRY(h, hipEventCreate(&h->tm_start[i])); HIP_TRY(h, hipEventCreate(&h->tm_stop[i])); }
+  h->tm_n = n_slots;
+  return TGR_OK;
+}
+extern "C" int tgr_kernel_times_ms(tgr_handle* h, float* out_ms, int n) {
+  if (!h || !out_ms || n < 0) return TGR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipDeviceSynchronize());
+  const long long have = h->tm_count < h->tm_n ? h->tm_count : h->tm_n;
+  const int cnt = (int)(have < n ? have : n);
+  for (int i = 0; i < cnt; i++) {
+    const int slot = (int)((h->tm_count - cnt + i) % h->tm_n);
+    HIP_TRY(h, hipEventElapsedTime(&out_ms[i], h->tm_start[slot], h->tm_stop[slot]));
+  }
+  return cnt;
+}
 extern "C" int tgr_stats(tgr_handle* h, uint64_t out[8]) {
   if (!h || !out) return TGR_ERR_INVALID;
   unsigned long long tmp[8];
@@ -2023,7 +2052,10 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
       // live rows on the caller's stream; the donor rows advance one control period on their own low-priority stream, concurrently --
       // after the match kernel of the previous step (whose commands this launch carries out)
       k.lane_base = 0; k.lane_limit = h->n;
+      const int ti = h->tm_n ? (int)(h->tm_count++ % h->tm_n) : -1;
+      if (ti >= 0) HIP_TRY(h, hipEventRecord(h->tm_start[ti], s));
       launch_rows(k, h->n, s);
+      if (ti >= 0) HIP_TRY(h, hipEventRecord(h->tm_stop[ti], s));
       HIP_TRY(h, hipGetLastError());
       KArgs<T> kd = k;
       kd.lane_base = h->n; kd.lane_limit = h->m; kd.dbg = nullptr;
@@ -2035,7 +2067,10 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
       HIP_TRY(h, hipStreamWaitEvent(s, h->ev_donor[(h->launch - 1) & 1], 0));
       k.lane_base = 0; k.lane_limit = h->m;
     } else {
+      const int ti = h->tm_n ? (int)(h->tm_count++ % h->tm_n) : -1;
+      if (ti >= 0) HIP_TRY(h, hipEventRecord(h->tm_start[ti], s));
       launch_rows(k, h->m, s);
+      if (ti >= 0) HIP_TRY(h, hipEventRecord(h->tm_stop[ti], s));
     }
   } else {
 #ifndef TGR_FAST_BUILD

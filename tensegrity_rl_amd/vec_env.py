@@ -355,6 +355,17 @@ class TensegrityVecEnv:
         N.check(self.handle, self.lib.tgr_bind_substep_trace(self.handle, self.trace.data_ptr() if on else None), "tgr_bind_substep_trace")
         return self.trace
 
+    def time_kernels(self, n_slots):
+        """HIP events around every launch of the dominant kernel from now on (a ring of n_slots; 0 = off): tgr_time_kernels"""
+        N.check(self.handle, self.lib.tgr_time_kernels(self.handle, int(n_slots)), "tgr_time_kernels")
+
+    def kernel_times_ms(self, n):
+        out = (C.c_float * int(n))()
+        got = self.lib.tgr_kernel_times_ms(self.handle, out, int(n))
+        if got < 0:
+            N.check(self.handle, got, "tgr_kernel_times_ms")
+        return [float(out[i]) for i in range(got)]
+
     def stats(self):
         out = (C.c_uint64 * 8)()
         N.check(self.handle, self.lib.tgr_stats(self.handle, out), "tgr_stats")

@@ -66,3 +66,29 @@ def test_full_size_tr_env_uneven_rollout_crosses_resets(golden_dir):
     assert s1["donor_resets"] - s0["donor_resets"] >= 2 * n, s1
     z = st["qpos"].reshape(n, 3, 7)[:, :, 2]
     assert z.max() < 0.6 and z.min() > -1.3 and np.isfinite(st["qpos"]).all()   # standing on the terrain (z in [-1, 0]), not on a z = 0 plane
+
+
+def test_kernel_timing_events_bracket_the_dominant_launch():
+    """tgr_time_kernels / tgr_kernel_times_ms (what bench.py's roofline divides by): one duration per step, each positive and no longer than the
+    step's wall time, for the donor-stream mode and for the fused launch"""
+    import time
+    import torch
+    from tensegrity_rl_amd import TensegrityVecEnv
+    for mode in (0, 1):
+        env = TensegrityVecEnv(1024, "tensegrity_env-v0", seed=1, donor_stream=mode)
+        env.reset_tensors()
+        a = torch.zeros((1024, 6), device="cuda") - 0.2
+        for _ in range(5):
+            env.step_tensors(a)
+        env.time_kernels(16)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10):
+            env.step_tensors(a)
+        torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
+        kt = env.kernel_times_ms(16)
+        assert len(kt) == 10 and all(0.05 < x < wall for x in kt) and sum(kt) <= wall * 1.05, (kt, wall)
+        assert len(env.kernel_times_ms(4)) == 4
+        env.time_kernels(0)
+        env.step_tensors(a)
+        assert env.kernel_times_ms(4) == []
+        env.close()
