@@ -42,8 +42,11 @@ def test_full_size_tr_env_flat_auto_reset_rollout():
     lane = s1["lane_substeps"] - s0["lane_substeps"]
     assert s1["unconverged_lane_substeps"] - s0["unconverged_lane_substeps"] < 0.002 * lane, s1
     assert s1["dropped_contacts"] - s0["dropped_contacts"] < 3e-4 * n * steps, s1
-    # (four synchronised TimeLimit waves of 4096 against 8192 donor lanes: all but a handful are served by a donor)
-    assert s1["donor_resets"] - s0["donor_resets"] >= 3 * n and s1["settle_kernel_resets"] - s0["settle_kernel_resets"] <= 16, s1
+    # (four synchronised TimeLimit waves of 4096 against 8192 donor lanes: all but a handful are served by a donor -- with the donor stream;
+    # the fused launch of TGR_DONOR_STREAM=0 paces half its donor rows, which then miss the third wave)
+    assert s1["donor_resets"] - s0["donor_resets"] >= 3 * n - (n if os.environ.get("TGR_DONOR_STREAM") == "0" else 0), s1
+    if os.environ.get("TGR_DONOR_STREAM") != "0":
+        assert s1["settle_kernel_resets"] - s0["settle_kernel_resets"] <= 16, s1
     q = st["qpos"].reshape(n, 3, 7)[:, :, 3:]
     assert np.abs(np.linalg.norm(q, axis=2) - 1).max() < 1e-5 and np.isfinite(st["qvel"]).all()
     assert st["aux"][:, 6].max() < 40   # TimeLimit clock (elapsed) restarted with every reset

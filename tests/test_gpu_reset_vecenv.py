@@ -166,8 +166,8 @@ def test_full_size_properties():
     for (o1, r1, t1), (o2, r2, t2) in zip(full, part):
         assert torch.equal(o1[1024:1536], o2) and torch.equal(r1[1024:1536], r2)  # results do not depend on the sharding
     # ... and with auto-reset on (the default: reset streams in classes of 512 envs) across two waves of resets
-    full_r, _ = rollout(0, n, steps=14, max_episode_steps=6)
-    part_r, _ = rollout(1024, 512, steps=14, max_episode_steps=6)
+    full_r, _ = rollout(0, n, steps=14, max_episode_steps=6, reset_stream_envs=512)
+    part_r, _ = rollout(1024, 512, steps=14, max_episode_steps=6, reset_stream_envs=512)
     for (o1, r1, t1), (o2, r2, t2) in zip(full_r, part_r):
         assert torch.equal(o1[1024:1536], o2) and torch.equal(r1[1024:1536], r2)
     o, r, t = full[-1]
