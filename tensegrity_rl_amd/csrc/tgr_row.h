@@ -520,11 +520,12 @@ template <typename F, typename S> TGR_RDEV void seg_seg_closest(V3<F> ca, V3<F> 
 // edge under the bar, the bar taken as a capsule of the cylinder's radius.  Same rules as tgr_device.h hfield_rod (3 x 3 cells x 3 edges in
 // the order j, i, k; the first of equally deep edges wins), but the 27 edge tests are dealt out over the 16 lanes of the row (lane l takes
 // edges l and l + 16) and the winner comes back through the row: 2 tests per lane instead of 27.  Returns dist (>= 0: none), normal,
-// arm -- replicated.
+// arm -- replicated.  (azk: the bar's axis in K.)
 template <typename K, typename F, typename SK, typename S>
-TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, V3<F> az, V3<F>& n_out, V3<F>& arm_out) {
+TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, V3<K> azk, V3<F>& n_out, V3<F>& arm_out) {
   typedef typename LaneTraits<F>::I I;
-  const S rad = P.rcyl_r, H = P.bar_half;
+  const S rad = P.rcyl_r, H = P.bar_half, near = S(2e-5);
+  const V3<F> az = cvt3<F>(azk);
   const F zero = F(S(0));
   const V3<F> z3 = mk<F>(zero, zero, zero);
   const F cx = cvt<F>(ck.x), cy = cvt<F>(ck.y), cz = cvt<F>(ck.z);
@@ -540,7 +541,6 @@ TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, 
   const K x0 = cvt<K>(from_int(c0, F())) * PK.hf_dx - PK.hf_rx, y0 = cvt<K>(from_int(r0, F())) * PK.hf_dy - PK.hf_ry;
   const V3<F> c = mk<F>(cvt<F>(ck.x - x0), cvt<F>(ck.y - y0), cz);
   F best = F(S(1)), bt = F(S(99));
-  V3<F> bpa = c, bpb = c;
   const I l = lane_id();
   for (int h = 0; h < 2; h++) {
     // my edge t = (j * 3 + i) * 3 + k of cell (c0 + i, r0 + j): k = 0: (c,r)-(c+1,r), 1: (c,r)-(c,r+1), 2: the strip diagonal (c,r+1)-(c+1,r)
@@ -559,21 +559,39 @@ TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, 
     const V3<F> pa = c + s_ * az, pb = mid + t_ * ed;
     const V3<F> df = pa - pb;
     const F dist = sqrt_(dot(df, df)) - rad;
-    const auto take = cell & (dist < S(0)) & (dist < best);
-    best = sel(take, dist, best); bpa = sel3(take, pa, bpa); bpb = sel3(take, pb, bpb); bt = sel(take, from_int(t, F()), bt);
+    const auto take = cell & (dist < near) & (dist < best);
+    best = sel(take, dist, best); bt = sel(take, from_int(t, F()), bt);
   }
   // the deepest edge of the row; of equally deep ones the first in the order of the plain loop
   const F dmin = -rowmax(-best);
-  const auto cand = (best == dmin) & (best < S(0));
+  const auto cand = (best == dmin) & (best < near);
   const F tmin = -rowmax(-sel(cand, bt, F(S(99))));
-  const auto win = cand & (bt == tmin);
-  const V3<F> wpa = rowsum3(sel3(win, bpa, z3)), wpb = rowsum3(sel3(win, bpb, z3));
-  const V3<F> df = wpa - wpb;
-  const F nn = sqrt_(dot(df, df));
-  const auto ok = (dmin < S(0)) & (nn > S(1e-12));
-  n_out = sel3(ok, rcp_(max_(nn, F(S(1e-30)))) * df, mk<F>(zero, zero, F(S(1))));
-  arm_out = sel3(ok, (wpa - c) - (rad + S(0.5) * dmin) * n_out, z3);
-  return sel(ok, dmin, F(S(1)));
+  // The search above is F and only NAMES the edge; whether the bar touches it, how deep, and where, is formed again in K for that one edge
+  // (every lane the same): over the metre-sized cells an F distance carries 2e-7 m of rounding, which moved a bar across dist = 0 in one
+  // env-step in a thousand (profiles/round3_accuracy_classified.log: most of the uneven model's contact flips were these).  Candidates
+  // are therefore kept up to `near` above the surface, and the K distance decides.
+  const auto some = tmin < S(27);
+  const I tw = sel(some, to_int(tmin), I(0));
+  const I j = (tw * 57) >> 9, rem = tw - j * 9, i = (rem * 43) >> 7, k = rem - i * 3;
+  const I ia = i, ja = j + sel(k == 2, I(1), I(0)), ib = i + sel(k == 1, I(0), I(1)), jb = j + sel(k == 1, I(1), I(0));
+  const V3<K> vaK = mk<K>(cvt<K>(from_int(ia, F())) * PK.hf_dx, cvt<K>(from_int(ja, F())) * PK.hf_dy, cvt<K>(hf_at<F>(P, c0 + ia, r0 + ja)));
+  const V3<K> vbK = mk<K>(cvt<K>(from_int(ib, F())) * PK.hf_dx, cvt<K>(from_int(jb, F())) * PK.hf_dy, cvt<K>(hf_at<F>(P, c0 + ib, r0 + jb)));
+  const V3<K> cK = mk<K>(ck.x - x0, ck.y - y0, ck.z);
+  V3<K> edK = vbK - vaK;
+  const K elK = sqrt_(dot(edK, edK));
+  edK = (K(SK(1)) / elK) * edK;
+  const V3<K> midK = SK(0.5) * (vaK + vbK);
+  K sK, tK;
+  seg_seg_closest(cK, azk, PK.bar_half, midK, edK, SK(0.5) * elK, sK, tK);
+  const V3<K> armK = sK * azk;
+  const V3<K> dfK = (cK + armK) - (midK + tK * edK);
+  const K nnK = sqrt_(dot(dfK, dfK));
+  const K distK = nnK - PK.rcyl_r;
+  const auto ok = some & (distK < SK(0)) & (nnK > SK(1e-12));
+  const F dist = cvt<F>(distK);
+  n_out = sel3(ok, cvt3<F>((K(SK(1)) / max_(nnK, K(SK(1e-30)))) * dfK), mk<F>(zero, zero, F(S(1))));
+  arm_out = sel3(ok, cvt3<F>(armK) - (rad + S(0.5) * dist) * n_out, z3);
+  return sel(ok, dist, F(S(1)));
 }
 
 // ------------------------------------------------------------------ row-distributed dense algebra (lane i holds row i)
@@ -1007,7 +1025,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
         static_for<3>([&](auto bc_) {  // (every bar's cylinder: the whole row works on it, lane 12 + b keeps the outcome)
           constexpr int b = decltype(bc_)::value;
           V3<F> bn, barm;
-          const F bd = hfield_rod_row<K, F>(PK, P, ld3(M.kd, KX + 3 * b) - org, cvt3<F>(ld3(M.kd, KEZ + 3 * b)), bn, barm);
+          const F bd = hfield_rod_row<K, F>(PK, P, ld3(M.kd, KX + 3 * b) - org, ld3(M.kd, KEZ + 3 * b), bn, barm);
           const auto mine = Ro.r == 12 + b;
           rd = sel(mine, bd, rd); rn = sel3(mine, bn, rn); rarm = sel3(mine, barm, rarm);
         });

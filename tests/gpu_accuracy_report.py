@@ -19,12 +19,19 @@ def oracle_trace(ob):
     return np.array([np.ctypeslib.as_array(ob.env(i).data.trace)[:20].copy() for i in range(ob.n)], dtype=np.uint32)
 
 
+FLIP_CLASSES = {"cap on the floor": 0x00003f, "bar pair": 0x000fc0, "lanes 12-14 (pair's third slot / bar on the terrain)": 0x007000,
+                "cap on a second facet": 0x3f0000}
+
+
 def classify(trg, tro):
-    """per env: (flip, capped) from the device trace [n, 24] and the oracle trace [n, 20] of the same env-step"""
+    """per env: (flip, capped, first) from the device trace [n, 24] and the oracle trace [n, 20] of the same env-step; first = the bits in
+    which the first differing sub-step differs (0 where there is no flip)"""
     trg = np.asarray(trg).astype(np.uint32)[:, :20]
-    flip = ((trg & 0x3fffff) != (np.asarray(tro, dtype=np.uint32)[:, :20] & 0x3fffff)).any(axis=1)
+    diff = (trg & 0x3fffff) ^ (np.asarray(tro, dtype=np.uint32)[:, :20] & 0x3fffff)
+    flip = (diff != 0).any(axis=1)
     capped = ((trg >> 30) & 1).astype(bool).any(axis=1)
-    return flip, capped
+    first = diff[np.arange(diff.shape[0]), np.argmax(diff != 0, axis=1)]
+    return flip, capped, first
 
 
 def run_case(kind, uneven, n, steps, img, **kw):
@@ -36,7 +43,7 @@ def run_case(kind, uneven, n, steps, img, **kw):
     env = TensegrityVecEnv(n, kind + "-v0", precision="f32", auto_reset=False, seed=1234, **gkw, **kw)
     trace = env.bind_substep_trace()
     rng = np.random.default_rng(0)
-    eq, ev, fl, cp = [], [], [], []
+    eq, ev, fl, cp, fb = [], [], [], [], []
     for t in range(steps):
         oracle_to_gpu_state(ob, env)
         a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
@@ -45,11 +52,11 @@ def run_case(kind, uneven, n, steps, img, **kw):
         st = env.get_state()
         q2, v2 = ob.get_state()[:2]
         eq.append(rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3)); ev.append(rel_env(st["qvel"] - v2, v2, 1e-2))
-        f, c = classify(trace.cpu().numpy(), oracle_trace(ob))
-        fl.append(f); cp.append(c)
+        f, c, b = classify(trace.cpu().numpy(), oracle_trace(ob))
+        fl.append(f); cp.append(c); fb.append(b)
     s = env.stats()
     env.close(); ob.close()
-    return dict(eq=np.concatenate(eq), ev=np.concatenate(ev), flip=np.concatenate(fl), capped=np.concatenate(cp), stats=s)
+    return dict(eq=np.concatenate(eq), ev=np.concatenate(ev), flip=np.concatenate(fl), capped=np.concatenate(cp), first=np.concatenate(fb), stats=s)
 
 
 def summary(r):
@@ -58,7 +65,8 @@ def summary(r):
     bad = ~finite | (eq >= 1e-4) | (ev >= 1e-4)
     nf = bad & ~fl
     worst = lambda m: float(max(np.nanmax(eq[m]), np.nanmax(ev[m]))) if m.any() else 0.0
-    return dict(n=int(eq.size), qpos_in=float((eq < 1e-4).mean()), qvel_in=float((ev < 1e-4).mean()), both_in=float((~bad).mean()),
+    kinds = {name: int(((r["first"][bad & fl] & mask) != 0).sum()) for name, mask in FLIP_CLASSES.items()}
+    return dict(flip_kinds=kinds, n=int(eq.size), qpos_in=float((eq < 1e-4).mean()), qvel_in=float((ev < 1e-4).mean()), both_in=float((~bad).mean()),
                 outliers=int(bad.sum()), flip=int((bad & fl).sum()), capped=int((nf & cp).sum()), neither=int((nf & ~cp).sum()),
                 nonfinite=int((~finite).sum()), worst_flip=worst(bad & fl), worst_nonflip=worst(nf), flips_inside_bound=int((~bad & fl).sum()),
                 median_qpos=float(np.median(eq)), median_qvel=float(np.median(ev)), p99_qvel=float(np.percentile(ev, 99)), p999_qvel=float(np.percentile(ev, 99.9)),
@@ -83,3 +91,5 @@ if __name__ == "__main__":
         print(f"{kind:15s} {'uneven' if uneven else 'flat  '} | {100*u['qpos_in']:.3f} % | {100*u['qvel_in']:.3f} % | {u['outliers']:4d}: {u['flip']:4d} / {u['capped']:3d} / {u['neither']:3d} "
               f"(non-finite {u['nonfinite']}) | {u['worst_flip']:.1e} / {u['worst_nonflip']:.1e} | {u['median_qvel']:.1e} | {u['p999_qvel']:.1e} | "
               f"{u['wave_iters_per_substep']:.2f} | {100*u['unconverged_fraction']:.3f} %", flush=True)
+        if u["flip"]:
+            print("#    what flipped first in the outliers that are flips: " + ", ".join(f"{k}: {v}" for k, v in u["flip_kinds"].items() if v), flush=True)

@@ -111,11 +111,12 @@ def test_uneven_fp32_close_to_oracle(oracle, golden_dir):
     env.close(); ob.close()
 
 
-@pytest.mark.parametrize("kind,qv_min,nonflip_max", [("tensegrity_env", 0.997, 0.0005), ("tr_env", 0.993, 0.004)])
+@pytest.mark.parametrize("kind,qv_min,nonflip_max", [("tensegrity_env", 0.999, 0.0005), ("tr_env", 0.996, 0.003)])
 def test_fp32_uneven_outliers_are_classified_and_bounded(oracle, golden_dir, kind, qv_min, nonflip_max):
     """2048 envs x 8 control periods on the heightfield, every env-step outside 1e-4 classified on the device's own sub-step trace
     (tests/gpu_accuracy_report.py).  The heightfield has more discrete choices than the flat floor (facet, second facet, grid edge under a
-    bar), so flips are more frequent; what is NOT a flip is bounded in number and in size: tr_env's quasi-static robots (velocities of
+    bar); the facet-plane and bar-on-grid-edge distances are formed in fp64 for that reason, which leaves tensegrity_env at >= 99.9 % like the
+    flat floor.  What is NOT a flip is bounded in number and in size: tr_env's quasi-static robots (velocities of
     mm/s against the 1e-2 floor of the relative error) keep ~0.4 % of env-steps between 1e-4 and 1e-3."""
     from gpu_accuracy_report import run_case, summary
     u = summary(run_case(kind, True, 2048, 8, terrain(golden_dir)))
