@@ -522,7 +522,7 @@ template <typename F, typename S> TGR_RDEV void seg_seg_closest(V3<F> ca, V3<F> 
 // edges l and l + 16) and the winner comes back through the row: 2 tests per lane instead of 27.  Returns dist (>= 0: none), normal,
 // arm -- replicated.  (azk: the bar's axis in K.)
 template <typename K, typename F, typename SK, typename S>
-TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, V3<K> azk, V3<F>& n_out, V3<F>& arm_out) {
+TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, V3<K> azk, V3<F>& n_out, V3<F>& arm_out, V3<F>& off_out) {
   typedef typename LaneTraits<F>::I I;
   const S rad = P.rcyl_r, H = P.bar_half, near = S(2e-5);
   const V3<F> az = cvt3<F>(azk);
@@ -590,7 +590,8 @@ TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, 
   const auto ok = some & (distK < SK(0)) & (nnK > SK(1e-12));
   const F dist = cvt<F>(distK);
   n_out = sel3(ok, cvt3<F>((K(SK(1)) / max_(nnK, K(SK(1e-30)))) * dfK), mk<F>(zero, zero, F(S(1))));
-  arm_out = sel3(ok, cvt3<F>(armK) - (rad + S(0.5) * dist) * n_out, z3);
+  off_out = sel3(ok, -(rad + S(0.5) * dist) * n_out, z3);  // from the point of the axis the contact sits under to the contact
+  arm_out = sel3(ok, cvt3<F>(armK) + off_out, z3);
   return sel(ok, dist, F(S(1)));
 }
 
@@ -871,6 +872,9 @@ TGR_RDEV void bar_sum(int b, V3<F> PfB, V3<F> PtB, V3<F> PtA, K PkB, K PkA, V3<F
 //   td (F, per lane):   tendon-role results u, ra x u, rb x u, damping                  rd (K, per lane, per block): tendon-role constants
 constexpr int KX = 0, KQ = 9, KL0 = 21, KA0 = 30, KEZ = 39, KTAX = 48, KACT = 51, K_SLAB = 57;
 constexpr int FV = 0, FW = 9, FCTRL = 18, FDL = 30, FDA = 39, FEZ = 48, FFCL = 57, FFCA = 66, FCAPD = 75, F_SLAB = 76;  // FDL / FDA: d = a - a0; FCAPD: cap radius minus the model's
+// MODEL 1 iterates on e = d - d_ref (see substep): d_ref (FRL / FRA) and I d_ref (FGA) sit behind the common part of the slab
+constexpr int FRL = 76, FRA = 85, FGA = 94;
+template <int MODEL> constexpr int f_slab() { return MODEL ? 103 : F_SLAB; }
 constexpr int TU = 0, TMA = 3, TMB = 6, TDAMP = 9, T_SLAB = 10;
 constexpr int CN = 0, CRA = 3, CRB = 6, CC0 = 9, CDN = 10, CACT = 11, CJL0 = 12, CJA0 = 15, CDLA = 18, CDAA = 21, CDLB = 24, CDAB = 27, C_SLAB = 30;  // cd (F, per lane): my contact slot
 constexpr int AMB = 0, AMA = 3, AZB = 6, AZA = 9, A_SLAB = 12;  // ad (K, per lane): my slot's axial levers z x r and axes z of its two bars
@@ -892,6 +896,9 @@ constexpr int lidx(int i) { return (i % 10) * 16 + i / 10; }
 constexpr int TRACE_WORDS = 24;
 template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; Slab<F> hd; Slab<F> lp; unsigned* dbg; };
 
+#ifndef TGR_IMPLICIT_K
+#define TGR_IMPLICIT_K 1
+#endif
 // `LAST`: what only the last sub-step of a control period records (lagged kinematics, tendon lengths, contact wrench).
 // K / PK: lane and scalar type of the pose, the kinematics, the tendon geometry and the smooth forces; F / P: of the rest.
 template <typename K, typename F, typename SK, typename S, int MODEL, bool LAST>
@@ -908,6 +915,15 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   RContact<F> c;
   V3<F> jl0, ja0;  // my slot's residual at the unconstrained acceleration: J (a0 + B v) + c0 n
   F dropped;
+  // MODEL 1, mixed precision: my tendon's Jacobian pieces stay in K registers for the implicitfast stage (see there); otherwise td holds them
+  constexpr bool TEN_K = (MODEL != 0) && TGR_IMPLICIT_K && !std::is_same<K, F>::value;
+  // MODEL 1: Newton iterates on e = d - d_ref, d_ref = the warm start.  The uneven-ground model's tendons (1e4 N/m, uneven xml:38) and cap
+  // friction give the bars explicit accelerations of 100 .. 1000 rad/s^2 that the implicit stage takes back; an F iterate of that size is
+  // known to 6e-5 rad/s^2, which times a lever and a contact's 1 / R is 1e-2 N of noise in the gradient -- the solver then stalls far above
+  // the tolerance (measured in the emulation by rounding single quantities of the fp64 instantiation to fp32: the iterate alone left 72 % of
+  // lane-sub-steps unconverged at tol 1e-5, everything else together 5 %).  e is small, and J d_ref is folded into the residual once, in K.
+  constexpr bool SHIFT = MODEL != 0;
+  V3<K> ten_u = kz3, ten_ma = kz3, ten_mb = kz3;
   {
     TGR_PHASE(0);
     const Roles<F> Ro = lane_roles<F, MODEL>();
@@ -972,6 +988,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       f = sel(Ro.is_ten, f, kzero);
       TGR_SCHED();
       const V3<K> ma = cross(ra, u), mb = cross(rb, u);
+      if (TEN_K) { ten_u = u; ten_ma = ma; ten_mb = mb; }
 #ifndef TGR_ROW_EMUL
       if (lane_id() < 9)  // (the other lanes' columns of this slab hold the solver's history, hd)
 #endif
@@ -1013,36 +1030,39 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       const F capr = P.cap_r + M.fd.ld(FCAPD);
       F dist, cc, dn;
       V3<F> fn = mk<F>(zero, zero, F(S(1))), frB;  // normal and arm of my floor contact (cap, or MODEL 1: rod)
+      V3<F> foff = z3;                              // MODEL 1: the same arm without its part along the bar's axis
       auto fhit = Ro.is_cap;
       if (MODEL) {
         // heightfield floor (uneven xml:48,56): caps get their two deepest triangles (page 0 / page 1), a bar's r-cylinder one edge
         const V3<K> org = mk<K>(K(PK.hf_x0), K(PK.hf_y0), K(PK.hf_z0));
         F d2[2]; V3<F> n2[2];
-        V3<F> rn, rarm;
+        V3<F> rn, rarm, roff = z3;
         hfield_cap<K, F>(PK, P, capr, (kxc + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc) - org, d2, n2);
         F rd = F(S(1));
         rn = mk<F>(zero, zero, F(S(1))); rarm = z3;
         static_for<3>([&](auto bc_) {  // (every bar's cylinder: the whole row works on it, lane 12 + b keeps the outcome)
           constexpr int b = decltype(bc_)::value;
-          V3<F> bn, barm;
-          const F bd = hfield_rod_row<K, F>(PK, P, ld3(M.kd, KX + 3 * b) - org, ld3(M.kd, KEZ + 3 * b), bn, barm);
+          V3<F> bn, barm, boff;
+          const F bd = hfield_rod_row<K, F>(PK, P, ld3(M.kd, KX + 3 * b) - org, ld3(M.kd, KEZ + 3 * b), bn, barm, boff);
           const auto mine = Ro.r == 12 + b;
-          rd = sel(mine, bd, rd); rn = sel3(mine, bn, rn); rarm = sel3(mine, barm, rarm);
+          rd = sel(mine, bd, rd); rn = sel3(mine, bn, rn); rarm = sel3(mine, barm, rarm); roff = sel3(mine, boff, roff);
         });
         const auto hit0 = sel(Ro.is_cap, d2[0] < S(0), sel(Ro.is_rod, rd < S(0), false));
         dist = sel(hit0, sel(Ro.is_cap, d2[0], rd), zero);
         fn = sel3(Ro.is_cap, n2[0], rn);
-        frB = sel3(Ro.is_cap, arm - (capr + S(0.5) * dist) * n2[0], rarm);
+        foff = sel3(Ro.is_cap, -(capr + S(0.5) * dist) * n2[0], roff);
+        frB = sel3(Ro.is_cap, arm + foff, rarm);
         fhit = hit0;
         // page 1: the cap's second terrain contact
         const auto hit1 = Ro.is_cap & (d2[1] < S(0));
         const F dist1 = sel(hit1, d2[1], zero);
         F cc1, dn1;
         contact_params(P, dist1, S(1), cc1, dn1);
-        const V3<F> rB1 = arm - (capr + S(0.5) * dist1) * n2[1];
+        const V3<F> off1 = -(capr + S(0.5) * dist1) * n2[1];
+        const V3<F> rB1 = arm + off1;
         st3(M.cd, C_SLAB + CN, n2[1]); st3(M.cd, C_SLAB + CRA, z3); st3(M.cd, C_SLAB + CRB, rB1);
         M.cd.st(C_SLAB + CC0, cc1); M.cd.st(C_SLAB + CDN, dn1); M.cd.st(C_SLAB + CACT, sel(hit1, F(S(1)), zero));
-        st3(M.ad, A_SLAB + AMB, cross(kzc, cvt3<K>(rB1 - arm))); st3(M.ad, A_SLAB + AZB, kzc);
+        st3(M.ad, A_SLAB + AMB, cross(kzc, cvt3<K>(off1))); st3(M.ad, A_SLAB + AZB, kzc);
         const V3<F> ylB1 = cvt3<F>(ld3(M.kd, KL0 + 3 * jb)) + P.B * ld3(M.fd, FV + 3 * jb), yaB1 = cvt3<F>(ld3(M.kd, KA0 + 3 * jb)) + P.B * ld3(M.fd, FW + 3 * jb);
         st3(M.cd, C_SLAB + CJL0, (ylB1 + cross(yaB1, rB1)) + cc1 * n2[1]); st3(M.cd, C_SLAB + CJA0, yaB1);
         any1 = hit1;
@@ -1076,7 +1096,10 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       // 10 N m cross products; the bar's inertia about that axis is 0.0038 kg m^2):  z . (r x f + t) = f . (z x r) + t . z, with the
       // levers z x r in K.  For a cap the axial part of r drops out of z x r exactly, so only its small offset from the bar end is used.
       const V3<K> kzA = sel3(hasA, ld3(M.kd, KEZ + 3 * ja_), kz3);
-      const V3<K> offB = cvt3<K>(sel3(Ro.is_cap, c.rB - arm, c.rB));
+      // (On the heightfield the normal force has a lever about the axis too -- on the flat floor z x (0, 0, r) . (0, 0, f) is exactly 0 --
+      // so there the offset is taken as it was built, -(r + dist / 2) n, not back out of the rounded sum arm + offset: that round trip
+      // leaves 1e-7 m in a random direction, times a normal force of 10 N, on an inertia of 0.0038 kg m^2.)
+      const V3<K> offB = cvt3<K>(MODEL ? sel3(is_floor, foff, c.rB) : sel3(Ro.is_cap, c.rB - arm, c.rB));
       st3(M.ad, AMB, cross(kzc, offB)); st3(M.ad, AMA, cross(kzA, cvt3<K>(c.rA)));
       st3(M.ad, AZB, kzc); st3(M.ad, AZA, kzA);
     }
@@ -1118,13 +1141,40 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       M.hd.st(hidx(HD + 9 + 3 * b), ca.x); M.hd.st(hidx(HD + 9 + 3 * b + 1), ca.y); M.hd.st(hidx(HD + 9 + 3 * b + 2), ca.z);
       dl[b] = P.warm_start ? sel3(any_contact, cl + wx * (cl - ql_), z3) : z3;
       da[b] = P.warm_start ? sel3(any_contact, ca + wx * (ca - qa_), z3) : z3;
-      st3(M.fd, FDL + 3 * b, dl[b]); st3(M.fd, FDA + 3 * b, da[b]);
+      if (SHIFT) {
+        // the start becomes the reference d_ref; the iterate e = d - d_ref starts at zero.  I d_ref is formed once, in K
+        const V3<K> kez = ld3(M.kd, KEZ + 3 * b), kda = cvt3<K>(da[b]);
+        st3(M.fd, FRL + 3 * b, dl[b]); st3(M.fd, FRA + 3 * b, da[b]);
+        st3(M.fd, FGA + 3 * b, cvt3<F>(PK.Ixx * kda + ((PK.Izz - PK.Ixx) * dot(kez, kda)) * kez));
+        st3(M.fd, FDL + 3 * b, z3); st3(M.fd, FDA + 3 * b, z3);
+      } else {
+        st3(M.fd, FDL + 3 * b, dl[b]); st3(M.fd, FDA + 3 * b, da[b]);
+      }
     }
-    st3(M.cd, CDLA, pick_bar0(Ro.sA, dl)); st3(M.cd, CDAA, pick_bar0(Ro.sA, da));
-    st3(M.cd, CDLB, pick_bar0(Ro.sB, dl)); st3(M.cd, CDAB, pick_bar0(Ro.sB, da));
     st3(M.cd, CN, c.n); st3(M.cd, CRA, c.rA); st3(M.cd, CRB, c.rB);
     M.cd.st(CC0, c.c0); M.cd.st(CDN, c.Dn); M.cd.st(CACT, sel(c.active, F(S(1)), zero));
-    st3(M.cd, CJL0, jl0); st3(M.cd, CJA0, ja0);
+    if (SHIFT) {
+      // my slot's residual AT d_ref, in K: J (a0 + B v) + c0 n and J d_ref are 10 m/s^2 each (100..1000 rad/s^2 times levers) and cancel to
+      // the 0.1 m/s^2 the contact really sees; the iterations then only add J e, which is small
+      const I jb = sel(Ro.sB >= 0, Ro.sB, I(0)), ja_ = sel(Ro.sA >= 0, Ro.sA, I(0));
+      const auto hasA = Ro.sA >= 0;
+      const V3<K> rl = cvt3<K>(pick_bar0(Ro.sB, dl)), ra = cvt3<K>(pick_bar0(Ro.sB, da));
+      const V3<K> ylB = (ld3(M.kd, KL0 + 3 * jb) + PK.B * cvt3<K>(ld3(M.fd, FV + 3 * jb))) + rl;
+      const V3<K> yaB = (ld3(M.kd, KA0 + 3 * jb) + PK.B * cvt3<K>(ld3(M.fd, FW + 3 * jb))) + ra;
+      const V3<K> ylA = sel3(hasA, (ld3(M.kd, KL0 + 3 * ja_) + PK.B * cvt3<K>(ld3(M.fd, FV + 3 * ja_))) + cvt3<K>(pick_bar0(Ro.sA, dl)), kz3);
+      const V3<K> yaA = sel3(hasA, (ld3(M.kd, KA0 + 3 * ja_) + PK.B * cvt3<K>(ld3(M.fd, FW + 3 * ja_))) + cvt3<K>(pick_bar0(Ro.sA, da)), kz3);
+      st3(M.cd, CJL0, cvt3<F>((ylB + cross(yaB, cvt3<K>(c.rB))) - (ylA + cross(yaA, cvt3<K>(c.rA))) + cvt<K>(c.c0) * cvt3<K>(c.n)));
+      st3(M.cd, CJA0, cvt3<F>(yaB - yaA));
+      // page 1 (a cap's second facet: same bar, no body A)
+      const V3<K> rB1 = cvt3<K>(ld3(M.cd, C_SLAB + CRB)), n1 = cvt3<K>(ld3(M.cd, C_SLAB + CN));
+      st3(M.cd, C_SLAB + CJL0, cvt3<F>((ylB + cross(yaB, rB1)) + cvt<K>(M.cd.ld(C_SLAB + CC0)) * n1));
+      st3(M.cd, C_SLAB + CJA0, cvt3<F>(yaB));
+      st3(M.cd, CDLA, z3); st3(M.cd, CDAA, z3); st3(M.cd, CDLB, z3); st3(M.cd, CDAB, z3);
+    } else {
+      st3(M.cd, CDLA, pick_bar0(Ro.sA, dl)); st3(M.cd, CDAA, pick_bar0(Ro.sA, da));
+      st3(M.cd, CDLB, pick_bar0(Ro.sB, dl)); st3(M.cd, CDAB, pick_bar0(Ro.sB, da));
+      st3(M.cd, CJL0, jl0); st3(M.cd, CJA0, ja0);
+    }
   }
   auto conv = !any_contact;
   auto stall = conv & !conv;  // rows whose line search found no descent at working precision
@@ -1192,12 +1242,15 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       K tax;
       bar_sum<MODEL>(b, PfB, PtB, PtA, PkB, PkA, fB, tB, tA, tauB, tauA, third, fcl, fca, tax);
       st3(M.fd, FFCL + 3 * b, fcl); st3(M.fd, FFCA + 3 * b, fca); M.kd.st(KTAX + b, tax);
-      const V3<F> gl = P.mass * dl - fcl;
-      const V3<F> Ida = inertia_mul(P, ezb, da);
+      // (SHIFT: dl, da are the iterate e; the full d = d_ref + e)
+      const V3<F> rl = SHIFT ? ld3(M.fd, FRL + 3 * b) : z3, ra = SHIFT ? ld3(M.fd, FRA + 3 * b) : z3;
+      const V3<F> fl_ = SHIFT ? rl + dl : dl, fa_ = SHIFT ? ra + da : da;
+      const V3<F> gl = P.mass * fl_ - fcl;
+      const V3<F> Ida = SHIFT ? ld3(M.fd, FGA + 3 * b) + inertia_mul(P, ezb, da) : inertia_mul(P, ezb, da);
       V3<F> ga = Ida - fca;
-      dn = dn + P.mass * dot(dl, dl) + dot(Ida, da);
+      dn = dn + P.mass * dot(fl_, fl_) + dot(Ida, fa_);
       // M-norm of the residual: force and transverse torque in F, the axial torque from K
-      const K gax = PK.Izz * dot(kez, cvt3<K>(da)) - tax;
+      const K gax = PK.Izz * dot(kez, SHIFT ? cvt3<K>(ra) + cvt3<K>(da) : cvt3<K>(da)) - tax;
       const F gz = dot(ezb, ga);
       gn = gn + cvt<K>(im * dot(gl, gl) + (dot(ga, ga) - gz * gz) * (S(1) / P.Ixx)) + gax * gax * (SK(1) / PK.Izz);
       ga = ga + (cvt<F>(gax) - gz) * ezb;  // the direction is solved for the same axial residual the test looks at
@@ -1243,7 +1296,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       pl[b] = sel3(conv, z3, mk<F>(pr[b][0], pr[b][1], pr[b][2]));
       pa[b] = sel3(conv, z3, mk<F>(pr[b][3], pr[b][4], pr[b][5]));
       const V3<F> Ipa = inertia_mul(P, ld3(M.fd, FEZ + 3 * b), pa[b]);
-      g1 = g1 + P.mass * dot(pl[b], ld3(M.fd, FDL + 3 * b)) + dot(Ipa, ld3(M.fd, FDA + 3 * b));
+      if (SHIFT) g1 = g1 + P.mass * dot(pl[b], ld3(M.fd, FRL + 3 * b) + ld3(M.fd, FDL + 3 * b)) + (dot(pa[b], ld3(M.fd, FGA + 3 * b)) + dot(Ipa, ld3(M.fd, FDA + 3 * b)));
+      else g1 = g1 + P.mass * dot(pl[b], ld3(M.fd, FDL + 3 * b)) + dot(Ipa, ld3(M.fd, FDA + 3 * b));
       g2 = g2 + P.mass * dot(pl[b], pl[b]) + dot(Ipa, pa[b]);
     }
     const V3<F> plA = pick_bar0(Ro.sA, pl), paA = pick_bar0(Ro.sA, pa), plB = pick_bar0(Ro.sB, pl), paB = pick_bar0(Ro.sB, pa);
@@ -1306,6 +1360,11 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   }
   TGR_PHASE(8);
   TGR_FENCE();
+  if (SHIFT)
+    for (int b = 0; b < 3; b++) {  // back to d = d_ref + e: what the next sub-step starts from and what the export calls qacc - a0
+      st3(M.fd, FDL + 3 * b, ld3(M.fd, FRL + 3 * b) + ld3(M.fd, FDL + 3 * b));
+      st3(M.fd, FDA + 3 * b, ld3(M.fd, FRA + 3 * b) + ld3(M.fd, FDA + 3 * b));
+    }
   lag.n_it += n_it; lag.n_ls += n_ls;
   lag.n_unconv = lag.n_unconv + sel(conv & !stall, zero, F(S(1)));
   if (M.dbg && sidx < TRACE_WORDS) {  // (every lane of the row stores the same word)
@@ -1334,9 +1393,6 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   // W: the arithmetic of this stage.  F for the flat-floor model; K for the uneven-ground model, whose nine tendons carry 1e4 N/m and
   // 1e3 N s/m (uneven xml:38): accelerations of 1e3 m/s^2 that cancel to the few m/s^2 the robot really does -- in F that cancellation left
   // 1e-4 m/s^2 of rounding in every sub-step, 0.4 % of tr_env env-steps outside the 1e-4 bound on qvel with no contact flip to blame.
-#ifndef TGR_IMPLICIT_K
-#define TGR_IMPLICIT_K 1
-#endif
   constexpr bool WK = (MODEL != 0) && TGR_IMPLICIT_K;
   typedef typename std::conditional<WK, K, F>::type W;
   typedef typename std::conditional<WK, SK, S>::type SW;
@@ -1363,8 +1419,17 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     TGR_SCHED();
     // (lanes 9.. own no tendon: what they read here is the solver's history or never written -- zero, not garbage, enters the row sums)
     const W sc = sqrt_(PW.h * cvt<W>(sel(Ro.is_ten, M.td.ld(TDAMP), zero)));
-    const V3<W> us = sc * cvt3<W>(sel3(Ro.is_ten, ld3(M.td, TU), z3)), mas = sc * cvt3<W>(sel3(Ro.is_ten, ld3(M.td, TMA), z3)),
-                mbs = sc * cvt3<W>(sel3(Ro.is_ten, ld3(M.td, TMB), z3));
+    // (the Jacobian of my tendon: from the K registers where the stage is K -- a moment arm z x r of 0.7 m rounded to F is off by 4e-8 m, which
+    // is 6e-7 of the 0.0675 m lever the tendon has about the bar's own axis; with tendon dampers that slave that spin to the tendon rates
+    // (uneven xml:38: 1e3 N s/m on an axial inertia of 0.0038 kg m^2) it showed as 1e-6 rad/s of noise per sub-step)
+    V3<W> us, mas, mbs;
+    if (TEN_K) {
+      const auto kt = Ro.is_ten;
+      us = sc * cvt3<W>(sel3(kt, ten_u, kz3)); mas = sc * cvt3<W>(sel3(kt, ten_ma, kz3)); mbs = sc * cvt3<W>(sel3(kt, ten_mb, kz3));
+    } else {
+      us = sc * cvt3<W>(sel3(Ro.is_ten, ld3(M.td, TU), z3)); mas = sc * cvt3<W>(sel3(Ro.is_ten, ld3(M.td, TMA), z3));
+      mbs = sc * cvt3<W>(sel3(Ro.is_ten, ld3(M.td, TMB), z3));
+    }
     auto ezw = [&](I bar) { return WK ? cvt3<W>(ld3(M.kd, KEZ + 3 * bar)) : cvt3<W>(ld3(M.fd, FEZ + 3 * bar)); };
     const V3<W> was = inv_inertia(PW, ezw(Ro.ba), mas), wbs = inv_inertia(PW, ezw(Ro.bb), mbs);
     W zt = dot(us, flB - flA) + dot(mbs, faB) - dot(mas, faA);

@@ -829,7 +829,7 @@ template <typename T, typename TK, int MODEL> struct RowShared {
   TK kd[NE * k_slab<MODEL>()];
   TK rd[row::R_SLAB * 16];
   TK ad[NE * row::A_SLAB * PAGES * 16];
-  T fd[NE * row::F_SLAB];
+  T fd[NE * row::f_slab<MODEL>()];
   T td[NE * row::T_SLAB * 16];
   T cd[NE * row::C_SLAB * PAGES * 16];  // (after the last sub-step: the row's observation line, <= 49 values)
 };
@@ -838,7 +838,7 @@ template <typename T, typename TK, int MODEL> TGR_DEV row::RMem<TK, T> row_mem(R
   row::RMem<TK, T> M;
   M.dbg = dbg;
   M.kd = row::Slab<TK>{sh.kd + slot * k_slab<MODEL>(), 1, 0};
-  M.fd = row::Slab<T>{sh.fd + slot * row::F_SLAB, 1, 0};
+  M.fd = row::Slab<T>{sh.fd + slot * row::f_slab<MODEL>(), 1, 0};
   M.td = row::Slab<T>{sh.td + slot * row::T_SLAB * 16, 16, r};
   M.hd = row::Slab<T>{sh.td + slot * row::T_SLAB * 16 + 9, 1, 0};   // columns 9, 10 of the tendon slab (tgr_row.h hidx)
   M.lp = row::Slab<T>{sh.td + slot * row::T_SLAB * 16 + 11, 1, 0};  // columns 11..13 (lidx)
@@ -1752,11 +1752,11 @@ template <typename T> static void params_to_row(const Params<T>& P, const tgr_co
   R.hf_nrow = P.hf_nrow; R.hf_ncol = P.hf_ncol; R.hf = P.hf;
   const bool f32 = c.precision != TGR_PRECISION_F64;
   // (uneven-ground model: 5 cm caps on tilted facets put more contact torque about the bars' own axes -- a tighter default keeps qvel inside 1e-4)
-  // fp32 handles: g^T M^-1 g < tol^2 + rtol^2 d^T M d with (tol, rtol) = (5e-4, 2e-5) on the flat floor, (3e-4, 5e-6) on the heightfield --
+  // fp32 handles: g^T M^-1 g < tol^2 + rtol^2 d^T M d with (tol, rtol) = (5e-4, 2e-5) on the flat floor, (2e-4, 5e-6) on the heightfield --
   // the relative term is what fp32 resolves of a gradient that is the difference of forces of that size (DESIGN.md 4.1,
   // profiles/round3_tolerance_study.log); iteration cap 16, and a row whose line search finds no descent at working precision leaves at
   // once (counted with the unconverged ones)
-  R.tol = T(c.solver_tolerance > 0 ? c.solver_tolerance : (f32 ? (c.model_kind ? 3e-4 : 5e-4) : 1e-8));
+  R.tol = T(c.solver_tolerance > 0 ? c.solver_tolerance : (f32 ? (c.model_kind ? 2e-4 : 5e-4) : 1e-8));
   R.rtol = T(c.solver_rel_tolerance > 0 ? c.solver_rel_tolerance : (c.solver_rel_tolerance < 0 ? 0.0 : (f32 ? (c.model_kind ? 5e-6 : 2e-5) : 0.0)));
   R.max_iter = c.solver_iterations > 0 ? c.solver_iterations : (f32 ? 16 : 40);
   R.ls_iter = f32 ? 6 : 50;

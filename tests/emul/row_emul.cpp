@@ -55,7 +55,7 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
   for (int e = 0; e < n; e++) {
     K kd[K_SLAB], rd[R_SLAB], ad[A_SLAB * n_pages<MODEL>()];
     F hd[H_SLAB], lp[LP_SLAB];
-    F fd[F_SLAB], td[T_SLAB], cd[C_SLAB * n_pages<MODEL>()];
+    F fd[f_slab<MODEL>()], td[T_SLAB], cd[C_SLAB * n_pages<MODEL>()];
     RMem<K, F> M;
     M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0}; M.cd = Slab<F>{cd, 1, 0}; M.hd = Slab<F>{hd, 1, 0}; M.lp = Slab<F>{lp, 1, 0};
     M.dbg = trace ? trace + (size_t)TRACE_WORDS * e : nullptr;

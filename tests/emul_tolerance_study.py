@@ -19,8 +19,13 @@ VARIANTS = [("round 2: fp32 pose between steps, tol 1e-3, cap 8", True, 1e-3, 8,
             ("... tol 5e-4, rtol 5e-6", False, 5e-4, 16, 5e-6),
             ("... tol 5e-4, rtol 1e-5", False, 5e-4, 16, 1e-5),
             ("... tol 5e-4, rtol 2e-5  (flat default)", False, 5e-4, 16, 2e-5),
-            ("... tol 3e-4, rtol 5e-6  (heightfield default)", False, 3e-4, 16, 5e-6),
-            ("... tol 1e-4, rtol 0", False, 1e-4, 16, 0.0)]
+            ("... tol 3e-4, rtol 5e-6", False, 3e-4, 16, 5e-6),
+            ("... tol 1e-4, rtol 0", False, 1e-4, 16, 0.0),
+            ("... tol 2e-4, rtol 5e-6  (heightfield default)", False, 2e-4, 16, 5e-6),
+            ("... tol 1.5e-4, rtol 5e-6", False, 1.5e-4, 16, 5e-6),
+            ("... tol 1e-4, rtol 5e-6", False, 1e-4, 16, 5e-6),
+            ("... tol 1e-4, rtol 1e-5", False, 1e-4, 16, 1e-5),
+            ("... tol 2e-4, rtol 1e-5", False, 2e-4, 16, 1e-5)]
 
 
 def main():

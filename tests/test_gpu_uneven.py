@@ -106,18 +106,19 @@ def test_uneven_fp32_close_to_oracle(oracle, golden_dir):
     eq, ev = np.concatenate(eq), np.concatenate(ev)
     print("uneven fp32: qpos median %.1e frac<1e-4 %.3f ; qvel median %.1e frac<1e-4 %.3f" % (np.median(eq), (eq < 1e-4).mean(), np.median(ev), (ev < 1e-4).mean()))
     assert np.isfinite(eq).all() and np.isfinite(ev).all()
-    assert (eq < 1e-4).mean() >= 0.99 and (ev < 1e-4).mean() >= 0.985
-    assert np.median(eq) < 1e-6 and np.median(ev) < 2e-5
+    assert (eq < 1e-4).mean() >= 0.99 and (ev < 1e-4).mean() >= 0.99
+    assert np.median(eq) < 1e-6 and np.median(ev) < 1e-5
     env.close(); ob.close()
 
 
-@pytest.mark.parametrize("kind,qv_min,nonflip_max", [("tensegrity_env", 0.999, 0.0005), ("tr_env", 0.996, 0.003)])
+@pytest.mark.parametrize("kind,qv_min,nonflip_max", [("tensegrity_env", 0.999, 0.0005), ("tr_env", 0.999, 0.0005)])
 def test_fp32_uneven_outliers_are_classified_and_bounded(oracle, golden_dir, kind, qv_min, nonflip_max):
     """2048 envs x 8 control periods on the heightfield, every env-step outside 1e-4 classified on the device's own sub-step trace
     (tests/gpu_accuracy_report.py).  The heightfield has more discrete choices than the flat floor (facet, second facet, grid edge under a
     bar); the facet-plane and bar-on-grid-edge distances are formed in fp64 for that reason, which leaves tensegrity_env at >= 99.9 % like the
-    flat floor.  What is NOT a flip is bounded in number and in size: tr_env's quasi-static robots (velocities of
-    mm/s against the 1e-2 floor of the relative error) keep ~0.4 % of env-steps between 1e-4 and 1e-3."""
+    flat floor.  tr_env's quasi-static robots (velocities of mm/s against the 1e-2 floor of the relative error, so 1e-6 rad/s of spin about a
+    bar's own axis counts) needed the Newton iteration on e = d - d_ref (tgr_row.h SHIFT); with it both env classes stay
+    >= 99.9 % inside 1e-4, and what is not a flip is bounded in number and in size."""
     from gpu_accuracy_report import run_case, summary
     u = summary(run_case(kind, True, 2048, 8, terrain(golden_dir)))
     assert u["nonfinite"] == 0
