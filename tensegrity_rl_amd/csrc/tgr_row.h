@@ -1166,9 +1166,11 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       st3(M.cd, CJL0, cvt3<F>((ylB + cross(yaB, cvt3<K>(c.rB))) - (ylA + cross(yaA, cvt3<K>(c.rA))) + cvt<K>(c.c0) * cvt3<K>(c.n)));
       st3(M.cd, CJA0, cvt3<F>(yaB - yaA));
       // page 1 (a cap's second facet: same bar, no body A)
-      const V3<K> rB1 = cvt3<K>(ld3(M.cd, C_SLAB + CRB)), n1 = cvt3<K>(ld3(M.cd, C_SLAB + CN));
-      st3(M.cd, C_SLAB + CJL0, cvt3<F>((ylB + cross(yaB, rB1)) + cvt<K>(M.cd.ld(C_SLAB + CC0)) * n1));
-      st3(M.cd, C_SLAB + CJA0, cvt3<F>(yaB));
+      if (MODEL) {
+        const V3<K> rB1 = cvt3<K>(ld3(M.cd, C_SLAB + CRB)), n1 = cvt3<K>(ld3(M.cd, C_SLAB + CN));
+        st3(M.cd, C_SLAB + CJL0, cvt3<F>((ylB + cross(yaB, rB1)) + cvt<K>(M.cd.ld(C_SLAB + CC0)) * n1));
+        st3(M.cd, C_SLAB + CJA0, cvt3<F>(yaB));
+      }
       st3(M.cd, CDLA, z3); st3(M.cd, CDAA, z3); st3(M.cd, CDLB, z3); st3(M.cd, CDAB, z3);
     } else {
       st3(M.cd, CDLA, pick_bar0(Ro.sA, dl)); st3(M.cd, CDAA, pick_bar0(Ro.sA, da));
