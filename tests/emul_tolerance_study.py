@@ -21,11 +21,17 @@ VARIANTS = [("round 2: fp32 pose between steps, tol 1e-3, cap 8", True, 1e-3, 8,
             ("... tol 5e-4, rtol 2e-5  (flat default)", False, 5e-4, 16, 2e-5),
             ("... tol 3e-4, rtol 5e-6", False, 3e-4, 16, 5e-6),
             ("... tol 1e-4, rtol 0", False, 1e-4, 16, 0.0),
-            ("... tol 2e-4, rtol 5e-6  (heightfield default)", False, 2e-4, 16, 5e-6),
+            ("... tol 2e-4, rtol 5e-6", False, 2e-4, 16, 5e-6),
             ("... tol 1.5e-4, rtol 5e-6", False, 1.5e-4, 16, 5e-6),
-            ("... tol 1e-4, rtol 5e-6", False, 1e-4, 16, 5e-6),
+            ("... tol 1e-4, rtol 5e-6  (heightfield default)", False, 1e-4, 16, 5e-6),
             ("... tol 1e-4, rtol 1e-5", False, 1e-4, 16, 1e-5),
-            ("... tol 2e-4, rtol 1e-5", False, 2e-4, 16, 1e-5)]
+            ("... tol 2e-4, rtol 1e-5", False, 2e-4, 16, 1e-5),
+            ("... tol 1e-4, rtol 2e-6", False, 1e-4, 16, 2e-6),
+            ("... tol 5e-5, rtol 2e-6", False, 5e-5, 16, 2e-6),
+            ("... tol 5e-5, rtol 5e-6", False, 5e-5, 16, 5e-6),
+            ("... tol 3e-5, rtol 1e-6", False, 3e-5, 16, 1e-6)]
+if os.environ.get("TGR_STUDY_ONLY"):   # e.g. TGR_STUDY_ONLY="2e-4, rtol 5e-6|1e-4, rtol 2e-6": a subset, by substring of the name
+    VARIANTS = [v for v in VARIANTS if any(k in v[0] for k in os.environ["TGR_STUDY_ONLY"].split("|"))]
 
 
 def main():
