@@ -1082,21 +1082,6 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       TGR_SCHED();
       bar_pair_contacts(P, capr, pxA, pzA, pxB, pzB, Ro.is_pair | Ro.is_pair2, p0, p1, p2, dropped, S(2e-5));
       TGR_SCHED();
-      if (any_lane(p0.active)) {
-        // Two bars side to side: whether they touch, and how deep, is decided on the distance of the two axes formed again in K (the F
-        // routine above names the candidate): over relative coordinates of 0.3 m an F distance carries 1e-7 m, ten times what the pose
-        // itself is uncertain by -- a third of the flat floor's contact flips started at such a contact.
-        const V3<K> zAk = ld3(M.kd, KEZ + 3 * ja_), wv = ld3(M.kd, KX + 3 * ja_) - kxc;
-        const K b = dot(zAk, kzc), dA = dot(zAk, wv), dB = dot(kzc, wv);
-        const K iden = K(SK(1)) / max_(K(SK(1)) - b * b, K(SK(1e-12)));
-        const K s_ = (b * dB - dA) * iden, t_ = (dB - b * dA) * iden;
-        const V3<K> dif = (t_ * kzc - s_ * zAk) - wv;
-        const K distK = sqrt_(dot(dif, dif)) - SK(2) * PK.rcyl_r;
-        const auto hitK = p0.active & (distK < SK(0));
-        F cc0, dn0;
-        contact_params(P, sel(hitK, cvt<F>(distK), zero), S(2), cc0, dn0);
-        p0.active = hitK; p0.c0 = sel(hitK, cc0, zero); p0.Dn = sel(hitK, dn0, zero);
-      }
       const auto s0 = Ro.sub == 0;
       const auto s2 = Ro.is_pair2;
       c.n = sel3(is_floor, fn, sel3(s2, p2.n, sel3(s0, p0.n, p1.n)));
@@ -1107,6 +1092,26 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       c.active = sel(is_floor, fhit, sel(s2, p2.active, sel(Ro.is_pair, sel(s0, p0.active, p1.active), false)));
       if (MODEL) dropped = dropped + sel(p2.active, F(S(1)), zero);  // (lanes 12..14 carry the rods there: the second other contact has no slot)
       dropped = sel(Ro.is_pair & s0, dropped, zero);
+      {
+        // Two bars side to side: whether they touch, and how deep, is decided on the distance of the two axes formed again in K (the F
+        // routine above names the candidate): over relative coordinates of 0.3 m an F distance carries 1e-7 m, ten times what the pose
+        // itself is uncertain by -- a third of the flat floor's contact flips started at such a contact.  (Here, after the slot has been
+        // picked: the three candidates of the pair are dead and the K temporaries fit the register budget.)
+        const auto side = Ro.is_pair & s0 & c.active;
+        if (any_lane(side)) {
+          const V3<K> zAk = ld3(M.kd, KEZ + 3 * ja_), wv = ld3(M.kd, KX + 3 * ja_) - kxc;
+          const K b = dot(zAk, kzc), dA = dot(zAk, wv), dB = dot(kzc, wv);
+          const K iden = K(SK(1)) / max_(K(SK(1)) - b * b, K(SK(1e-12)));
+          const K s_ = (b * dB - dA) * iden, t_ = (dB - b * dA) * iden;
+          const V3<K> dif = (t_ * kzc - s_ * zAk) - wv;
+          const K distK = sqrt_(dot(dif, dif)) - SK(2) * PK.rcyl_r;
+          const auto hitK = side & (distK < SK(0));
+          F cc0, dn0;
+          contact_params(P, sel(hitK, cvt<F>(distK), zero), S(2), cc0, dn0);
+          c.active = (side & hitK) | (!side & c.active);
+          c.c0 = sel(side, sel(hitK, cc0, zero), c.c0); c.Dn = sel(side, sel(hitK, dn0, zero), c.Dn);
+        }
+      }
       // The torque of my contact force about the OWN AXIS of each of its bars is the one place where fp32 is not enough (1e-6 N m inside
       // 10 N m cross products; the bar's inertia about that axis is 0.0038 kg m^2):  z . (r x f + t) = f . (z x r) + t . z, with the
       // levers z x r in K.  For a cap the axial part of r drops out of z x r exactly, so only its small offset from the bar end is used.

@@ -1005,7 +1005,8 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   }
   // Who this row is gets worked out a second time, from laundered thread and block numbers: carried through the twenty sub-steps in
   // registers it was spilled (a dozen dwords per lane: 6 MB of scratch stores per launch), recomputed it is ten instructions.
-  unsigned tx2 = threadIdx.x, bx2 = blockIdx.x;
+  // (TGR_ROW_ENVS == 4: the block is one wavefront and the thread number is the lane number, which mbcnt gives without keeping v0 alive)
+  unsigned tx2 = TGR_ROW_ENVS == 4 ? __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : threadIdx.x, bx2 = blockIdx.x;
   asm volatile("" : "+v"(tx2));
   asm volatile("" : "+s"(bx2));
   {

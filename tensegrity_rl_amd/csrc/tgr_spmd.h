@@ -91,7 +91,13 @@ template <int K> TGR_RDEV bool any_slot(bool flag) {
   return (__ballot(flag) & (0x0001000100010001ull << K)) != 0ull;
 }
 // the flags of my row's 16 lanes as a bit mask (replicated), and a replicated value as a plain scalar -- for the sub-step trace
-TGR_RDEV unsigned row_bits(bool flag) { return (unsigned)((__ballot(flag) >> (threadIdx.x & 48u)) & 0xffffull); }
+// (the lane number from mbcnt, worked out where it is used: taken from threadIdx.x the shift amount is hoisted to the top of the kernel and
+// kept -- spilled -- across all twenty sub-steps)
+TGR_RDEV unsigned row_bits(bool flag) {
+  unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(l));
+  return (unsigned)((__ballot(flag) >> (l & 48u)) & 0xffffull);
+}
 template <typename T> TGR_RDEV T lane0(T x) { return x; }
 // ... or the flag of any of the slots in MASK (bit K = slot K)
 template <unsigned MASK> TGR_RDEV bool any_slots(bool flag) { return (__ballot(flag) & (0x0001000100010001ull * (unsigned long long)MASK)) != 0ull; }
