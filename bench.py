@@ -64,21 +64,28 @@ def useful_lane_fraction():
         return None
 
 
-def vecenv_rate(n, env_id, device, steps=150):
-    """env-steps/s through the numpy-facing SB3 surface -- TensegrityVecEnv.step(actions), info_mode="minimal": host actions in, host
-    obs / rewards / dones / infos out (what SB3's collect_rollouts drives, run.py:41-101).  Measured on its own env AFTER the headline
-    region; reported as config.vecenv_step_wait_env_steps_per_s, never as `value`."""
+def vecenv_rate(n, env_id, device, steps=150, info_mode="minimal"):
+    """env-steps/s through the numpy-facing SB3 surface -- TensegrityVecEnv.step(actions): host actions in, host obs / rewards / dones /
+    infos out (what SB3's collect_rollouts drives, run.py:41-101).  info_mode="minimal": what SB3 itself reads; "full": the reference's info
+    dict for every env (lazy snapshot mappings), with env 0's entries read every step the way run.py:139-161 reads them.  Measured on its
+    own env AFTER the headline region; reported as config.vecenv_step_wait[_full]_env_steps_per_s, never as `value`."""
     import numpy as np
     from tensegrity_rl_amd import TensegrityVecEnv
-    env = TensegrityVecEnv(n, env_id, device=device, desired_action="straight", desired_direction=1, seed=1234, n_donors=5 * n // 4)
+    env = TensegrityVecEnv(n, env_id, device=device, desired_action="straight", desired_direction=1, seed=1234, n_donors=5 * n // 4, info_mode=info_mode)
     env.reset()
     rng = np.random.default_rng(0)
     acts = [rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32) for _ in range(8)]
+    keys = ("x_position", "y_position", "x_velocity", "reward_forward") + (("tendon_length", "real_observation") if env_id.startswith("tr_env") else ())
+    sink = 0.0
     for i in range(20):
         env.step(acts[i % 8])
     t0 = time.perf_counter()
     for i in range(steps):
-        env.step(acts[i % 8])
+        obs, rew, dones, infos = env.step(acts[i % 8])
+        if info_mode == "full":
+            i0 = infos[0]
+            for k in keys:
+                sink += float(np.sum(i0[k]))
     dt = time.perf_counter() - t0
     env.close()
     return n * steps / dt
@@ -337,10 +344,11 @@ def main():
                          "valu_useful_frac_of_peak": (valu_rate * ulf / 78.6e12) if (valu_rate and ulf) else None},
         }
         if not args.no_vecenv and world == 1 and args.model == "flat":
-            try:
-                out["config"]["vecenv_step_wait_env_steps_per_s"] = vecenv_rate(n_local, args.env_id, local_rank)
-            except Exception as e:
-                out["config"]["vecenv_step_wait_env_steps_per_s"] = f"failed: {e}"
+            for key, mode in (("vecenv_step_wait_env_steps_per_s", "minimal"), ("vecenv_step_wait_full_env_steps_per_s", "full")):
+                try:
+                    out["config"][key] = vecenv_rate(n_local, args.env_id, local_rank, info_mode=mode)
+                except Exception as e:
+                    out["config"][key] = f"failed: {e}"
         if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed once: rank 0 of the one-GPU run
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 64)

@@ -289,6 +289,21 @@ class OracleBatch:
                 aux["ring"][i, j] = rg[(e.ring_head + j) % RING]
         return qpos, qvel, ctrl, warm, aux
 
+    def translate(self, dx, dy):
+        """move every robot (and what its env remembers of absolute positions: way-point, origin) by (dx, dy) and refresh the derived
+        arrays the way set_state's mj_forward does.  On the flat floor the physics does not depend on where the robot stands, so a
+        translated batch is the same experiment far from the origin; on the heightfield move the terrain along (model.hf_pos)."""
+        for i in range(self.n):
+            e = self.env(i)
+            q = arr(e.data.qpos)
+            for b in range(NBAR):
+                q[7 * b] += dx; q[7 * b + 1] += dy
+            e.waypt[0] += dx; e.waypt[1] += dy
+            e.oripoint[0] += dx; e.oripoint[1] += dy
+            warm = arr(e.data.qacc_warmstart).copy()
+            lib().tgo_forward(C.byref(e.model), C.byref(e.data))
+            arr(e.data.qacc_warmstart)[:] = warm
+
     def close(self):
         if self.h:
             lib().tgo_batch_destroy(self.h)

@@ -981,9 +981,13 @@ uint32_t tgo_contact_mask(const tgo_model* m, const tgo_data* d) {
       const int g1 = c->geom1 - 1 - 5 * c->body1, g2 = c->geom2 - 1 - 5 * c->body2;
       if (g1 == 0 && g2 == 0) mask |= 1u << (6 + 2 * p);
       else if (others[p]++ == 0) mask |= 1u << (7 + 2 * p);
-      else if (!m->hf_data) mask |= 1u << (12 + p); /* flat-floor model: the row kernels keep a second one of these on lane 12 + p */
+      else if (!m->hf_data && others[p] == 2) mask |= 1u << (12 + p); /* flat-floor model: the row kernels keep a second one of these on lane 12 + p */
     }
   }
+  /* bit 15: the row kernels' roving slot (lane 15) -- the next "other" contact (flat floor: the third, heightfield: the second) of the
+   * FIRST bar pair that has one */
+  for (int p = 0; p < 3; p++)
+    if (others[p] >= (m->hf_data ? 2 : 3)) { mask |= 1u << 15; break; }
   return mask;
 }
 

@@ -52,10 +52,13 @@ def build(force=False, verbose=False):
                 return LIB
             tmp = f"{LIB}.tmp.{os.getpid()}"
             cmd = [hipcc] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-o", tmp, SRC]
+            stamp = _src_hash()  # of the sources as they are NOW: an edit made while the compiler runs must leave the library stale
             subprocess.check_call(cmd)
+            if _src_hash() != stamp:
+                stamp = "stale: sources changed during the build"
             os.replace(tmp, LIB)
             with open(STAMP + ".tmp", "w") as f:
-                f.write(_src_hash())
+                f.write(stamp)
             os.replace(STAMP + ".tmp", STAMP)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

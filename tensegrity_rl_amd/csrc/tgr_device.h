@@ -139,7 +139,10 @@ template <typename T> struct Sim {
 
 // quantities of the forward pass of the LAST sub-step (what the reference reads after mj_step: one sub-step old)
 template <typename T> struct Lag {
+  // x: the lagged bar positions RELATIVE to their centre com = (x0 + x1 + x2) / 3; the centre's x, y stay in double (what the reference calls
+  // xy_position: its change per control period is the velocity that is_healthy and the rewards read, tensegrity_env.py:279,311-315)
   V3<T> x[3];
+  double com[2];
   V3<T> z[3];
   T q[3][4];
   T tenL[9];
@@ -1334,11 +1337,16 @@ TGR_DEV void substep(const Params<T>& P, Sim<T>& S, T* lds, int wid, Lag<T>& lag
   if (last) {
 #pragma unroll
     for (int b = 0; b < 3; b++) {
-      lag.x[b] = S.x[b];
       lag.z[b] = R[b].ez;
 #pragma unroll
       for (int i = 0; i < 4; i++) lag.q[b][i] = S.q[b][i];
     }
+    // (the centre is formed in double from the T coordinates: exact for fp64 handles, as good as the T state allows for fp32 ones)
+    const double cx = ((double)S.x[0].x + (double)S.x[1].x + (double)S.x[2].x) * (1.0 / 3.0), cy = ((double)S.x[0].y + (double)S.x[1].y + (double)S.x[2].y) * (1.0 / 3.0);
+    const T cz = (S.x[0].z + S.x[1].z + S.x[2].z) * T(1.0 / 3.0);
+    lag.com[0] = cx; lag.com[1] = cy;
+#pragma unroll
+    for (int b = 0; b < 3; b++) lag.x[b] = mk(T((double)S.x[b].x - cx), T((double)S.x[b].y - cy), S.x[b].z - cz);
   }
   if (wid == 0) base_bar<T, LW, 0, last, MODEL>(P, S, R, lds, lag);
   else if (wid == 1) base_bar<T, LW, 1, last, MODEL>(P, S, R, lds, lag);

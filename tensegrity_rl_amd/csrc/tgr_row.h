@@ -50,7 +50,9 @@ constexpr int pair_b(int p) { return p == 0 ? 1 : 2; }
 // contact slot c of page 0: 0..5 cap c on the floor, 6..11 sub-slot (c-6)&1 of pair (c-6)>>1 (sub-slot 0: the r-cylinders side to side, 1: the
 // deepest of every other contact of the two bars), 12..14 -- MODEL 0: the second deepest of those other contacts of pair c-12 (a bar
 // crossing deeper than 3.1 mm touches the b-cylinder inside the r-cylinder as well: mujoco keeps every geom pair), MODEL 1: rod of bar c-12
-// on the terrain; page 1 (MODEL 1 only): 0..5 second terrain contact of cap c
+// on the terrain; 15: the ROVING slot -- the next deepest "other" contact (MODEL 0: the third, MODEL 1: the second) of the first bar pair
+// that has one; which pair that is (p15) is a run-time value of the environment, kept in the xs slab, and the bars of lane 15 follow it
+// (lane_roles); page 1 (MODEL 1 only): 0..5 second terrain contact of cap c
 template <int MODEL> constexpr int slot_bar_a(int page, int c) {
   return page != 0 ? -1 : ((c >= 6 && c < 12) ? pair_a((c - 6) >> 1) : ((!MODEL && c >= 12 && c < 15) ? pair_a(c - 12) : -1));
 }
@@ -58,7 +60,7 @@ template <int MODEL> constexpr int slot_bar_b(int page, int c) {
   return c < 6 ? (c >> 1) : (page != 0 ? -1 : (c < 12 ? pair_b((c - 6) >> 1) : (c < 15 ? (MODEL ? c - 12 : pair_b(c - 12)) : -1)));
 }
 template <int MODEL> constexpr int n_pages() { return MODEL ? 2 : 1; }
-template <int MODEL> constexpr int n_slots(int page) { return page == 0 ? 15 : (MODEL ? 6 : 0); }
+template <int MODEL> constexpr int n_slots(int page) { return page == 0 ? 15 : (MODEL ? 6 : 0); }  // (fixed-bar slots; lane 15: hess_add_roving)
 
 // ------------------------------------------------------------------ replicated state of one environment
 // K: the lane type of pose, kinematics, tendon geometry and smooth forces (double in the mixed-precision production kernels: a tendon
@@ -119,7 +121,7 @@ template <typename F> struct Roles {
   // tendon role (its K constants -- site coordinates, stiffness, damping, spring length -- live in the role slab)
   B is_ten; I ba, bb; B actuated;
   // slot role (page 0)
-  B is_cap, is_pair, is_pair2, is_rod; I sub; I sA, sB; F cap_sign;
+  B is_cap, is_pair, is_pair2, is_rod, is_rove; I sub; I sA, sB; F cap_sign;
   // dof role
   B is_dof, is_ang; I k;
 };
@@ -147,7 +149,8 @@ template <typename K, typename F, typename SK, int MODEL> TGR_RDEV void store_ro
 }
 // what lane r does: pure arithmetic on the lane number, recomputed where it is needed (a role kept in a register for the whole kernel
 // costs more than the few instructions that rebuild it)
-template <typename F, int MODEL> TGR_RDEV Roles<F> lane_roles() {
+// p15: the bar pair lane 15's roving slot serves in this sub-step (replicated; < 0: none)
+template <typename F, int MODEL> TGR_RDEV Roles<F> lane_roles(typename LaneTraits<F>::I p15 = typename LaneTraits<F>::I(-1)) {
   typedef typename LaneTraits<F>::I I;
   typedef typename LaneTraits<F>::S S;
   Roles<F> R;
@@ -163,8 +166,9 @@ template <typename F, int MODEL> TGR_RDEV Roles<F> lane_roles() {
   R.is_pair = (r >= 6) & (r < 12);
   R.is_rod = MODEL ? ((r >= 12) & (r < 15)) : (r < 0);
   R.is_pair2 = MODEL ? (r < 0) : ((r >= 12) & (r < 15));  // third slot of a bar pair (flat-floor model)
-  const I pr = sel(R.is_pair2, r - 12, (r - 6) >> 1);
-  const auto anypair = R.is_pair | R.is_pair2;
+  R.is_rove = (r == 15) & (p15 >= 0);
+  const I pr = sel(R.is_rove, p15, sel(R.is_pair2, r - 12, (r - 6) >> 1));
+  const auto anypair = R.is_pair | R.is_pair2 | R.is_rove;
   R.sub = (r - 6) & 1;
   R.sA = sel(anypair, sel(pr == 2, I(1), I(0)), I(-1));
   R.sB = sel(R.is_cap, r >> 1, sel(anypair, sel(pr == 0, I(1), I(2)), sel(R.is_rod, r - 12, I(-1))));
@@ -250,24 +254,34 @@ template <typename F, typename S> TGR_RDEV RCone<F> cone_eval(const RParams<S>& 
 
 // ---- contact geometry between two bars (slot role, pair lanes); same rules as tgr_device.h bar_pair_contacts
 template <typename F> struct RCand { F dist; V3<F> n, p; typename LaneTraits<F>::B ok; };
-// the deepest and the second deepest of the candidates seen so far
-template <typename F, typename B> TGR_RDEV void keep_deeper(RCand<F>& best, RCand<F>& second, F& count, F dist, V3<F> n, V3<F> p, B valid) {
+// the deepest, the second and the third deepest of the candidates seen so far
+template <typename F> struct RCands { RCand<F> best, second, third; F count; };
+template <typename F, typename B> TGR_RDEV void keep_deeper(RCands<F>& k, F dist, V3<F> n, V3<F> p, B valid) {
   typedef typename LaneTraits<F>::S S;
+  RCand<F>& best = k.best; RCand<F>& second = k.second; RCand<F>& third = k.third;
   auto hit = valid & (dist < S(0));
-  count = count + sel(hit, F(S(1)), F(S(0)));
+  k.count = k.count + sel(hit, F(S(1)), F(S(0)));
   auto first = hit & (!best.ok | (dist < best.dist));
   auto sec = hit & !first & (!second.ok | (dist < second.dist));
+  auto thr = hit & !first & !sec & (!third.ok | (dist < third.dist));
+  {
+    const auto push = first | sec;  // the old second moves down
+    third.dist = sel(push, second.dist, sel(thr, dist, third.dist));
+    third.n = sel3(push, second.n, sel3(thr, n, third.n));
+    third.p = sel3(push, second.p, sel3(thr, p, third.p));
+    third.ok = (push & second.ok) | ((!push) & (third.ok | thr));
+  }
   second.dist = sel(first, best.dist, sel(sec, dist, second.dist));
   second.n = sel3(first, best.n, sel3(sec, n, second.n));
   second.p = sel3(first, best.p, sel3(sec, p, second.p));
-  second.ok = (first & best.ok) | (!first & (second.ok | sec));
+  second.ok = (first & best.ok) | ((!first) & (second.ok | sec));
   best.dist = sel(first, dist, best.dist);
   best.n = sel3(first, n, best.n);
   best.p = sel3(first, p, best.p);
   best.ok = best.ok | hit;
 }
 template <typename F, typename S, typename B>
-TGR_RDEV void sphere_vs_bar(const RParams<S>& P, F capr, V3<F> c, V3<F> xo, V3<F> zo, bool flip, B enable, RCand<F>& best, RCand<F>& second, F& count) {
+TGR_RDEV void sphere_vs_bar(const RParams<S>& P, F capr, V3<F> c, V3<F> xo, V3<F> zo, bool flip, B enable, RCands<F>& cands) {
   V3<F> wv = c - xo;
   F t = dot(wv, zo);
   V3<F> rad = wv - t * zo;
@@ -290,21 +304,21 @@ TGR_RDEV void sphere_vs_bar(const RParams<S>& P, F capr, V3<F> c, V3<F> xo, V3<F
     V3<F> pos = c + (capr + S(0.5) * dist) * n;
     auto valid = enable & sel(inside, rho > S(1e-12), dd > S(1e-12));
     V3<F> nn = flip ? -n : n;
-    keep_deeper(best, second, count, dist, nn, pos, valid);
+    keep_deeper(cands, dist, nn, pos, valid);
   }
 }
-// c0: r-cylinder against r-cylinder (side-side; kept as a candidate up to near0 above touching); c1, c2: the deepest and the second deepest
-// of everything else; dropped: further hits that found no slot
+// c0: r-cylinder against r-cylinder (side-side; kept as a candidate up to near0 above touching); c1, c2, c3: the deepest, the second and the
+// third deepest of everything else; count: how many of those others there are in all (the caller knows how many slots it has for them)
 template <typename F, typename S>
 TGR_RDEV void bar_pair_contacts(const RParams<S>& P, F capr, V3<F> xA, V3<F> zA, V3<F> xB, V3<F> zB, typename LaneTraits<F>::B lanes,
-                                RContact<F>& c0, RContact<F>& c1, RContact<F>& c2, F& dropped, S near0 = S(0)) {
+                                RContact<F>& c0, RContact<F>& c1, RContact<F>& c2, RContact<F>& c3, F& count, S near0 = S(0)) {
   typedef typename LaneTraits<F>::B B;
   const F zero = F(S(0));
-  c0.active = B(false); c1.active = B(false); c2.active = B(false);
-  c0.n = mk<F>(zero, zero, F(S(1))); c1.n = c0.n; c2.n = c0.n;
-  c0.rA = mk<F>(zero, zero, zero); c0.rB = c0.rA; c1.rA = c0.rA; c1.rB = c0.rA; c2.rA = c0.rA; c2.rB = c0.rA;
-  c0.c0 = zero; c1.c0 = zero; c2.c0 = zero; c0.Dn = zero; c1.Dn = zero; c2.Dn = zero;
-  dropped = zero;
+  c0.active = B(false); c1.active = B(false); c2.active = B(false); c3.active = B(false);
+  c0.n = mk<F>(zero, zero, F(S(1))); c1.n = c0.n; c2.n = c0.n; c3.n = c0.n;
+  c0.rA = mk<F>(zero, zero, zero); c0.rB = c0.rA; c1.rA = c0.rA; c1.rB = c0.rA; c2.rA = c0.rA; c2.rB = c0.rA; c3.rA = c0.rA; c3.rB = c0.rA;
+  c0.c0 = zero; c1.c0 = zero; c2.c0 = zero; c3.c0 = zero; c0.Dn = zero; c1.Dn = zero; c2.Dn = zero; c3.Dn = zero;
+  count = zero;
   V3<F> wv = xA - xB;
   F b = dot(zA, zB), dA = dot(zA, wv), dB = dot(zB, wv);
   F den = S(1) - b * b;
@@ -356,9 +370,10 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, F capr, V3<F> xA, V3<F> zA,
     ends = ends & near_;
   }
   if (!any_lane(deep | ends)) return;
-  RCand<F> best; best.ok = B(false); best.dist = zero; best.n = c0.n; best.p = xA;
-  RCand<F> second = best;
-  F count = zero;
+  RCands<F> cands;
+  cands.best.ok = B(false); cands.best.dist = zero; cands.best.n = c0.n; cands.best.p = xA;
+  cands.second = cands.best; cands.third = cands.best;
+  cands.count = zero;
   const S bc = S(0.5) * (P.bcyl_hi + P.bcyl_lo), bh = S(0.5) * (P.bcyl_hi - P.bcyl_lo);
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
@@ -368,11 +383,11 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, F capr, V3<F> xA, V3<F> zA,
       auto interior = near_ & okdir & (abs_(s - ci) < hi_) & (abs_(t - cj) < hj_);
       F dist = dd - (ri + rj);
       V3<F> pos = pa + (ri + S(0.5) * dist) * n;
-      keep_deeper(best, second, count, dist, n, pos, interior);
+      keep_deeper(cands, dist, n, pos, interior);
     }
   for (int ea = 0; ea < 2; ea++) {
     V3<F> ca = xA + (ea == 0 ? P.bar_half : -P.bar_half) * zA;
-    sphere_vs_bar(P, capr, ca, xB, zB, false, near_, best, second, count);
+    sphere_vs_bar(P, capr, ca, xB, zB, false, near_, cands);
     for (int eb = 0; eb < 2; eb++) {
       V3<F> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
       V3<F> dv = cb - ca;
@@ -380,32 +395,26 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, F capr, V3<F> xA, V3<F> zA,
       F dist = cd - S(2) * capr;
       V3<F> nn = rcp_(max_(cd, F(S(1e-30)))) * dv;
       V3<F> pos = ca + (capr + S(0.5) * dist) * nn;
-      keep_deeper(best, second, count, dist, nn, pos, near_ & (cd > S(1e-12)));
+      keep_deeper(cands, dist, nn, pos, near_ & (cd > S(1e-12)));
     }
   }
   for (int eb = 0; eb < 2; eb++) {
     V3<F> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
-    sphere_vs_bar(P, capr, cb, xA, zA, true, near_, best, second, count);
+    sphere_vs_bar(P, capr, cb, xA, zA, true, near_, cands);
   }
-  {
-    auto hit = best.ok;
-    c1.active = hit;
-    c1.n = sel3(hit, best.n, c1.n);
-    c1.rA = sel3(hit, best.p - xA, c1.rA); c1.rB = sel3(hit, best.p - xB, c1.rB);
+  auto take = [&](const RCand<F>& k, RContact<F>& c) {
+    auto hit = k.ok;
+    c.active = hit;
+    c.n = sel3(hit, k.n, c.n);
+    c.rA = sel3(hit, k.p - xA, c.rA); c.rB = sel3(hit, k.p - xB, c.rB);
     F cc, dn;
-    contact_params(P, sel(hit, best.dist, zero), S(2), cc, dn);
-    c1.c0 = sel(hit, cc, zero); c1.Dn = sel(hit, dn, zero);
-  }
-  {
-    auto hit = second.ok;
-    c2.active = hit;
-    c2.n = sel3(hit, second.n, c2.n);
-    c2.rA = sel3(hit, second.p - xA, c2.rA); c2.rB = sel3(hit, second.p - xB, c2.rB);
-    F cc, dn;
-    contact_params(P, sel(hit, second.dist, zero), S(2), cc, dn);
-    c2.c0 = sel(hit, cc, zero); c2.Dn = sel(hit, dn, zero);
-  }
-  dropped = sel(count > S(2), count - S(2), zero);
+    contact_params(P, sel(hit, k.dist, zero), S(2), cc, dn);
+    c.c0 = sel(hit, cc, zero); c.Dn = sel(hit, dn, zero);
+  };
+  take(cands.best, c1);
+  take(cands.second, c2);
+  take(cands.third, c3);
+  count = cands.count;
 }
 
 // ------------------------------------------------------------------ heightfield floor (MODEL 1), slot role, select form
@@ -787,6 +796,38 @@ TGR_RDEV void hess_add_slot(RHess<F>& H, const DofC<F>& d, const RContact<F>& c,
   }
 }
 
+// the roving slot of lane 15: its bar pair is a run-time value of the environment (p15), so each of the three pairs is handled under a mask
+// (environments whose slot serves another pair add zero), and a pair nobody in the wavefront routes to lane 15 is skipped
+template <typename F> TGR_RDEV void row_acc_masked(F* R, V3<F> wl, V3<F> wa, V3<F> arm, F m) {  // m: +1, -1 or 0
+  V3<F> t = cross(arm, wl) + wa;
+  R[0] = R[0] + m * wl.x; R[1] = R[1] + m * wl.y; R[2] = R[2] + m * wl.z; R[3] = R[3] + m * t.x; R[4] = R[4] + m * t.y; R[5] = R[5] + m * t.z;
+}
+template <typename F, typename I>
+TGR_RDEV void hess_add_roving(RHess<F>& H, const DofC<F>& d, const RContact<F>& c, const RCone<F>& o, I p15) {
+  typedef typename LaneTraits<F>::S S;
+  constexpr int C = 15;
+  SlotB<F> s;
+  s.n = bcast3<C>(c.n); s.rA = bcast3<C>(c.rA); s.rB = bcast3<C>(c.rB);
+  s.a1 = bcast<C>(o.a1); s.a2 = bcast<C>(o.a2); s.b1 = bcast<C>(o.b1); s.b2 = bcast<C>(o.b2);
+  const bool cone = any_slot<C>(o.cg != S(0));
+  if (cone) { s.cg = bcast<C>(o.cg); s.cw = bcast<C>(o.cw); s.gl = bcast3<C>(o.gl); s.ga = bcast3<C>(o.ga); s.wl = bcast3<C>(o.wl); s.wa = bcast3<C>(o.wa); }
+  V3<F> ulB, uaB, wlB, waB, ulA, uaA, wlA, waA;
+  dof_col(d, s.rB, ulB, uaB);
+  cone_mul(s, cone, ulB, uaB, wlB, waB);
+  dof_col(d, s.rA, ulA, uaA);
+  cone_mul(s, cone, ulA, uaA, wlA, waA);
+  static_for<3>([&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    constexpr int A = pair_a(p), Bb = pair_b(p);
+    const auto mine = p15 == p;
+    if (!any_lane(mine)) return;
+    const F m = sel(mine, F(S(1)), F(S(0)));
+    row_acc_masked(H.D[Bb], wlB, waB, s.rB, m);
+    row_acc_masked(hess_off(H, A, Bb), wlB, waB, s.rA, -m);  // rows: B dofs, columns: A dofs
+    row_acc_masked(H.D[A], wlA, waA, s.rA, m);
+  });
+}
+
 // p = -H^-1 g.  g: per bar distributed (lane r: component r of the bar's 6-vector); returns p replicated, pr[b][0..6)
 // c01 / c02 / c12: does ANY environment of the wavefront couple bars (0,1) / (0,2) / (1,2)?  (uniform flags; an off-diagonal block
 // nobody fills is zero and its part of the factorisation is skipped.  O21 also fills in through O20 O10^T.)
@@ -842,9 +883,10 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
 // a pair slot).  Pairs (A, B): lanes 6,7 = (0,1); 8,9 = (0,2); 10,11 = (1,2).  MODEL 1: bar b's cylinder slot on lane 12 + b (no neighbour).
 template <int L, typename F> TGR_RDEV V3<F> bcast3v(V3<F> a) { return mk<F>(bcast<L>(a.x), bcast<L>(a.y), bcast<L>(a.z)); }
 // MODEL 0: the third slot of pair (0,1) / (0,2) / (1,2) sits alone on lane 12 / 13 / 14; `third`: does any environment of the wavefront use one?
-template <int MODEL, typename K, typename F>
-TGR_RDEV void bar_sum(int b, V3<F> PfB, V3<F> PtB, V3<F> PtA, K PkB, K PkA, V3<F> fB, V3<F> tB, V3<F> tA, K tauB, K tauA, bool third, V3<F>& f,
-                      V3<F>& t, K& tax) {
+// rove / p15: does any environment of the wavefront use the roving slot (lane 15), and which pair does it serve in THIS environment
+template <int MODEL, typename K, typename F, typename I>
+TGR_RDEV void bar_sum(int b, V3<F> PfB, V3<F> PtB, V3<F> PtA, K PkB, K PkA, V3<F> fB, V3<F> tB, V3<F> tA, K tauB, K tauA, bool third, bool rove, I p15,
+                      V3<F>& f, V3<F>& t, K& tax) {
   if (b == 0) {
     f = (bcast3v<0>(PfB) - bcast3v<6>(PfB)) - bcast3v<8>(PfB);
     t = (bcast3v<0>(PtB) - bcast3v<6>(PtA)) - bcast3v<8>(PtA);
@@ -863,6 +905,17 @@ TGR_RDEV void bar_sum(int b, V3<F> PfB, V3<F> PtB, V3<F> PtA, K PkB, K PkA, V3<F
     tax = (bcast<4>(PkB) + bcast<8>(PkB)) + bcast<10>(PkB);
     if (MODEL) { f = f + bcast3v<14>(fB); t = t + bcast3v<14>(tB); tax = tax + bcast<14>(tauB); }
     else if (third) { f = (f + bcast3v<13>(fB)) + bcast3v<14>(fB); t = (t + bcast3v<13>(tB)) + bcast3v<14>(tB); tax = (tax + bcast<13>(tauB)) + bcast<14>(tauB); }
+  }
+  if (rove) {
+    // pair p15 = (A, B): bar A gets -f (torque about A's centre: tA), bar B gets +f.  (0,1), (0,2), (1,2).  (An idle slot carries zero force.)
+    typedef typename LaneTraits<F>::S S;
+    typedef typename LaneTraits<K>::S SK;
+    const V3<F> z3 = mk<F>(F(S(0)), F(S(0)), F(S(0)));
+    const auto asA = b == 0 ? ((p15 == 0) | (p15 == 1)) : (b == 1 ? (p15 == 2) : (p15 == 99));
+    const auto asB = b == 0 ? (p15 == 99) : (b == 1 ? (p15 == 0) : ((p15 == 1) | (p15 == 2)));
+    f = (f + sel3(asB, bcast3v<15>(fB), z3)) - sel3(asA, bcast3v<15>(fB), z3);
+    t = (t + sel3(asB, bcast3v<15>(tB), z3)) - sel3(asA, bcast3v<15>(tA), z3);
+    tax = (tax + sel(asB, bcast<15>(tauB), K(SK(0)))) - sel(asA, bcast<15>(tauA), K(SK(0)));
   }
 }
 
@@ -884,6 +937,15 @@ constexpr int RSA = 0, RSB = 3, RTK = 6, RTB = 7, RTL0 = 8, R_SLAB = 9;
 constexpr int HD = 0, HPC = 18, HPPC = 19, H_SLAB = 20;
 // lp (F, replicated): the lagged pose of the last sub-step, x (9), q (12), and its tendon lengths (9) -- columns 11..13 of the tendon slab.
 constexpr int LPX = 0, LPQ = 9, LPT = 21, LP_SLAB = 30;
+// lc (K, replicated): the lagged centre of the three bars, (x0 + x1 + x2) / 3 -- what the reference calls xy_position (tensegrity_env.py:293-294,
+// 311-315).  The lagged bar positions in lp are kept RELATIVE to it: everything the env layer derives from them (headings, cap positions
+// about the centroid) is a difference of positions, and the one absolute quantity -- the centre itself, whose change per control period is
+// the x / y velocity the health test and the reward read -- stays in K.  A robot 30 m from the origin resolves its fp32 coordinates to
+// 2e-6 m, i.e. 1e-4 m/s of velocity: the size of the is_healthy threshold (tensegrity_env.py:279).  On the GPU: columns 14, 15 of the tendon slab.
+constexpr int LCX = 0, LC_SLAB = 3;
+// xs (F, replicated): small per-environment scalars -- XP15: the bar pair the roving slot of lane 15 serves in this sub-step (-1: none).  On
+// the GPU: rows 3.. of column 14 of the tendon slab.
+constexpr int XP15 = 0, XS_SLAB = 1;
 #ifdef TGR_ROW_EMUL
 constexpr int hidx(int i) { return i; }
 constexpr int lidx(int i) { return i; }
@@ -894,7 +956,7 @@ constexpr int lidx(int i) { return (i % 10) * 16 + i / 10; }
 // dbg: optional sub-step trace of this environment (null in production; tgr_bind_substep_trace): word s = contact slots active in sub-step s
 // (bits 0..15 page 0, 16..21 page 1) | (Newton iterations the environment itself needed so far, mod 256) << 22 | (left at the cap or stalled) << 30 | (stalled) << 31
 constexpr int TRACE_WORDS = 24;
-template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; Slab<F> hd; Slab<F> lp; unsigned* dbg; };
+template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; Slab<F> hd; Slab<F> lp; Slab<K> lc; Slab<F> xs; unsigned* dbg; };
 
 #ifndef TGR_IMPLICIT_K
 #define TGR_IMPLICIT_K 1
@@ -937,11 +999,18 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       st3(M.kd, KEZ + 3 * b, kz);
       st3(M.fd, FEZ + 3 * b, cvt3<F>(kz));
       if (LAST) {
-        const V3<F> lx = cvt3<F>(ld3(M.kd, KX + 3 * b));
-        M.lp.st(lidx(LPX + 3 * b), lx.x); M.lp.st(lidx(LPX + 3 * b + 1), lx.y); M.lp.st(lidx(LPX + 3 * b + 2), lx.z);
         for (int i = 0; i < 4; i++) M.lp.st(lidx(LPQ + 4 * b + i), cvt<F>(q[i]));
       }
     });
+    if (LAST) {  // the lagged bar positions, relative to their centre (K); the centre itself stays in K (lc)
+      const V3<K> x0 = ld3(M.kd, KX), x1 = ld3(M.kd, KX + 3), x2 = ld3(M.kd, KX + 6);
+      const V3<K> com = SK(1.0 / 3.0) * ((x0 + x1) + x2);
+      st3(M.lc, LCX, com);
+      const V3<F> l0 = cvt3<F>(x0 - com), l1 = cvt3<F>(x1 - com), l2 = cvt3<F>(x2 - com);
+      M.lp.st(lidx(LPX), l0.x); M.lp.st(lidx(LPX + 1), l0.y); M.lp.st(lidx(LPX + 2), l0.z);
+      M.lp.st(lidx(LPX + 3), l1.x); M.lp.st(lidx(LPX + 4), l1.y); M.lp.st(lidx(LPX + 5), l1.z);
+      M.lp.st(lidx(LPX + 6), l2.x); M.lp.st(lidx(LPX + 7), l2.y); M.lp.st(lidx(LPX + 8), l2.z);
+    }
     TGR_PHASE(1);
     // ---- tendons (tendon role): geometry, force, Jacobian pieces; smooth wrench per bar (replicated).  Each lane reads the pose of
     // ITS two bars straight from the slab (a lane-dependent LDS address), so no lane ever holds all three bars
@@ -1020,8 +1089,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     }
     TGR_PHASE(2);
     // ---- contacts (slot role)
-    const I jb = sel(Ro.sB >= 0, Ro.sB, I(0)), ja_ = sel(Ro.sA >= 0, Ro.sA, I(0));  // my slot's bars (a missing one reads bar 0 and is masked)
-    const auto hasA = Ro.sA >= 0;
+    I jb = sel(Ro.sB >= 0, Ro.sB, I(0)), ja_ = sel(Ro.sA >= 0, Ro.sA, I(0));  // my slot's bars (a missing one reads bar 0 and is masked)
+    auto hasA = Ro.sA >= 0;
     {
       // caps on the floor: the distance is a small difference of pose quantities -> K
       const V3<K> kzc = ld3(M.kd, KEZ + 3 * jb), kxc = ld3(M.kd, KX + 3 * jb);
@@ -1078,20 +1147,53 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       // (positions relative to bar A's centre, the difference formed in K: a robot that has walked 30 m resolves a 0.5 mm bar-bar
       // penetration as well as one at the origin -- in absolute F coordinates it would carry 2e-6 m of rounding)
       const V3<F> pxA = z3, pzA = ld3(M.fd, FEZ + 3 * ja_), pxB = cvt3<F>(kxc - ld3(M.kd, KX + 3 * ja_)), pzB = cvt3<F>(kzc);
-      RContact<F> p0, p1, p2;
+      RContact<F> p0, p1, p2, p3;
+      F others;  // how many contacts of my pair besides the r-cylinders side to side
       TGR_SCHED();
-      bar_pair_contacts(P, capr, pxA, pzA, pxB, pzB, Ro.is_pair | Ro.is_pair2, p0, p1, p2, dropped, S(2e-5));
+      bar_pair_contacts(P, capr, pxA, pzA, pxB, pzB, Ro.is_pair | Ro.is_pair2, p0, p1, p2, p3, others, S(2e-5));
       TGR_SCHED();
       const auto s0 = Ro.sub == 0;
       const auto s2 = Ro.is_pair2;
-      c.n = sel3(is_floor, fn, sel3(s2, p2.n, sel3(s0, p0.n, p1.n)));
-      c.rA = sel3(is_floor, z3, sel3(s2, p2.rA, sel3(s0, p0.rA, p1.rA)));
-      c.rB = sel3(is_floor, frB, sel3(s2, p2.rB, sel3(s0, p0.rB, p1.rB)));
-      c.c0 = sel(is_floor, cc, sel(s2, p2.c0, sel(s0, p0.c0, p1.c0)));
-      c.Dn = sel(is_floor, dn, sel(s2, p2.Dn, sel(s0, p0.Dn, p1.Dn)));
-      c.active = sel(is_floor, fhit, sel(s2, p2.active, sel(Ro.is_pair, sel(s0, p0.active, p1.active), false)));
-      if (MODEL) dropped = dropped + sel(p2.active, F(S(1)), zero);  // (lanes 12..14 carry the rods there: the second other contact has no slot)
-      dropped = sel(Ro.is_pair & s0, dropped, zero);
+      // The roving slot (lane 15): the next deepest "other" contact -- MODEL 0: the third, MODEL 1 (lanes 12..14 carry the rods): the second --
+      // of the first bar pair that has one.  Lane 6 + 2p holds pair p's candidates.  Rare (a crossing deeper than 6 mm near the b-cylinders:
+      // 1e-4 per env-step under random actions), so everything about it sits behind wavefront-uniform tests.
+      const RContact<F>& pn = MODEL ? p2 : p3;
+      const auto want = Ro.is_pair & s0 & pn.active;
+      I p15 = I(-1);
+      RContact<F> rv;
+      rv.n = mk<F>(zero, zero, F(S(1))); rv.rA = z3; rv.rB = z3; rv.c0 = zero; rv.Dn = zero; rv.active = B(false);
+      if (any_slots<0x0540u>(want)) {
+        const F w_ = sel(want, F(S(1)), zero);
+        const auto w0 = bcast<6>(w_) != S(0), w1 = bcast<8>(w_) != S(0), w2 = bcast<10>(w_) != S(0);
+        p15 = sel(w0, I(0), sel(w1, I(1), sel(w2, I(2), I(-1))));
+        auto pick = [&](F x) { return sel(p15 == 0, bcast<6>(x), sel(p15 == 1, bcast<8>(x), bcast<10>(x))); };
+        rv.n = mk<F>(pick(pn.n.x), pick(pn.n.y), pick(pn.n.z));
+        rv.rA = mk<F>(pick(pn.rA.x), pick(pn.rA.y), pick(pn.rA.z));
+        rv.rB = mk<F>(pick(pn.rB.x), pick(pn.rB.y), pick(pn.rB.z));
+        rv.c0 = pick(pn.c0); rv.Dn = pick(pn.Dn);
+        rv.active = p15 >= 0;
+      }
+      M.xs.st(XP15, from_int(p15, F()));
+      const auto s3 = Ro.r == 15;
+      c.n = sel3(is_floor, fn, sel3(s3, rv.n, sel3(s2, p2.n, sel3(s0, p0.n, p1.n))));
+      c.rA = sel3(is_floor, z3, sel3(s3, rv.rA, sel3(s2, p2.rA, sel3(s0, p0.rA, p1.rA))));
+      c.rB = sel3(is_floor, frB, sel3(s3, rv.rB, sel3(s2, p2.rB, sel3(s0, p0.rB, p1.rB))));
+      c.c0 = sel(is_floor, cc, sel(s3, rv.c0, sel(s2, p2.c0, sel(s0, p0.c0, p1.c0))));
+      c.Dn = sel(is_floor, dn, sel(s3, rv.Dn, sel(s2, p2.Dn, sel(s0, p0.Dn, p1.Dn))));
+      c.active = sel(is_floor, fhit, sel(s3, rv.active, sel(s2, p2.active, sel(Ro.is_pair, sel(s0, p0.active, p1.active), false))));
+      {
+        // what found no slot (counted on the pair's first lane): the pair's others beyond its fixed slots (MODEL 0: two, MODEL 1: one) and
+        // the roving slot, if that serves this pair
+        const auto mine = p15 == ((Ro.r - 6) >> 1);
+        const F slots = sel(mine, F(S(MODEL ? 2 : 3)), F(S(MODEL ? 1 : 2)));
+        dropped = sel(Ro.is_pair & s0 & (others > slots), others - slots, zero);
+      }
+      // my slot's bars, now that lane 15 knows whose contact it carries
+      const auto rove = s3 & (p15 >= 0);
+      jb = sel(rove, sel(p15 == 0, I(1), I(2)), jb); ja_ = sel(rove, sel(p15 == 2, I(1), I(0)), ja_);
+      hasA = hasA | rove;
+      V3<K> kzcL = kzc;
+      if (any_lane(rove)) kzcL = ld3(M.kd, KEZ + 3 * jb);
       {
         // Two bars side to side: whether they touch, and how deep, is decided on the distance of the two axes formed again in K (the F
         // routine above names the candidate): over relative coordinates of 0.3 m an F distance carries 1e-7 m, ten times what the pose
@@ -1120,8 +1222,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       // so there the offset is taken as it was built, -(r + dist / 2) n, not back out of the rounded sum arm + offset: that round trip
       // leaves 1e-7 m in a random direction, times a normal force of 10 N, on an inertia of 0.0038 kg m^2.)
       const V3<K> offB = cvt3<K>(MODEL ? sel3(is_floor, foff, c.rB) : sel3(Ro.is_cap, c.rB - arm, c.rB));
-      st3(M.ad, AMB, cross(kzc, offB)); st3(M.ad, AMA, cross(kzA, cvt3<K>(c.rA)));
-      st3(M.ad, AZB, kzc); st3(M.ad, AZA, kzA);
+      st3(M.ad, AMB, cross(kzcL, offB)); st3(M.ad, AMA, cross(kzA, cvt3<K>(c.rA)));
+      st3(M.ad, AZB, kzcL); st3(M.ad, AZA, kzA);
     }
     // my slot's residual at the unconstrained acceleration
     {
@@ -1144,7 +1246,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   // Start: last sub-step's constraint acceleration (P.warm_start) -- a contact's reference acceleration moves by ~B h a every sub-step,
   // so last sub-step's ACCELERATION is a poor guess, but the part of it the contacts produced is a good one -- or zero.
   {
-    const Roles<F> Ro = lane_roles<F, MODEL>();
+    const Roles<F> Ro = lane_roles<F, MODEL>(to_int(M.xs.ld(XP15)));
     V3<F> dl[3], da[3];
     const F pc = M.hd.ld(hidx(HPC)), ppc = M.hd.ld(hidx(HPPC));
     #ifndef TGR_WX
@@ -1205,7 +1307,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   TGR_FENCE();
   for (int it = 0;; it++) {
     TGR_PHASE(3);
-    const Roles<F> Ro = lane_roles<F, MODEL>();
+    const I p15 = to_int(M.xs.ld(XP15));  // (the roving slot's pair; -1: none)
+    const Roles<F> Ro = lane_roles<F, MODEL>(p15);
     DofC<F> dc;
     dc.dof = Ro.is_dof; dc.ang = Ro.is_ang;
     dc.e = mk<F>(sel(Ro.is_dof & (Ro.k == 0), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 1), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 2), F(S(1)), zero));
@@ -1251,6 +1354,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
                 PtA = mk<F>(pairsum(tA.x), pairsum(tA.y), pairsum(tA.z));
     const K PkB = pairsum(tauB), PkA = pairsum(tauA);
     const bool third = !MODEL && any_slots<0x7000u>(cs.active);
+    const bool rove = any_slot<15>(cs.active);
     K gn = kzero;  // g^T M^-1 g
     F dn = zero;   // d^T M d: the scale of the forces the gradient is the difference of
     F gd[3];
@@ -1262,7 +1366,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       TGR_SCHED();
       V3<F> fcl, fca;
       K tax;
-      bar_sum<MODEL>(b, PfB, PtB, PtA, PkB, PkA, fB, tB, tA, tauB, tauA, third, fcl, fca, tax);
+      bar_sum<MODEL>(b, PfB, PtB, PtA, PkB, PkA, fB, tB, tA, tauB, tauA, third, rove, p15, fcl, fca, tax);
       st3(M.fd, FFCL + 3 * b, fcl); st3(M.fd, FFCA + 3 * b, fca); M.kd.st(KTAX + b, tax);
       // (SHIFT: dl, da are the iterate e; the full d = d_ref + e)
       const V3<F> rl = SHIFT ? ld3(M.fd, FRL + 3 * b) : z3, ra = SHIFT ? ld3(M.fd, FRA + 3 * b) : z3;
@@ -1278,7 +1382,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       ga = ga + (cvt<F>(gax) - gz) * ezb;  // the direction is solved for the same axial residual the test looks at
       gd[b] = sel(Ro.is_dof, sel(Ro.is_ang, pick_comp(Ro.k, ga), pick_comp(Ro.k, gl)), zero);
     });
-    if (LAST) bar_force = rowsum(sel(Ro.is_pair | Ro.is_pair2, sqrt_(dot(o.fl, o.fl)), zero));
+    if (LAST) bar_force = rowsum(sel(Ro.is_pair | Ro.is_pair2 | Ro.is_rove, sqrt_(dot(o.fl, o.fl)), zero));
     // converged: the M^-1-norm of the gradient is below the tolerance -- or below what the arithmetic resolves of it: the gradient is the
     // difference of inertial and contact forces of size sqrt(d^T M d) (a hard contact onset: 1e3 sqrt(kg) m/s^2), each known to a few ulp
     conv = conv | !(gn >= PK.tol * PK.tol + (PK.rtol * PK.rtol) * cvt<K>(dn));
@@ -1302,9 +1406,11 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     for (int i = 0; i < 6; i++) { H.O10[i] = zero; H.O20[i] = zero; H.O21[i] = zero; }
     static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<MODEL, 0, decltype(cc)::value>(H, dc, cs, o); });
     if (page1) static_for<6>([&](auto cc) { hess_add_slot<MODEL, 1, decltype(cc)::value>(H, dc, cs1, o1); });
+    if (rove) hess_add_roving(H, dc, cs, o, p15);
     // which bar pairs does any environment of the wavefront couple?  (uniform: lets the factorisation skip zero blocks)
-    const bool cp0 = any_slots<MODEL ? 0x00c0u : 0x10c0u>(cs.active), cp1 = any_slots<MODEL ? 0x0300u : 0x2300u>(cs.active),
-               cp2 = any_slots<MODEL ? 0x0c00u : 0x4c00u>(cs.active);
+    bool cp0 = any_slots<MODEL ? 0x00c0u : 0x10c0u>(cs.active), cp1 = any_slots<MODEL ? 0x0300u : 0x2300u>(cs.active),
+         cp2 = any_slots<MODEL ? 0x0c00u : 0x4c00u>(cs.active);
+    if (rove) { cp0 = cp0 || any_lane(Ro.is_rove & cs.active & (p15 == 0)); cp1 = cp1 || any_lane(Ro.is_rove & cs.active & (p15 == 1)); cp2 = cp2 || any_lane(Ro.is_rove & cs.active & (p15 == 2)); }
     TGR_PHASE(6);
     // ---- direction p = -H^-1 g
     F pr[3][6], gHg;

@@ -34,6 +34,11 @@ enum : int {
 };
 enum : int { I_STEPNUM = 0, I_ELAPSED, I_RINGLEN, I_RINGHEAD, I_EPISODE, I_PHASE, I_SRC, I_SRCEP, I_HALF, NI };  // I_HALF: row kernels, paced donor rows
 constexpr int RING = 32;
+// rows of the fp64 side array hp[HP_ROWS][m] (fp32 handles on the row kernels): qpos, and what the env layer keeps of ABSOLUTE positions --
+// the lagged centre (xy_position_before), tr_env's way-point and origin.  In fp32 a robot 30 m from the origin would resolve them to 2e-6 m:
+// 1e-4 m/s of x / y velocity, the size of the is_healthy threshold (tensegrity_env.py:279).  st keeps rounded copies.
+enum : int { HP_QPOS = 0, HP_XYLAG = 21, HP_WAYPT = 23, HP_ORI = 25, HP_ROWS = 27 };
+static_assert(HP_WAYPT == HP_XYLAG + 2 && HP_ORI == HP_XYLAG + 4 && HP_ROWS == HP_XYLAG + 6, "set_state's hp rows");
 static_assert(RING == TGR_RING_CAPACITY && TGR_AUX_K == TGR_AUX_RING + RING + 1, "aux layout of tgr_get_state / tgr_set_state");
 constexpr double PI = 3.14159265358979323846;
 
@@ -58,8 +63,9 @@ template <typename T> struct KArgs {
   int n, m;  // live envs, total lanes (live + donors)
   int slow_e;  // row kernels: donor rows from this index on (a multiple of 4) settle in half quanta -- see step_kernel_row; >= m: none
   T* st; int* ist; T* ring;
-  double* hp;  // fp32 handles stepped by the row kernels: qpos in fp64, [21][m] (the pose is fp64 inside the kernels; rounding it to fp32 between
-               // env-steps alone moved a cap across dist = 0 in 0.1..0.4 % of env-steps).  null: the pose lives in st only
+  double* hp;  // fp32 handles stepped by the row kernels: qpos (and the env layer's absolute positions) in fp64, [HP_ROWS][m] (the pose is fp64
+               // inside the kernels; rounding it to fp32 between env-steps alone moved a cap across dist = 0 in 0.1..0.4 % of env-steps).
+               // null: the pose lives in st only
   const float* actions;
   T* obs; T* reward; uint8_t* terminated; uint8_t* truncated; T* terminal_obs; T* info;
   int* list_count; int* list; int* rlist;  // envs to (re)settle / ready donors
@@ -86,6 +92,15 @@ template <typename T> struct KArgs {
   T* obs_clean;  // info["real_observation"] of tr_env.py:507: the noise-free observation of the step ([N][D]) or null
   unsigned* dbg;  // row kernels: sub-step trace of the live envs ([N][row::TRACE_WORDS], tgr_bind_substep_trace) or null
 };
+
+// an absolute position of the env layer: from the fp64 side array where the handle has one, else from st; stores keep both up to date
+template <typename T> TGR_DEV double aux_ld(const KArgs<T>& k, int hp_row, int st_field, int e) {
+  return k.hp ? k.hp[(size_t)hp_row * k.m + e] : (double)k.st[(size_t)st_field * k.m + e];
+}
+template <typename T> TGR_DEV void aux_st(const KArgs<T>& k, int hp_row, int st_field, int e, double v) {
+  if (k.hp) k.hp[(size_t)hp_row * k.m + e] = v;
+  k.st[(size_t)st_field * k.m + e] = T(v);
+}
 
 __constant__ double c_qpos0[21] = {0.08369179, -0.28792231, 0.24830847, -0.49145555, 0.7539914, -0.27511722, -0.33805166,
                                    0.14497616, -0.19291743, 0.35052097, -0.84766041, 0.27950622, 0.45085889, 0.00862359,
@@ -248,7 +263,8 @@ TGR_DEV void make_obs(const Params<T>& P, const EnvCfg<T>& E, const Sim<T>& S, c
 #pragma unroll
   for (int t = 0; t < 9; t++) o[k++] = lag.tenL[t];
   if (E.action == TGR_ACT_TRACKING || E.action == TGR_ACT_AIMING) {  // tr_env.py:626-639
-    T tx = ms.waypt[0] - c.x, ty = ms.waypt[1] - c.y;
+    // (c is relative to the lagged centre: the way-point is taken relative to it in double first)
+    T tx = T((ms.waypt[0] - lag.com[0]) - (double)c.x), ty = T((ms.waypt[1] - lag.com[1]) - (double)c.y);
     T in = rsqrt_(tx * tx + ty * ty);
     o[k++] = tx; o[k++] = ty; o[k++] = atan2_(ty * in, tx * in);
   } else if (E.action == TGR_ACT_VEL_TRACK) {
@@ -308,10 +324,10 @@ TGR_DEV void apply_obs_noise(const EnvCfg<T>& E, unsigned long long key, unsigne
   }
 }
 
-template <typename T> struct StepOut { T reward; bool terminated; T info[10]; T psi_straight; T xy[2]; };
+template <typename T> struct StepOut { T reward; bool terminated; T info[10]; T psi_straight; double xy[2]; };
 
 // per-env members of tr_env's command modes (tr_env.py:229-240): way-point, origin, velocity command
-template <typename T> struct ModeState { T waypt[2], ori[2], vcmd[3]; T psi_before; int step_num; };
+template <typename T> struct ModeState { double waypt[2], ori[2]; T vcmd[3]; T psi_before; int step_num; };  // (absolute positions: double)
 template <typename T> TGR_DEV T exp_(T x) { return sizeof(T) == 4 ? T(expf(float(x))) : T(exp(double(x))); }
 template <typename T> TGR_DEV T sin_(T x) { return sizeof(T) == 4 ? T(sinf(float(x))) : T(sin(double(x))); }
 template <typename T> TGR_DEV T angle_normalize(T th) {  // tr_env.py:648-654 -> (-pi, pi]
@@ -319,17 +335,20 @@ template <typename T> TGR_DEV T angle_normalize(T th) {  // tr_env.py:648-654 ->
   while (th <= T(-PI)) th += T(2 * PI);
   return th;
 }
-template <typename T> TGR_DEV T ditch_reward(const EnvCfg<T>& E, const ModeState<T>& ms, T x, T y) {  // tr_env.py:656-667
-  T pvx = ms.waypt[0] - ms.ori[0], pvy = ms.waypt[1] - ms.ori[1];
-  T dp = sqrt_(pvx * pvx + pvy * pvy);
-  T idp = rcp_(dp);
-  T pnx = pvx * idp, pny = pvy * idp;
-  T tvx = ms.waypt[0] - x, tvy = ms.waypt[1] - y;
-  T along = tvx * pnx + tvy * pny;
-  T bx = tvx - along * pnx, by = tvy - along * pny;
-  T bias2 = bx * bx + by * by;
-  T ditch = E.ditch_max * (T(1) - abs_(along) * idp) * exp_(-bias2 * rcp_(T(2) * E.ditch_std * E.ditch_std));
-  T way = E.waypt_amp * exp_(-(tvx * tvx + tvy * tvy) * rcp_(T(2) * E.waypt_std * E.waypt_std));
+// (in double whatever the handle's precision: the tracking reward is the DIFFERENCE of two of these, each up to ditch_max + waypt_amp = 400,
+// a control period apart -- evaluated in fp32 the difference would carry 5e-5 of rounding)
+template <typename T> TGR_DEV double ditch_reward(const EnvCfg<T>& E, const ModeState<T>& ms, double x, double y) {  // tr_env.py:656-667
+  const double pvx = ms.waypt[0] - ms.ori[0], pvy = ms.waypt[1] - ms.ori[1];
+  const double dp = sqrt(pvx * pvx + pvy * pvy);
+  const double idp = 1.0 / dp;
+  const double pnx = pvx * idp, pny = pvy * idp;
+  const double tvx = ms.waypt[0] - x, tvy = ms.waypt[1] - y;
+  const double along = tvx * pnx + tvy * pny;
+  const double bx = tvx - along * pnx, by = tvy - along * pny;
+  const double bias2 = bx * bx + by * by;
+  const double dstd = (double)E.ditch_std, wstd = (double)E.waypt_std;
+  const double ditch = (double)E.ditch_max * (1.0 - fabs(along) * idp) * exp(-bias2 / (2.0 * dstd * dstd));
+  const double way = (double)E.waypt_amp * exp(-(tvx * tvx + tvy * tvy) / (2.0 * wstd * wstd));
   return ditch + way;
 }
 
@@ -341,12 +360,14 @@ template <typename T> TGR_DEV T ring_pop(RingRef<T>& r) { T v = r.ring[r.head * 
 // reward / termination of one env step (tensegrity_env.py:291-410, tr_env.py:327-527; straight and turn)
 template <typename T>
 TGR_DEV StepOut<T> env_epilogue(const Params<T>& P, const EnvCfg<T>& E, const Sim<T>& S, const Lag<T>& lag, const V3<T>* wb,
-                                const T* action, T xy_bx, T xy_by, T reset_psi, RingRef<T>& ring, const ModeState<T>& ms) {
+                                const T* action, double xy_bx, double xy_by, T reset_psi, RingRef<T>& ring, const ModeState<T>& ms) {
   StepOut<T> o;
-  T third = T(1.0 / 3.0);
-  T xa = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x), ya = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
+  // xy_position_after / _before (tensegrity_env.py:293-294,311-315): the centre of the three bars, in double; its change per control period
+  // is formed in double and only then rounded
+  const double xa = lag.com[0], ya = lag.com[1];
   T idt = rcp_(E.dt);
-  T xv = (xa - xy_bx) * idt, yv = (ya - xy_by) * idt;
+  const T dxy[2] = {T(xa - xy_bx), T(ya - xy_by)};
+  T xv = dxy[0] * idt, yv = dxy[1] * idt;
   V3<T> cap[6], l, r;
   caps_of(P, lag, cap);
   left_right(cap, l, r);
@@ -393,13 +414,13 @@ TGR_DEV StepOut<T> env_epilogue(const Params<T>& P, const EnvCfg<T>& E, const Si
       ctrl_cost = cc;
     }
   } else if (E.action == TGR_ACT_STRAIGHT) {
-    T dx = xa - xy_bx, dy = ya - xy_by;
+    T dx = dxy[0], dy = dxy[1];
     T pm = atan2_(dy, dx);
     T pd = abs_(pm - reset_psi);
     fwd = E.direction * (sqrt_(dx * dx + dy * dy) * cos_(pd) * idt);
     ctrl_cost = cc;
   } else if (E.action == TGR_ACT_AIMING) {  // tr_env.py:425-446
-    T tdx = ms.waypt[0] - xy_bx, tdy = ms.waypt[1] - xy_by;
+    T tdx = T(ms.waypt[0] - xy_bx), tdy = T(ms.waypt[1] - xy_by);
     T in = rsqrt_(tdx * tdx + tdy * tdy);
     T target_psi = atan2_(tdy * in, tdx * in);
     T np_ = angle_normalize(target_psi - psi);
@@ -411,7 +432,7 @@ TGR_DEV StepOut<T> env_epilogue(const Params<T>& P, const EnvCfg<T>& E, const Si
     }
     ctrl_cost = cc;
   } else if (E.action == TGR_ACT_TRACKING) {  // tr_env.py:448-460
-    fwd = ditch_reward(E, ms, xa, ya) - ditch_reward(E, ms, xy_bx, xy_by);
+    fwd = T(ditch_reward(E, ms, xa, ya) - ditch_reward(E, ms, xy_bx, xy_by));
     ctrl_cost = cc;
   } else {  // vel_track, tr_env.py:462-474
     T ang = angle_normalize(psi - ms.psi_before) * idt;
@@ -434,10 +455,10 @@ TGR_DEV StepOut<T> env_epilogue(const Params<T>& P, const EnvCfg<T>& E, const Si
     o.info[TGR_INFO_REWARD_CTRL] = -contact_cost;
   }
   o.info[TGR_INFO_REWARD_SURVIVE] = hr;
-  o.info[TGR_INFO_X_POSITION] = xa;
-  o.info[TGR_INFO_Y_POSITION] = ya;
+  o.info[TGR_INFO_X_POSITION] = T(xa);
+  o.info[TGR_INFO_Y_POSITION] = T(ya);
   o.info[TGR_INFO_PSI] = psi;
-  o.info[TGR_INFO_DISTANCE] = sqrt_(xa * xa + ya * ya);
+  o.info[TGR_INFO_DISTANCE] = T(sqrt(xa * xa + ya * ya));
   o.info[TGR_INFO_X_VELOCITY] = xv;
   o.info[TGR_INFO_Y_VELOCITY] = yv;
   o.info[TGR_INFO_FORWARD_REWARD] = fwd;
@@ -527,7 +548,7 @@ template <typename T> TGR_DEV int settle_total(const EnvCfg<T>& E) {
 // bookkeeping after settle period `st` (0-based) of reset_model() (tensegrity_env.py:495-510, tr_env.py:811-866)
 template <typename T>
 TGR_DEV void settle_period_done(const Params<T>& P, const EnvCfg<T>& E, const Lag<T>& lag, int st, RingRef<T>& ring, int& step_num,
-                                T& reset_psi, ModeState<T>& ms, T* xy_prev, unsigned long long key, unsigned long long episode) {
+                                T& reset_psi, ModeState<T>& ms, double* xy_prev, unsigned long long key, unsigned long long episode) {
   V3<T> cap[6], l, r;
   caps_of(P, lag, cap);
   left_right(cap, l, r);
@@ -540,16 +561,17 @@ TGR_DEV void settle_period_done(const Params<T>& P, const EnvCfg<T>& E, const La
       double len = E.waypt_range[0] + dr.u_way[0] * (E.waypt_range[1] - E.waypt_range[0]);
       double yaw;
       if (E.action == TGR_ACT_TRACKING) {  // tr_env.py:827-839
-        ms.ori[0] = (l.x + r.x) * T(0.5); ms.ori[1] = (l.y + r.y) * T(0.5);
+        // (l, r are relative to the lagged centre)
+        ms.ori[0] = lag.com[0] + (double)((l.x + r.x) * T(0.5)); ms.ori[1] = lag.com[1] + (double)((l.y + r.y) * T(0.5));
         yaw = E.waypt_angle_range[0] + dr.u_way[1] * (E.waypt_angle_range[1] - E.waypt_angle_range[0]) + (double)reset_psi;
         if (E.is_test) { len = 0.5 * E.waypt_range[1] + 0.5 * E.waypt_range[0]; yaw = 0.5 * E.waypt_angle_range[1] + 0.5 * E.waypt_angle_range[0] + (double)reset_psi; }
       } else {  // aiming, tr_env.py:842-855 (the reference's oripoint[0] = lx + rx/2 is kept)
-        ms.ori[0] = l.x + r.x * T(0.5); ms.ori[1] = (l.y + r.y) * T(0.5);
+        ms.ori[0] = 1.5 * lag.com[0] + (double)(l.x + r.x * T(0.5)); ms.ori[1] = lag.com[1] + (double)((l.y + r.y) * T(0.5));
         yaw = -PI + dr.u_way[1] * 2 * PI + (double)reset_psi;
         if (E.is_test) { len = 0.5 * E.waypt_range[1] + 0.5 * E.waypt_range[0]; yaw = 0.75 * PI + 0.25 * (-PI) + (double)reset_psi; }
       }
-      ms.waypt[0] = T((double)ms.ori[0] + len * cos(yaw)); ms.waypt[1] = T((double)ms.ori[1] + len * sin(yaw));
-      if (E.action == TGR_ACT_AIMING && E.is_test) { ms.waypt[0] = T(0); ms.waypt[1] = T(0); }
+      ms.waypt[0] = ms.ori[0] + len * cos(yaw); ms.waypt[1] = ms.ori[1] + len * sin(yaw);
+      if (E.action == TGR_ACT_AIMING && E.is_test) { ms.waypt[0] = 0.0; ms.waypt[1] = 0.0; }
     } else if (tr && E.action == TGR_ACT_VEL_TRACK) {
       ms.vcmd[0] = T(0.5) * cos_(reset_psi); ms.vcmd[1] = T(0.5) * sin_(reset_psi); ms.vcmd[2] = T(0);
     }
@@ -561,7 +583,7 @@ TGR_DEV void settle_period_done(const Params<T>& P, const EnvCfg<T>& E, const La
     if (!tr) v = atan2_(r.y - l.y, r.x - l.x);
     else if (E.action == TGR_ACT_TURN) v = psi_s;
     else {
-      T tdx = ms.waypt[0] - xy_prev[0], tdy = ms.waypt[1] - xy_prev[1];
+      T tdx = T(ms.waypt[0] - xy_prev[0]), tdy = T(ms.waypt[1] - xy_prev[1]);
       T in = rsqrt_(tdx * tdx + tdy * tdy);
       v = angle_normalize(atan2_(tdy * in, tdx * in) - psi_s);
     }
@@ -569,33 +591,34 @@ TGR_DEV void settle_period_done(const Params<T>& P, const EnvCfg<T>& E, const La
     if (ring.len > E.reward_delay_steps) (void)ring_pop(ring);
   }
   if (st >= 50) step_num += 1;
-  T third = T(1.0 / 3.0);
-  xy_prev[0] = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x);
-  xy_prev[1] = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
+  xy_prev[0] = lag.com[0];
+  xy_prev[1] = lag.com[1];
 }
 
 // what reset_model() leaves behind besides qpos/qvel
 template <typename T>
-TGR_DEV void store_modes(T* st, int m, int e, const ModeState<T>& ms) {
-  st[(F_WAYPT + 0) * m + e] = ms.waypt[0]; st[(F_WAYPT + 1) * m + e] = ms.waypt[1];
-  st[(F_ORI + 0) * m + e] = ms.ori[0]; st[(F_ORI + 1) * m + e] = ms.ori[1];
+TGR_DEV void store_modes(const KArgs<T>& k, int e, const ModeState<T>& ms) {
+  T* const st = k.st; const int m = k.m;
+  aux_st(k, HP_WAYPT, F_WAYPT, e, ms.waypt[0]); aux_st(k, HP_WAYPT + 1, F_WAYPT + 1, e, ms.waypt[1]);
+  aux_st(k, HP_ORI, F_ORI, e, ms.ori[0]); aux_st(k, HP_ORI + 1, F_ORI + 1, e, ms.ori[1]);
   st[(F_VCMD + 0) * m + e] = ms.vcmd[0]; st[(F_VCMD + 1) * m + e] = ms.vcmd[1]; st[(F_VCMD + 2) * m + e] = ms.vcmd[2];
 }
-template <typename T> TGR_DEV ModeState<T> load_modes(const T* st, const int* ist, int m, int e) {
+template <typename T> TGR_DEV ModeState<T> load_modes(const KArgs<T>& k, int e) {
+  const T* const st = k.st; const int* const ist = k.ist; const int m = k.m;
   ModeState<T> ms;
-  ms.waypt[0] = st[(F_WAYPT + 0) * m + e]; ms.waypt[1] = st[(F_WAYPT + 1) * m + e];
-  ms.ori[0] = st[(F_ORI + 0) * m + e]; ms.ori[1] = st[(F_ORI + 1) * m + e];
+  ms.waypt[0] = aux_ld(k, HP_WAYPT, F_WAYPT, e); ms.waypt[1] = aux_ld(k, HP_WAYPT + 1, F_WAYPT + 1, e);
+  ms.ori[0] = aux_ld(k, HP_ORI, F_ORI, e); ms.ori[1] = aux_ld(k, HP_ORI + 1, F_ORI + 1, e);
   ms.vcmd[0] = st[(F_VCMD + 0) * m + e]; ms.vcmd[1] = st[(F_VCMD + 1) * m + e]; ms.vcmd[2] = st[(F_VCMD + 2) * m + e];
   ms.psi_before = st[F_PSILAG * m + e];
   ms.step_num = ist[I_STEPNUM * m + e];
   return ms;
 }
 template <typename T>
-TGR_DEV void store_reset_aux(const Params<T>& P, T* st, int* ist, int m, int e, const Lag<T>& lag, T reset_psi, int step_num,
-                             const RingRef<T>& ring) {
-  T third = T(1.0 / 3.0);
-  st[(F_XYLAG + 0) * m + e] = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x);
-  st[(F_XYLAG + 1) * m + e] = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
+TGR_DEV void store_reset_aux(const KArgs<T>& k, int e, const Lag<T>& lag, T reset_psi, int step_num, const RingRef<T>& ring) {
+  const Params<T>& P = k.P;
+  T* const st = k.st; int* const ist = k.ist; const int m = k.m;
+  aux_st(k, HP_XYLAG, F_XYLAG, e, lag.com[0]);
+  aux_st(k, HP_XYLAG + 1, F_XYLAG + 1, e, lag.com[1]);
   V3<T> cap[6], l, r;
   caps_of(P, lag, cap);
   left_right(cap, l, r);
@@ -626,13 +649,13 @@ TGR_DEV void finish_lane(const KArgs<T>& k, Sim<T>& S, const Lag<T>& lag, int e,
 #pragma unroll
     for (int i = 0; i < 6; i++) action[i] = S.ctrl[i];  // settling: constant tendon targets
   }
-  T xy_bx = k.st[(F_XYLAG + 0) * m + e], xy_by = k.st[(F_XYLAG + 1) * m + e];
+  const double xy_bx = aux_ld(k, HP_XYLAG, F_XYLAG, e), xy_by = aux_ld(k, HP_XYLAG + 1, F_XYLAG + 1, e);
   T reset_psi = k.st[F_RESETPSI * m + e];
   T ep_ret = k.st[F_EPRET * m + e];
   int step_num = k.ist[I_STEPNUM * m + e], elapsed = k.ist[I_ELAPSED * m + e];
   RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
   ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
-  ModeState<T> ms = load_modes(k.st, k.ist, m, e);
+  ModeState<T> ms = load_modes(k, e);
   V3<T> wb[3];
   if (active && w0) store_sim(k.st, m, e, S, lag, wb);
   else if (active) {
@@ -647,11 +670,11 @@ TGR_DEV void finish_lane(const KArgs<T>& k, Sim<T>& S, const Lag<T>& lag, int e,
     if (active && w0) {
       const int stp = total - phase;  // 0-based index of the period just run
       if (stp == 0) { step_num = 0; }
-      T xy_prev[2] = {xy_bx, xy_by};
+      double xy_prev[2] = {xy_bx, xy_by};
       settle_period_done(P, E, lag, stp, ring, step_num, reset_psi, ms, xy_prev, lane_key(E, n, e),
                          (unsigned long long)(unsigned)k.ist[I_SRCEP * m + e]);
-      k.st[(F_XYLAG + 0) * m + e] = xy_prev[0]; k.st[(F_XYLAG + 1) * m + e] = xy_prev[1];
-      store_modes(k.st, m, e, ms);
+      aux_st(k, HP_XYLAG, F_XYLAG, e, xy_prev[0]); aux_st(k, HP_XYLAG + 1, F_XYLAG + 1, e, xy_prev[1]);
+      store_modes(k, e, ms);
       ms.step_num = step_num;
       phase -= 1;
       k.st[F_RESETPSI * m + e] = reset_psi;
@@ -660,7 +683,7 @@ TGR_DEV void finish_lane(const KArgs<T>& k, Sim<T>& S, const Lag<T>& lag, int e,
       k.ist[I_PHASE * m + e] = phase;
       if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
       if (phase == PH_READY) {
-        store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
+        store_reset_aux(k, e, lag, reset_psi, step_num, ring);
         make_obs(P, E, S, lag, wb, ms, orow);
         if (E.use_obs_noise) apply_obs_noise<T, ZEXT>(E, lane_key(E, n, e), (unsigned)k.ist[I_SRCEP * m + e], 0, orow, zext);
         T* op = k.dobs + (size_t)(e - n) * D;
@@ -685,7 +708,7 @@ TGR_DEV void finish_lane(const KArgs<T>& k, Sim<T>& S, const Lag<T>& lag, int e,
         for (int i = 0; i < D; i++) cp[i] = orow[i];
       }
       if (E.use_obs_noise) apply_obs_noise<T, ZEXT>(E, lane_key(E, n, k.ist[I_SRC * m + e]), (unsigned)k.ist[I_SRCEP * m + e], elapsed, orow, zext);
-      k.st[(F_XYLAG + 0) * m + e] = out.xy[0]; k.st[(F_XYLAG + 1) * m + e] = out.xy[1];
+      aux_st(k, HP_XYLAG, F_XYLAG, e, out.xy[0]); aux_st(k, HP_XYLAG + 1, F_XYLAG + 1, e, out.xy[1]);
       k.st[F_PSILAG * m + e] = out.psi_straight;
       k.st[F_EPRET * m + e] = ep_ret;
       k.ist[I_STEPNUM * m + e] = step_num; k.ist[I_ELAPSED * m + e] = elapsed;
@@ -698,8 +721,8 @@ TGR_DEV void finish_lane(const KArgs<T>& k, Sim<T>& S, const Lag<T>& lag, int e,
         T* ip = k.info + (size_t)e * TGR_INFO_K;
 #pragma unroll
         for (int i = 0; i < 10; i++) ip[i] = out.info[i];
-        ip[TGR_INFO_WAYPT_X] = ms.waypt[0]; ip[TGR_INFO_WAYPT_Y] = ms.waypt[1];
-        ip[TGR_INFO_ORI_X] = ms.ori[0]; ip[TGR_INFO_ORI_Y] = ms.ori[1];
+        ip[TGR_INFO_WAYPT_X] = T(ms.waypt[0]); ip[TGR_INFO_WAYPT_Y] = T(ms.waypt[1]);
+        ip[TGR_INFO_ORI_X] = T(ms.ori[0]); ip[TGR_INFO_ORI_Y] = T(ms.ori[1]);
         ip[TGR_INFO_EP_RETURN] = ep_ret; ip[TGR_INFO_EP_LENGTH] = T(elapsed);
 #pragma unroll
         for (int i = 0; i < 9; i++) ip[TGR_INFO_TENDON_LENGTH + i] = lag.tenL[i];
@@ -842,6 +865,10 @@ template <typename T, typename TK, int MODEL> TGR_DEV row::RMem<TK, T> row_mem(R
   M.td = row::Slab<T>{sh.td + slot * row::T_SLAB * 16, 16, r};
   M.hd = row::Slab<T>{sh.td + slot * row::T_SLAB * 16 + 9, 1, 0};   // columns 9, 10 of the tendon slab (tgr_row.h hidx)
   M.lp = row::Slab<T>{sh.td + slot * row::T_SLAB * 16 + 11, 1, 0};  // columns 11..13 (lidx)
+  // columns 14, 15: rows 0..2 the lagged centre (K: one double spans the two columns of an fp32 handle's row); row 9 the donor-stream word
+  M.lc = row::Slab<TK>{reinterpret_cast<TK*>(sh.td + slot * row::T_SLAB * 16 + 14), (int)(16 * sizeof(T) / sizeof(TK)), 0};
+  M.xs = row::Slab<T>{sh.td + slot * row::T_SLAB * 16 + 14 + 16 * row::LC_SLAB, 16, 0};  // rows 3.. of column 14: small replicated scalars
+  static_assert(row::LC_SLAB + row::XS_SLAB <= 9, "row 9 of column 14 is the donor-stream word");
   M.rd = row::Slab<TK>{sh.rd, 16, r};
   M.ad = row::Slab<TK>{sh.ad + slot * row::A_SLAB * PAGES * 16, 16, r};
   M.cd = row::Slab<T>{sh.cd + slot * row::C_SLAB * PAGES * 16, 16, r};
@@ -913,6 +940,7 @@ TGR_DEV void row_export(const row::RMem<TK, T>& M, const row::RLag<TK, T>& rl, S
   S.capd = M.fd.ld(row::FCAPD);
 #pragma unroll
   for (int i = 0; i < 9; i++) lag.tenL[i] = M.lp.ld(row::lidx(row::LPT + i));
+  lag.com[0] = (double)M.lc.ld(row::LCX); lag.com[1] = (double)M.lc.ld(row::LCX + 1);  // (lp's positions are relative to it)
   lag.cfrc_absmax = rl.cfrc_absmax; lag.cfrc_clip_sq = rl.cfrc_clip_sq; lag.bar_contact = rl.bar_contact;
   lag.overflow = (int)rl.overflow; lag.n_it = rl.n_it; lag.n_ls = rl.n_ls; lag.n_unconv = (int)rl.n_unconv;
 }
@@ -960,11 +988,16 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   const bool live = valid && e < n;  // (rows past the end do nothing at all)
   int phase = k.ist[I_PHASE * m + e];
   unsigned long long cmd = 0ull;
+  int cmd_tag0 = 0;
   if (k.async && valid && e >= n) {  // donor stream: a command of an earlier step's match kernel that this lane has not carried out yet
     cmd = k.dcmd[e];
     const int tag = (int)(unsigned)(cmd & 0xffffffffull);
-    if (tag != 0 && tag != k.dapplied[e] && tag < k.launch_idx) phase = PH_INIT;
+    if (tag != 0 && tag != k.dapplied[e] && tag < k.launch_idx) { phase = PH_INIT; cmd_tag0 = tag; }
   }
+  // dcmd is read ONCE per launch: this step's match kernel runs concurrently and may overwrite the word (a starved class re-arms the holder of
+  // an episode: match_kernel_stream) -- a second read after the sub-steps could see a different command than the one carried out above.
+  // The decision is parked in the row's LDS (row 9 of column 14 of the tendon slab: lanes >= 9 own no tendon) and read back below.
+  *reinterpret_cast<int*>(sh.td + slot * (row::T_SLAB * 16) + 9 * 16 + 14) = cmd_tag0;
   const bool donor_run = valid && e >= n && (phase > 0 || phase == PH_INIT);
   const bool active = live || donor_run;
   const int total = settle_total(E);
@@ -1019,11 +1052,8 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
     const EnvCfg<T>& E = k.E;
     const bool live = valid && e < n;
     int phase = k.ist[I_PHASE * m + e];  // (only written below)
-    int cmd_tag = 0;
-    if (k.async && valid && e >= n) {
-      const int tag = (int)(unsigned)(k.dcmd[e] & 0xffffffffull);
-      if (tag != 0 && tag != k.dapplied[e] && tag < k.launch_idx) { phase = PH_INIT; cmd_tag = tag; }
-    }
+    const int cmd_tag = *reinterpret_cast<const int*>(sh.td + slot * (row::T_SLAB * 16) + 9 * 16 + 14);  // (the command carried out at the top, or 0)
+    if (cmd_tag) phase = PH_INIT;
     const bool donor_run = valid && e >= n && (phase > 0 || phase == PH_INIT);
     const bool active = live || donor_run;
     const int total = settle_total(E);
@@ -1118,8 +1148,8 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   row_lag_init<T, TK>(rl);
   Lag<T> lag;
   T reset_psi = T(0);
-  ModeState<T> ms = load_modes(k.st, k.ist, m, e);
-  T xy_prev[2] = {T(0), T(0)};
+  ModeState<T> ms = load_modes(k, e);
+  double xy_prev[2] = {0.0, 0.0};
   const bool w0 = valid && r == 0;
 #pragma unroll 1
   for (int st = 0; st < total; st++) {
@@ -1134,8 +1164,8 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   V3<T> wb[3];
   store_sim(k.st, m, e, S, lag, wb);
   if (k.hp) row_store_pose<T, TK>(M, k.hp, m, e);
-  store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
-  store_modes(k.st, m, e, ms);
+  store_reset_aux(k, e, lag, reset_psi, step_num, ring);
+  store_modes(k, e, ms);
   ms.step_num = step_num;
   k.ist[I_SRC * m + e] = klane;
   k.ist[I_SRCEP * m + e] = episode;
@@ -1185,8 +1215,8 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
 #pragma unroll
   for (int i = 0; i < 9; i++) lag.tenL[i] = T(0);  // wave 3 never evaluates tendons
   T reset_psi = T(0);
-  ModeState<T> ms = load_modes(k.st, k.ist, m, e);
-  T xy_prev[2] = {T(0), T(0)};
+  ModeState<T> ms = load_modes(k, e);
+  double xy_prev[2] = {0.0, 0.0};
   warm_to_lds<T, LW>(S, lds, wid);
 #pragma unroll 1
   for (int st = 0; st < total; st++) {
@@ -1199,8 +1229,8 @@ template <typename T, int LW, int MODEL> __global__ __launch_bounds__(256) void 
   V3<T> wb[3];
   warm_from_lds<T, LW>(S, lds);
   store_sim(k.st, m, e, S, lag, wb);
-  store_reset_aux(P, k.st, k.ist, m, e, lag, reset_psi, step_num, ring);
-  store_modes(k.st, m, e, ms);
+  store_reset_aux(k, e, lag, reset_psi, step_num, ring);
+  store_modes(k, e, ms);
   ms.step_num = step_num;
   k.ist[I_SRC * m + e] = e;
   k.ist[I_SRCEP * m + e] = episode;
@@ -1251,7 +1281,9 @@ template <typename T> __global__ __launch_bounds__(1024) void match_kernel(KArgs
   auto donor_ready = [&](int lane) {
     if (!k.async) return k.ist[I_PHASE * m + lane] == PH_READY;
     const int rd = k.dready[lane];
-    return rd != 0 && rd < k.launch_idx && rd != k.consumed[lane];
+    // (rd > tag of the lane's last command: an episode commanded at step t cannot be ready before donor launch t + 1 -- a dready at or
+    // below it belongs to the episode the command replaced, whatever the donor side has or has not cleared yet)
+    return rd != 0 && rd < k.launch_idx && rd != k.consumed[lane] && rd > (int)(unsigned)(k.dcmd[lane] & 0xffffffffull);
   };
   compact(n, [&](int i) { return k.doneflag[i] != 0; }, k.list, &nd_s);
   compact(nd_lanes, [&](int i) { return donor_ready(n + i); }, k.rlist, &nr_s);
@@ -1259,7 +1291,7 @@ template <typename T> __global__ __launch_bounds__(1024) void match_kernel(KArgs
   const int pairs = min(nd, nr);
   const int D = k.E.obs_dim;
   // copy donor -> slot : state fields, int fields, heading ring, reset observation
-  const int NH = k.hp ? 21 : 0;
+  const int NH = k.hp ? HP_ROWS : 0;
   const int per = NF + RING + NH + D;
   for (int w = tid; w < pairs * per; w += NT) {
     int p = w / per, f = w - p * per;
@@ -1334,7 +1366,10 @@ template <typename T> __global__ __launch_bounds__(256) void match_kernel_stream
   __syncthreads();
   for (int j = tid; j < Dc; j += NT) {
     bool ready;
-    if (k.async) { const int rd = k.dready[d0 + j]; ready = rd != 0 && rd < k.launch_idx && rd != k.consumed[d0 + j]; }
+    // (rd > tag of the lane's last command: an episode commanded at step t cannot be ready before donor launch t + 1.  A dready at or below
+    // it is the REPLACED episode's -- the starved path below re-arms a holder without touching consumed[], and the donor side clears dready
+    // only at the end of the launch that carries the command out, while I_SRCEP already names the new episode)
+    if (k.async) { const int rd = k.dready[d0 + j]; ready = rd != 0 && rd < k.launch_idx && rd != k.consumed[d0 + j] && rd > (int)(unsigned)(k.dcmd[d0 + j] & 0xffffffffull); }
     else ready = k.ist[I_PHASE * m + d0 + j] == PH_READY;
     if (ready) {
       const int off = k.ist[I_SRCEP * m + d0 + j] - next_hand;
@@ -1354,7 +1389,7 @@ template <typename T> __global__ __launch_bounds__(256) void match_kernel_stream
   nr = nr_s;
   const int pairs = min(nd, nr);
   const int D = k.E.obs_dim;
-  const int NH = k.hp ? 21 : 0;
+  const int NH = k.hp ? HP_ROWS : 0;
   const int per = NF + RING + NH + D;
   for (int w = tid; w < pairs * per; w += NT) {
     const int p = w / per, f = w - p * per;
@@ -1420,14 +1455,23 @@ template <typename T> __global__ void refresh_lag_kernel(KArgs<T> k) {
   Sim<T> S;
   load_sim(k.st, m, e, S);
   Lag<T> lag;
+  // the centre in double, from the fp64 pose where the handle keeps one; the bar positions relative to it (the headings below are
+  // differences of positions)
+  double px[3][3], c[3] = {0.0, 0.0, 0.0};
 #pragma unroll
   for (int b = 0; b < 3; b++) {
-    lag.x[b] = S.x[b];
+    const T xs[3] = {S.x[b].x, S.x[b].y, S.x[b].z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) { px[b][i] = k.hp ? k.hp[(size_t)(HP_QPOS + 7 * b + i) * m + e] : (double)xs[i]; c[i] += px[b][i] * (1.0 / 3.0); }
+  }
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    lag.x[b] = mk(T(px[b][0] - c[0]), T(px[b][1] - c[1]), T(px[b][2] - c[2]));
     lag.z[b] = quat_rot(S.q[b]).ez;
   }
-  T third = T(1.0 / 3.0);
-  k.st[(F_XYLAG + 0) * m + e] = third * (lag.x[0].x + lag.x[1].x + lag.x[2].x);
-  k.st[(F_XYLAG + 1) * m + e] = third * (lag.x[0].y + lag.x[1].y + lag.x[2].y);
+  lag.com[0] = c[0]; lag.com[1] = c[1];
+  aux_st(k, HP_XYLAG, F_XYLAG, e, c[0]);
+  aux_st(k, HP_XYLAG + 1, F_XYLAG + 1, e, c[1]);
   V3<T> cap[6], l, r;
   caps_of(k.P, lag, cap);
   left_right(cap, l, r);
@@ -1446,7 +1490,7 @@ struct tgr_handle {
   int pace_from = -1;  // TGR_PACE_FROM=<lane>: test hook -- pace the donor rows from this lane on, whatever the device's size
   void* st = nullptr;   // T[NF][m]
   int* ist = nullptr;   // int[NI][m]
-  double* hp = nullptr; // double[21][m]: qpos at full precision (fp32 handles on the row kernels), else null
+  double* hp = nullptr; // double[HP_ROWS][m]: qpos and the env layer's absolute positions at full precision (fp32 handles on the row kernels), else null
   void* ring = nullptr; // T[RING][m]
   void* dobs = nullptr; // T[m-n][D]
   int* list_count = nullptr;
@@ -1459,6 +1503,7 @@ struct tgr_handle {
   // donor stream (see KArgs)
   bool async = false;
   int launch = 1;  // index of the last tgr_step (donor launches and match kernels are numbered by it)
+  bool seed_dirty = false;  // tgr_set_seed on a handle with donor lanes: they hold episodes settled under the old key until a full tgr_reset
   hipStream_t sb = nullptr;
   hipEvent_t ev_donor[2] = {nullptr, nullptr}, ev_match = nullptr;
   unsigned long long* dcmd = nullptr; int* dapplied = nullptr; int* dready = nullptr; int* consumed = nullptr;
@@ -1699,8 +1744,8 @@ static int alloc_handle(tgr_handle* h, int n_envs, int donors) {
     HIP_TRY(h, hipMemcpy(h->ist, ist.data(), sizeof(int) * NI * m, hipMemcpyHostToDevice));
   }
   if (h->cfg.precision != TGR_PRECISION_F64 && use_row_kernels(h)) {
-    HIP_TRY(h, hipMalloc((void**)&h->hp, sizeof(double) * 21 * m));
-    HIP_TRY(h, hipMemset(h->hp, 0, sizeof(double) * 21 * m));
+    HIP_TRY(h, hipMalloc((void**)&h->hp, sizeof(double) * HP_ROWS * m));
+    HIP_TRY(h, hipMemset(h->hp, 0, sizeof(double) * HP_ROWS * m));
   }
   HIP_TRY(h, hipMalloc(&h->ring, ts * RING * m));
   HIP_TRY(h, hipMemset(h->ring, 0, ts * RING * m));
@@ -1780,6 +1825,9 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   }
   if (cfg->model_kind < 0 || cfg->model_kind > 1) { g_err = "tgr_create: model_kind must be 0 (flat) or 1 (uneven ground)"; return TGR_ERR_UNSUPPORTED; }
   if (cfg->solimp[4] != 2.0 || cfg->solref[0] >= 0) { g_err = "tgr_create: only direct solref and power-2 solimp"; return TGR_ERR_UNSUPPORTED; }
+  if (cfg->use_cap_size_noise && cfg->env_kind != TGR_ENV_TR) {  // (the reference's tensegrity_env has no such kwarg: TypeError there)
+    g_err = "tgr_create: use_cap_size_noise is a tr_env option"; return TGR_ERR_UNSUPPORTED;
+  }
   if (cfg->use_cap_size_noise && cfg->env_kind == TGR_ENV_TR && cfg->kernel_layout == TGR_KERNEL_BLOCK) {
     g_err = "tgr_create: use_cap_size_noise needs the row kernels"; return TGR_ERR_UNSUPPORTED;
   }
@@ -1886,6 +1934,9 @@ extern "C" int tgr_set_seed(tgr_handle* h, uint64_t seed) {
   HIP_TRY(h, hipDeviceSynchronize());
   HIP_TRY(h, hipMemset(h->ist + (size_t)I_EPISODE * h->m, 0, sizeof(int) * (size_t)h->m));
   if (h->n_classes > 0) HIP_TRY(h, hipMemset(h->cls, 0, sizeof(int) * 2 * h->n_classes));  // (the full reset that follows deals the streams out afresh)
+  // the donor lanes still hold episodes settled under the old key (and, with the donor stream, stay marked ready): a full tgr_reset must
+  // follow before the handle is stepped again -- tgr_step refuses until then rather than hand out old-seed episodes silently
+  if (h->m > h->n) h->seed_dirty = true;
   return TGR_OK;
 }
 extern "C" int tgr_bind_real_observation(tgr_handle* h, void* real_obs_dev) {
@@ -1959,7 +2010,11 @@ template <typename T> static int reset_impl(tgr_handle* h, const uint8_t* mask, 
     for (int i = h->n; i < h->m; i++) idx.push_back(i);
   int cnt = (int)idx.size();
   if (cnt == 0) return TGR_OK;
-  if (h->async && !mask) HIP_TRY(h, hipStreamSynchronize(h->sb));  // (a full reset rewrites the donor lanes: their stream must be idle)
+  if (!mask) h->seed_dirty = false;
+  if (h->async && !mask) {
+    HIP_TRY(h, hipStreamSynchronize(h->sb));  // (a full reset rewrites the donor lanes: their stream must be idle)
+    h->launch = 1;  // launch indices start over: the settle kernel below rewrites dready / consumed / dcmd / dapplied of every donor lane
+  }
   if (h->n_classes > 0) {
     // reset streams: explicit resets of live envs run under the env's own key; a full reset also deals each class's donors the next
     // stream_donors episodes of its stream (donor j of the class: episode next_start + j), ready to be handed out in that order
@@ -2026,6 +2081,7 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
                      T* terminal_obs, T* info, hipStream_t s) {
   if (!actions || !obs || !reward || !terminated || !truncated) { h->err = "tgr_step: null buffer"; return TGR_ERR_INVALID; }
   if (h->cfg.model_kind == 1 && !h->hf) { h->err = "tgr_step: the uneven-ground model needs tgr_set_hfield first"; return TGR_ERR_INVALID; }
+  if (h->seed_dirty) { h->err = "tgr_step: tgr_set_seed must be followed by a full tgr_reset (mask = NULL): the donor lanes hold episodes settled under the old seed"; return TGR_ERR_INVALID; }
   KArgs<T> k;
   fill_args<T>(h, k);
   k.actions = actions; k.obs = obs; k.reward = reward; k.terminated = terminated; k.truncated = truncated;
@@ -2036,7 +2092,11 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
   constexpr int LW = LaneW<T>::value;
   const bool rowk = use_row_kernels(h);
   RowArgs<T, double> ra;
-  if (h->async) h->launch += 1;  // this step's index: its donor launch and its match kernel carry it
+  if (h->async) {
+    // (32-bit launch indices: ~4 weeks of continuous stepping at 900 steps/s; a full tgr_reset starts them over)
+    if (h->launch >= 0x7ffffff0) { h->err = "tgr_step: launch counter exhausted -- call tgr_reset (all envs) to start it over"; return TGR_ERR_INVALID; }
+    h->launch += 1;  // this step's index: its donor launch and its match kernel carry it
+  }
   k.launch_idx = h->launch;
   if (rowk) {
     fill_row_args<T>(h, k, ra);
@@ -2139,10 +2199,12 @@ template <typename T> static int get_state_impl(tgr_handle* h, double* qpos, dou
     HIP_TRY(h, hipMemcpy(ring.data(), h->ring, sizeof(T) * RING * n, hipMemcpyDeviceToHost));
   }
   std::vector<double> hp;
-  if (qpos && h->hp) {
-    hp.resize(21 * n);
-    HIP_TRY(h, hipMemcpy(hp.data(), h->hp, sizeof(double) * 21 * n, hipMemcpyDeviceToHost));
+  if ((qpos || aux) && h->hp) {
+    hp.resize(HP_ROWS * n);
+    HIP_TRY(h, hipMemcpy(hp.data(), h->hp, sizeof(double) * HP_ROWS * n, hipMemcpyDeviceToHost));
   }
+  // an absolute position of the env layer: from the fp64 side array where the handle has one
+  auto absq = [&](int hp_row, int st_field, size_t e) { return h->hp ? hp[(size_t)hp_row * n + e] : (double)st[(size_t)st_field * n + e]; };
   for (size_t e = 0; e < nlive; e++) {
     if (qpos) for (int i = 0; i < 21; i++) qpos[e * 21 + i] = h->hp ? hp[i * n + e] : (double)st[(F_QPOS + i) * n + e];
     if (qvel) for (int i = 0; i < 18; i++) qvel[e * 18 + i] = (double)st[(F_QVEL + i) * n + e];
@@ -2150,13 +2212,13 @@ template <typename T> static int get_state_impl(tgr_handle* h, double* qpos, dou
     if (warm) for (int i = 0; i < 18; i++) warm[e * 18 + i] = (double)st[(F_WARM + i) * n + e];
     if (aux) {
       double* a = aux + e * TGR_AUX_K;
-      a[TGR_AUX_XY_LAG_X] = (double)st[(F_XYLAG + 0) * n + e]; a[TGR_AUX_XY_LAG_Y] = (double)st[(F_XYLAG + 1) * n + e];
+      a[TGR_AUX_XY_LAG_X] = absq(HP_XYLAG, F_XYLAG, e); a[TGR_AUX_XY_LAG_Y] = absq(HP_XYLAG + 1, F_XYLAG + 1, e);
       a[TGR_AUX_PSI_LAG] = (double)st[F_PSILAG * n + e]; a[TGR_AUX_RESET_PSI] = (double)st[F_RESETPSI * n + e];
       a[TGR_AUX_EP_RETURN] = (double)st[F_EPRET * n + e];
       a[TGR_AUX_STEP_NUM] = ist[I_STEPNUM * n + e]; a[TGR_AUX_ELAPSED] = ist[I_ELAPSED * n + e];
       a[TGR_AUX_EPISODE] = ist[I_SRCEP * n + e]; a[TGR_AUX_RING_LEN] = ist[I_RINGLEN * n + e]; a[TGR_AUX_SRC] = ist[I_SRC * n + e];
-      a[TGR_AUX_WAYPT_X] = (double)st[(F_WAYPT + 0) * n + e]; a[TGR_AUX_WAYPT_Y] = (double)st[(F_WAYPT + 1) * n + e];
-      a[TGR_AUX_ORI_X] = (double)st[(F_ORI + 0) * n + e]; a[TGR_AUX_ORI_Y] = (double)st[(F_ORI + 1) * n + e];
+      a[TGR_AUX_WAYPT_X] = absq(HP_WAYPT, F_WAYPT, e); a[TGR_AUX_WAYPT_Y] = absq(HP_WAYPT + 1, F_WAYPT + 1, e);
+      a[TGR_AUX_ORI_X] = absq(HP_ORI, F_ORI, e); a[TGR_AUX_ORI_Y] = absq(HP_ORI + 1, F_ORI + 1, e);
       a[TGR_AUX_VCMD_X] = (double)st[(F_VCMD + 0) * n + e]; a[TGR_AUX_VCMD_Y] = (double)st[(F_VCMD + 1) * n + e];
       a[TGR_AUX_VCMD_W] = (double)st[(F_VCMD + 2) * n + e];
       for (int i = 0; i < 6; i++) a[TGR_AUX_ACT + i] = (double)st[(F_ACT + i) * n + e];
@@ -2187,7 +2249,7 @@ static int set_state_impl(tgr_handle* h, const double* qpos, const double* qvel,
     HIP_TRY(h, hipMemcpy(hp.data(), h->hp, sizeof(double) * 21 * n, hipMemcpyDeviceToHost));
     for (size_t e = 0; e < nlive; e++)
       for (int i = 0; i < 21; i++) hp[i * n + e] = qpos[e * 21 + i];
-    HIP_TRY(h, hipMemcpy(h->hp, hp.data(), sizeof(double) * 21 * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->hp, hp.data(), sizeof(double) * 21 * n, hipMemcpyHostToDevice));  // (rows HP_QPOS ..: the first 21 rows)
   }
   if (qpos) {
     KArgs<T> k;
@@ -2224,6 +2286,19 @@ static int set_state_impl(tgr_handle* h, const double* qpos, const double* qvel,
     HIP_TRY(h, hipMemcpy(h->ring, ring.data(), sizeof(T) * RING * n, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->st, st.data(), sizeof(T) * NF * n, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->ist, ist.data(), sizeof(int) * NI * n, hipMemcpyHostToDevice));
+    if (h->hp) {  // the env layer's absolute positions at full precision (rows HP_XYLAG .. HP_ROWS)
+      const size_t nr = HP_ROWS - HP_XYLAG;
+      std::vector<double> hx(nr * n);
+      double* const dst = h->hp + (size_t)HP_XYLAG * n;
+      HIP_TRY(h, hipMemcpy(hx.data(), dst, sizeof(double) * nr * n, hipMemcpyDeviceToHost));
+      for (size_t e = 0; e < nlive; e++) {
+        const double* a = aux + e * TGR_AUX_K;
+        hx[0 * n + e] = a[TGR_AUX_XY_LAG_X]; hx[1 * n + e] = a[TGR_AUX_XY_LAG_Y];
+        hx[2 * n + e] = a[TGR_AUX_WAYPT_X]; hx[3 * n + e] = a[TGR_AUX_WAYPT_Y];
+        hx[4 * n + e] = a[TGR_AUX_ORI_X]; hx[5 * n + e] = a[TGR_AUX_ORI_Y];
+      }
+      HIP_TRY(h, hipMemcpy(dst, hx.data(), sizeof(double) * nr * n, hipMemcpyHostToDevice));
+    }
   }
   return TGR_OK;
 }

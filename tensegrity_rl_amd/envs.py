@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 from . import _native as N
-from .vec_env import TensegrityVecEnv
+from .vec_env import _TE_KEYS, _TR_KEYS, TensegrityVecEnv
 
 
 class _GymEnvBase:
@@ -43,18 +43,14 @@ class _GymEnvBase:
         a = np.asarray(action, dtype=np.float32)
         if a.shape != (6,):
             raise ValueError("Action dimension mismatch")
-        obs, rew, term, trunc, tobs, info = self._venv.step_tensors(a.reshape(1, 6))
-        ih = info.cpu().numpy().astype(np.float64)[0]
-        d = dict(zip(N.INFO_KEYS, ih[:10]))
-        if self._env_id == "tr_env-v0":
-            d["waypt"] = ih[10:12].copy()
-            d["oripoint"] = ih[12:14].copy()
-            d["tendon_length"] = ih[N.INFO_TENDON_LENGTH:N.INFO_TENDON_LENGTH + 9].copy()
-            ro = self._venv.real_obs if self._venv.real_obs is not None else obs  # tr_env.py:507; equal to obs without observation noise
-            d["real_observation"] = ro.cpu().numpy().astype(np.float64)[0]
-        d["total_bar_contact"] = float(ih[N.INFO_BAR_CONTACT])  # what run.py:149-155 computes from data.contact
-        return (obs.cpu().numpy().astype(np.float64)[0], float(rew.cpu().numpy()[0]), bool(term.cpu().numpy()[0]),
-                bool(trunc.cpu().numpy()[0]), d)
+        # the numpy-facing step of the vec env: ONE packed device-to-host copy brings obs, reward, flags, info (and, with observation noise,
+        # the noise-free observation) home
+        v = self._venv
+        obs, rew, dones, infos = v.step(a.reshape(1, 6))
+        lazy = infos[0]
+        keys = _TR_KEYS if self._env_id == "tr_env-v0" else _TE_KEYS  # the reference's info keys (tensegrity_env.py:383-398, tr_env.py:496-511)
+        d = {k: lazy[k] for k in keys}
+        return obs[0], float(rew[0]), bool(v._h_term[0]), bool(v._h_trunc[0]), d
 
     def render(self):
         return None

@@ -9,6 +9,8 @@ import ctypes as C
 import os
 import time
 
+from collections.abc import Mapping
+
 import numpy as np
 
 from . import _native as N
@@ -66,6 +68,9 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
     if desired_action not in N.ACTIONS:
         raise ValueError(f"unknown desired_action {desired_action!r}")
     cfg = N.default_config(kind, desired_action)
+    if kwargs.get("use_cap_size_noise") and kind != N.ENV_TR:
+        # (the reference's tensegrity_env has no such kwarg -- TypeError there; silently doing nothing would be worse)
+        raise TypeError("use_cap_size_noise is a tr_env option (tr_env.py:143,163,685-706)")
     # the reference picks the model with xml_file (run.py --env_xml); `model="uneven"` does the same without a path
     if kwargs.pop("model", "flat") == "uneven" or is_uneven_xml(kwargs.get("xml_file")):
         N.load().tgr_uneven_config(C.byref(cfg))
@@ -109,6 +114,90 @@ def make_config(env_id="tensegrity_env-v0", desired_action="straight", precision
     return cfg
 
 
+class _InfoFrame:
+    """what one step brought home for info_mode="full": host copies (taken once per step, a few hundred KB) of the info block and of the
+    noise-free observations -- immutable from then on, so a mapping handed out for this step keeps its values whatever steps follow"""
+    __slots__ = ("info", "real_obs", "tr")
+
+    def __init__(self, info, real_obs, tr):
+        self.info, self.real_obs, self.tr = info, real_obs, tr
+
+
+_SCALAR = {k: j for j, k in enumerate(N.INFO_KEYS)}
+_TR_KEYS = N.INFO_KEYS + ["waypt", "oripoint", "tendon_length", "real_observation", "total_bar_contact"]
+_TE_KEYS = N.INFO_KEYS + ["total_bar_contact"]
+
+
+class LazyInfo(Mapping):
+    """The reference's info dict of ONE env for ONE step (tensegrity_env.py:383-398, tr_env.py:496-511), materialised key by key on access from
+    the step's frame.  A snapshot, not a view: the frame is never written again.  `extra` holds what VecEnv semantics add for an env that
+    finished (terminal_observation, TimeLimit.truncated, episode)."""
+    __slots__ = ("_f", "_i", "_extra")
+
+    def __init__(self, frame, i, extra=None):
+        self._f, self._i, self._extra = frame, i, extra
+
+    def __getitem__(self, k):
+        if self._extra is not None and k in self._extra:
+            return self._extra[k]
+        f, i = self._f, self._i
+        j = _SCALAR.get(k)
+        if j is not None:
+            return np.float64(f.info[i, j])
+        if k == "total_bar_contact":  # what run.py:149-155 computes from data.contact
+            return float(f.info[i, N.INFO_BAR_CONTACT])
+        if f.tr:  # tr_env.py:506-511
+            if k == "waypt":
+                return f.info[i, 10:12].astype(np.float64)
+            if k == "oripoint":
+                return f.info[i, 12:14].astype(np.float64)
+            if k == "tendon_length":
+                return f.info[i, N.INFO_TENDON_LENGTH:N.INFO_TENDON_LENGTH + 9].astype(np.float64)
+            if k == "real_observation":
+                return f.real_obs[i].astype(np.float64)
+        raise KeyError(k)
+
+    def __iter__(self):
+        yield from (_TR_KEYS if self._f.tr else _TE_KEYS)
+        if self._extra is not None:
+            yield from self._extra
+
+    def __len__(self):
+        return len(_TR_KEYS if self._f.tr else _TE_KEYS) + (len(self._extra) if self._extra is not None else 0)
+
+    def copy(self):
+        return dict(self)
+
+    def __repr__(self):
+        return repr(dict(self))
+
+
+class LazyInfoList(list):
+    """infos of one step: a list whose entries come into being when they are looked at (SB3 indexes the finished envs and iterates for
+    `episode`; run.py:139-161 reads env 0's keys) -- building 4096 dicts per step cost 4-8x the device step"""
+    __slots__ = ("_frame", "_extras")
+
+    def __init__(self, n, frame, extras):
+        super().__init__([None] * n)
+        self._frame, self._extras = frame, extras
+
+    def _make(self, i):
+        x = LazyInfo(self._frame, i, self._extras.get(i))
+        list.__setitem__(self, i, x)
+        return x
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        x = list.__getitem__(self, i)
+        return x if x is not None else self._make(i if i >= 0 else len(self) + i)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            x = list.__getitem__(self, i)
+            yield x if x is not None else self._make(i)
+
+
 class TensegrityVecEnv:
     """SB3 VecEnv duck type.  Not a subclass so that stable_baselines3 is optional; `to_sb3()` wraps it in a real
     VecEnv subclass when SB3 is importable."""
@@ -148,7 +237,10 @@ class TensegrityVecEnv:
             # every output of a step lives in ONE device allocation, so that the numpy-facing step_wait() brings a step home with a single
             # device-to-host copy into a pinned mirror (hard part 6): [obs | terminal_obs | info | reward | terminated | truncated]
             isz = 8 if self.f64 else 4
-            sizes = [n * D * isz, n * D * isz, n * N.INFO_K * isz, n * isz, n, n]
+            # info["real_observation"] (tr_env.py:507): the noise-free observation; only needed (and bound) with use_obs_noise -- part of
+            # the packed block, so that it comes home in the same copy
+            want_real = bool(self.cfg.use_obs_noise and self.cfg.env_kind == N.ENV_TR)
+            sizes = [n * D * isz, n * D * isz, n * N.INFO_K * isz, n * isz, n, n, (-2 * n) % 8, n * D * isz if want_real else 0]
             offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
             self._pack = torch.zeros(int(offs[-1]), dtype=torch.uint8, device=self.device)
             self._pack_h = torch.zeros(int(offs[-1]), dtype=torch.uint8).pin_memory()
@@ -164,8 +256,8 @@ class TensegrityVecEnv:
             self._h_obs, self._h_tobs, self._h_info, self._h_rew, self._h_term, self._h_trunc = hv
             self._act_h = torch.zeros((n, 6), dtype=torch.float32).pin_memory()
             self._act_d = torch.zeros((n, 6), dtype=torch.float32, device=self.device)
-            # info["real_observation"] (tr_env.py:507): the noise-free observation; only needed (and bound) with use_obs_noise
-            self.real_obs = torch.zeros((n, D), dtype=dt, device=self.device) if self.cfg.use_obs_noise and self.cfg.env_kind == N.ENV_TR else None
+            self.real_obs = sec(self._pack, 7, dt, (n, D)) if want_real else None
+            self._h_real = sec(self._pack_h, 7, dt, (n, D)).numpy() if want_real else None
         if self.real_obs is not None:
             N.check(self.handle, self.lib.tgr_bind_real_observation(self.handle, self.real_obs.data_ptr()), "tgr_bind_real_observation")
         self.observation_space = Box(low=-np.inf, high=np.inf, shape=(D,), dtype=np.float64)
@@ -248,29 +340,27 @@ class TensegrityVecEnv:
         return self.step_wait()
 
     def _infos(self, dones, term_h, trunc_h, obs_h):
-        """info_mode="minimal": empty dicts except for finished envs (all SB3 itself reads); "full": the reference's info dict.
-        Reads the pinned host mirror of the step that has just been brought home."""
+        """info_mode="minimal": empty dicts except for finished envs (all SB3 itself reads); "full": the reference's info dict for every env,
+        as lazy snapshot mappings (LazyInfo).  Reads the pinned host mirror of the step that has just been brought home."""
         n = self.num_envs
         ih = self._h_info
-        if self.info_mode == "full":
-            ih = ih.astype(np.float64)
-            infos = [dict(zip(N.INFO_KEYS, ih[i, :10])) for i in range(n)]
+        full = self.info_mode == "full"
+        if full:
+            # one frame per step: copies of the info block and of the noise-free observations (tr_env.py:507: of this step -- for an env that
+            # just finished, of its last step); the per-env mappings are made when somebody looks at them (LazyInfoList)
             tr = self.cfg.env_kind == N.ENV_TR
-            for i in range(n):
-                if tr:  # tr_env.py:506-511
-                    infos[i]["waypt"] = ih[i, 10:12].copy(); infos[i]["oripoint"] = ih[i, 12:14].copy()
-                    infos[i]["tendon_length"] = ih[i, N.INFO_TENDON_LENGTH:N.INFO_TENDON_LENGTH + 9].copy()
-                infos[i]["total_bar_contact"] = float(ih[i, N.INFO_BAR_CONTACT])  # what run.py:149-155 computes from data.contact
-            if tr:  # tr_env.py:507: the noise-free observation of this step (of the last step for an env that just finished)
-                if self.real_obs is not None:
-                    rh = self.real_obs.cpu().numpy().astype(np.float64)
+            rh = None
+            if tr:
+                if self._h_real is not None:
+                    rh = self._h_real.copy()
                 else:
-                    rh = obs_h.copy()
+                    rh = self._h_obs.copy()
                     fin = np.nonzero(dones)[0]
                     if fin.size and self.cfg.auto_reset:
                         rh[fin] = self._h_tobs[fin]
-                for i in range(n):
-                    infos[i]["real_observation"] = rh[i]
+            frame = _InfoFrame(ih.copy(), rh, tr)
+            extras = {}
+            infos = LazyInfoList(n, frame, extras)
         else:
             infos = [{} for _ in range(n)]
         idx = np.nonzero(dones)[0]
@@ -279,7 +369,7 @@ class TensegrityVecEnv:
             ep = ih[idx, 14:16]
             now = round(time.time() - self._t0, 6)
             for j, i in enumerate(idx):
-                d = infos[i]
+                d = extras.setdefault(int(i), {}) if full else infos[i]
                 d["terminal_observation"] = th[j]
                 d["TimeLimit.truncated"] = bool(trunc_h[i] and not term_h[i])
                 d["episode"] = {"r": float(ep[j, 0]), "l": int(ep[j, 1]), "t": now}
@@ -296,12 +386,15 @@ class TensegrityVecEnv:
         except Exception:
             pass
 
-    def seed(self, seed=None, reset=True):
-        """re-key the reset RNG (SB3's VecEnv.seed).  Every lane's episode counter starts over, and the donor lanes -- which hold episodes
-        settled under the old key -- are settled afresh by the full reset that follows, so that seed(s) twice gives the same episodes twice"""
+    def seed(self, seed=None, reset=False):
+        """re-key the reset RNG (SB3's VecEnv.seed).  Every lane's episode counter starts over.  LAZY: SB3 calls env.seed() and then
+        env.reset(), and a full reset settles every env and every donor lane for 50 control periods -- so seed() itself only re-keys, and the
+        reset() that follows is the ONE full reset (the first visible episodes are episode 0 of the new key; seed(s) twice gives the same
+        episodes twice).  Until that reset the donor lanes still hold episodes settled under the old key: the library refuses to step
+        (tgr_step returns an error) rather than hand them out.  reset=True does the full reset right here."""
         if seed is not None:
             N.check(self.handle, self.lib.tgr_set_seed(self.handle, int(seed)), "tgr_set_seed")
-            if reset:  # (reset=False: the caller resets right away itself)
+            if reset:
                 self.reset_tensors()
         return [seed] * self.num_envs
 

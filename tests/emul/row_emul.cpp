@@ -55,9 +55,11 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
   for (int e = 0; e < n; e++) {
     K kd[K_SLAB], rd[R_SLAB], ad[A_SLAB * n_pages<MODEL>()];
     F hd[H_SLAB], lp[LP_SLAB];
+    K lc[LC_SLAB];
+    F xs[XS_SLAB];
     F fd[f_slab<MODEL>()], td[T_SLAB], cd[C_SLAB * n_pages<MODEL>()];
     RMem<K, F> M;
-    M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0}; M.cd = Slab<F>{cd, 1, 0}; M.hd = Slab<F>{hd, 1, 0}; M.lp = Slab<F>{lp, 1, 0};
+    M.kd = Slab<K>{kd, 1, 0}; M.fd = Slab<F>{fd, 1, 0}; M.td = Slab<F>{td, 1, 0}; M.rd = Slab<K>{rd, 1, 0}; M.ad = Slab<K>{ad, 1, 0}; M.cd = Slab<F>{cd, 1, 0}; M.hd = Slab<F>{hd, 1, 0}; M.lp = Slab<F>{lp, 1, 0}; M.lc = Slab<K>{lc, 1, 0}; M.xs = Slab<F>{xs, 1, 0};
     M.dbg = trace ? trace + (size_t)TRACE_WORDS * e : nullptr;
     store_role_consts<K, F, TK, MODEL>(PK, M.rd);
     RLag<K, F> lag;
@@ -96,7 +98,8 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
     for (int i = 0; i < 6; i++) act[6 * e + i] = kd[KACT + i].v[0];
     double* o = out + 32 * e;
     for (int t = 0; t < 9; t++) { o[t] = lp[LPT + t].v[0]; bad += check_rep(lp[LPT + t], "tenL", e); }
-    for (int i = 0; i < 9; i++) o[9 + i] = lp[LPX + i].v[0];
+    for (int i = 0; i < 9; i++) o[9 + i] = (double)lp[LPX + i].v[0] + (double)lc[LCX + i % 3].v[0];  // (lp holds the lagged positions relative to their centre lc)
+    for (int i = 0; i < 3; i++) { o[26 + i] = (double)lc[LCX + i].v[0]; bad += check_rep(lc[LCX + i], "lagged centre", e); }
     o[18] = lag.cfrc_absmax.v[0]; o[19] = lag.cfrc_clip_sq.v[0]; o[20] = lag.bar_contact.v[0]; o[21] = lag.overflow.v[0];
     o[22] = lag.n_unconv.v[0]; o[23] = lag.n_it; o[24] = lag.n_ls; o[25] = lag.n_own.v[0];
     bad += check_rep(lag.cfrc_absmax, "cfrc", e) + check_rep(lag.bar_contact, "bar_contact", e) + check_rep(lag.n_unconv, "n_unconv", e);

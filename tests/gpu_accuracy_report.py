@@ -20,7 +20,7 @@ def oracle_trace(ob):
 
 
 FLIP_CLASSES = {"cap on the floor": 0x00003f, "bar pair": 0x000fc0, "lanes 12-14 (pair's third slot / bar on the terrain)": 0x007000,
-                "cap on a second facet": 0x3f0000}
+                "cap on a second facet": 0x3f0000, "roving slot (lane 15)": 0x008000}
 
 
 def classify(trg, tro):
@@ -34,29 +34,52 @@ def classify(trg, tro):
     return flip, capped, first
 
 
-def run_case(kind, uneven, n, steps, img, **kw):
+def run_case(kind, uneven, n, steps, img, action="straight", offset=(0.0, 0.0), **kw):
+    """fp32 handle against the oracle on identical (state, action), `steps` control periods from the oracle's own trajectory.
+    action: the env's desired_action; offset: the whole experiment moved by (dx, dy) metres from the origin (flat floor: the robots; heightfield:
+    the robots and the terrain -- the physics is the same, the coordinates are not).  Per env-step: qpos / qvel relative error, and the ENV
+    LAYER of the production path -- observation, reward, x / y velocity, terminated -- against the oracle's."""
     from tensegrity_rl_amd import TensegrityVecEnv
     from tensegrity_rl_amd.vec_env import heights_from_image
     okw = dict(heights=heights_from_image(img), model_kind=1) if uneven else {}
     gkw = dict(model="uneven", terrain=img) if uneven else {}
-    ob = O.OracleBatch(O.make_cfg(kind, "straight", **okw), n, seed=1234); ob.reset()
-    env = TensegrityVecEnv(n, kind + "-v0", precision="f32", auto_reset=False, seed=1234, **gkw, **kw)
+    dx, dy = float(offset[0]), float(offset[1])
+    ob = O.OracleBatch(O.make_cfg(kind, action, **okw), n, seed=1234); ob.reset()
+    if dx or dy:
+        if uneven:
+            for i in range(n):
+                m = ob.env(i).model
+                m.hf_pos[0] += dx; m.hf_pos[1] += dy
+            gkw["config_overrides"] = dict(kw.pop("config_overrides", {}), hf_pos=(dx, dy, -1.0))
+        ob.translate(dx, dy)
+    env = TensegrityVecEnv(n, kind + "-v0", desired_action=action, precision="f32", auto_reset=False, seed=1234, **gkw, **kw)
     trace = env.bind_substep_trace()
     rng = np.random.default_rng(0)
-    eq, ev, fl, cp, fb = [], [], [], [], []
+    cols = {k: [] for k in ("eq", "ev", "flip", "capped", "first", "obs", "obs_rel", "rew", "rew_rel", "vel", "term", "oterm", "info")}
     for t in range(steps):
         oracle_to_gpu_state(ob, env)
         a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
-        ob.step(a, auto_reset=False)
-        env.step_tensors(a)
+        o_obs, o_rew, o_term, _, _, o_info = ob.step(a, auto_reset=False)
+        g_obs, g_rew, g_term, _, _, g_info = [x.cpu().numpy().astype(np.float64) for x in env.step_tensors(a)]
         st = env.get_state()
         q2, v2 = ob.get_state()[:2]
-        eq.append(rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3)); ev.append(rel_env(st["qvel"] - v2, v2, 1e-2))
+        cols["eq"].append(rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3)); cols["ev"].append(rel_env(st["qvel"] - v2, v2, 1e-2))
         f, c, b = classify(trace.cpu().numpy(), oracle_trace(ob))
-        fl.append(f); cp.append(c); fb.append(b)
+        cols["flip"].append(f); cols["capped"].append(c); cols["first"].append(b)
+        # the env layer: observation (absolute, and relative to the env's largest velocity entry like qvel: most of an observation IS qvel),
+        # reward, x / y velocity (info 7, 8), the ten scalar info entries, terminated
+        eo = np.abs(g_obs - o_obs).max(axis=1)
+        cols["obs"].append(eo); cols["obs_rel"].append(eo / np.maximum(np.abs(v2).max(axis=1), 1e-2))
+        cols["rew"].append(np.abs(g_rew - o_rew)); cols["rew_rel"].append(np.abs(g_rew - o_rew) / np.maximum(1.0, np.abs(o_rew)))
+        cols["vel"].append(np.abs(g_info[:, 7:9] - o_info[:, 7:9]).max(axis=1))
+        sc = np.maximum(1.0, np.abs(o_info[:, :10]))
+        cols["info"].append((np.abs(g_info[:, :10] - o_info[:, :10]) / sc).max(axis=1))
+        cols["term"].append(g_term.astype(bool) != o_term); cols["oterm"].append(o_term.copy())
     s = env.stats()
     env.close(); ob.close()
-    return dict(eq=np.concatenate(eq), ev=np.concatenate(ev), flip=np.concatenate(fl), capped=np.concatenate(cp), first=np.concatenate(fb), stats=s)
+    r = {k: np.concatenate(v) for k, v in cols.items()}
+    r["stats"] = s
+    return r
 
 
 def summary(r):
@@ -66,11 +89,30 @@ def summary(r):
     nf = bad & ~fl
     worst = lambda m: float(max(np.nanmax(eq[m]), np.nanmax(ev[m]))) if m.any() else 0.0
     kinds = {name: int(((r["first"][bad & fl] & mask) != 0).sum()) for name, mask in FLIP_CLASSES.items()}
+    mx = lambda a, m: float(np.nanmax(a[m])) if m.any() else 0.0
+    ok = ~fl & finite  # env-steps whose twenty sub-steps instantiated the oracle's contacts: where the env layer is held to its bounds
     return dict(flip_kinds=kinds, n=int(eq.size), qpos_in=float((eq < 1e-4).mean()), qvel_in=float((ev < 1e-4).mean()), both_in=float((~bad).mean()),
                 outliers=int(bad.sum()), flip=int((bad & fl).sum()), capped=int((nf & cp).sum()), neither=int((nf & ~cp).sum()),
                 nonfinite=int((~finite).sum()), worst_flip=worst(bad & fl), worst_nonflip=worst(nf), flips_inside_bound=int((~bad & fl).sum()),
+                flips=int(fl.sum()),
                 median_qpos=float(np.median(eq)), median_qvel=float(np.median(ev)), p99_qvel=float(np.percentile(ev, 99)), p999_qvel=float(np.percentile(ev, 99.9)),
-                wave_iters_per_substep=s["newton_iters_per_substep"], unconverged_fraction=s["unconverged_lane_substeps"] / max(1, s["lane_substeps"]))
+                wave_iters_per_substep=s["newton_iters_per_substep"], unconverged_fraction=s["unconverged_lane_substeps"] / max(1, s["lane_substeps"]),
+                # env layer, outside flips: worst observation error (absolute; relative to max(|qvel|_inf, 1e-2)), reward error relative to
+                # max(1, |reward|), x / y velocity error [m/s], the ten info scalars relative to max(1, |value|)
+                obs_nonflip=mx(r["obs"], ok), obs_rel_nonflip=mx(r["obs_rel"], ok), rew_nonflip=mx(r["rew_rel"], ok), vel_nonflip=mx(r["vel"], ok),
+                info_nonflip=mx(r["info"], ok), obs_median=float(np.median(r["obs"])), rew_median=float(np.median(r["rew_rel"])),
+                obs_in=float((r["obs_rel"] < 1e-4).mean()), rew_in=float((r["rew_rel"] < 1e-4).mean()),
+                term_mismatch=int(r["term"].sum()), term_mismatch_nonflip=int((r["term"] & ~fl).sum()), oracle_terminated=int(r["oterm"].sum()))
+
+
+MODES = [("tensegrity_env", "straight"), ("tensegrity_env", "turn"), ("tr_env", "straight"), ("tr_env", "turn"), ("tr_env", "tracking"),
+         ("tr_env", "aiming"), ("tr_env", "vel_track")]
+
+
+def env_layer_line(tag, u):
+    return (f"{tag:38s} | obs {100*u['obs_in']:.3f} % rew {100*u['rew_in']:.3f} % inside 1e-4 | outside flips: obs {u['obs_nonflip']:.1e} (rel {u['obs_rel_nonflip']:.1e}) "
+            f"rew {u['rew_nonflip']:.1e} vel {u['vel_nonflip']:.1e} info {u['info_nonflip']:.1e} | terminated: oracle {u['oracle_terminated']}, "
+            f"mismatches {u['term_mismatch']} ({u['term_mismatch_nonflip']} outside flips) | flips {u['flips']} | qpos {100*u['qpos_in']:.3f} % qvel {100*u['qvel_in']:.3f} %")
 
 
 if __name__ == "__main__":
@@ -93,3 +135,11 @@ if __name__ == "__main__":
               f"{u['wave_iters_per_substep']:.2f} | {100*u['unconverged_fraction']:.3f} %", flush=True)
         if u["flip"]:
             print("#    what flipped first in the outliers that are flips: " + ", ".join(f"{k}: {v}" for k, v in u["flip_kinds"].items() if v), flush=True)
+    print("# env layer of the fp32 handles (observation / reward / x, y velocity / info / terminated against the oracle), every mode, at the origin and 30 m away")
+    for kind, action in MODES:
+        for off in ((0.0, 0.0), (30.0, -20.0)):
+            for uneven in (False, True):
+                if uneven and action not in ("straight", "tracking"):
+                    continue
+                u = summary(run_case(kind, uneven, n, steps, img, action=action, offset=off, **kw))
+                print(env_layer_line(f"{kind} {action} {'uneven' if uneven else 'flat'} @({off[0]:g},{off[1]:g})", u), flush=True)

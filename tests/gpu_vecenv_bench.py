@@ -15,9 +15,14 @@ def measure(n=4096, env_id="tensegrity_env-v0", steps=300, info_mode="minimal", 
     for i in range(30):
         env.step(acts[i % 16])
     t0 = time.perf_counter(); dones = 0
+    keys = ("x_position", "y_position", "x_velocity", "reward_forward") + (("tendon_length", "real_observation") if env_id.startswith("tr_env") else ())
+    sink = 0.0
     for i in range(steps):
         obs, rew, done, infos = env.step(acts[i % 16])
         dones += int(done.sum())
+        if info_mode == "full":  # what run.py:139-161 does with the info of its one env, every step
+            for k in keys:
+                sink += float(np.sum(infos[0][k]))
     dt = time.perf_counter() - t0
     dacts = [torch.as_tensor(a, device=env.device) for a in acts]
     torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -34,4 +39,4 @@ if __name__ == "__main__":
     env_id = sys.argv[2] if len(sys.argv) > 2 else "tensegrity_env-v0"
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 300
     for mode in ("minimal", "full"):
-        print(measure(n, env_id, steps if mode == "minimal" else max(steps // 10, 10), mode), flush=True)
+        print(measure(n, env_id, steps, mode), flush=True)

@@ -123,11 +123,10 @@ def test_every_recorded_fixture_is_replayed(golden_dir):
     assert have == sorted(FIXTURES)
 
 
-@pytest.mark.parametrize("fname", FIXTURES)
-def test_reward_obs_epilogue_against_reference_fixture(oracle, golden_dir, fname):
-    """fp64 HIP epilogue on the states recorded from the reference classes (tests/golden, oracle/gen_golden.py), every fixture:
-    set_state(golden state k-1, incl. the heading deque and tr_env's _step_num) ; step(golden action k) -> golden obs / reward /
-    terminated / info of step k, and the deque the reference holds afterwards (tensegrity_env.py:326-345, tr_env.py:376-378,425-446)."""
+def _replay_fixture(golden_dir, fname, prec):
+    """set_state(golden state k-1, incl. the heading deque and tr_env's _step_num) ; step(golden action k) on a handle of precision `prec`;
+    returns the worst deviations from the golden obs / reward / info of step k and from the deque the reference holds afterwards, and the
+    number of steps whose `terminated` differs"""
     import os
     from gpu_common import AUX, AUX_K
     from tensegrity_rl_amd import TensegrityVecEnv
@@ -138,8 +137,9 @@ def test_reward_obs_epilogue_against_reference_fixture(oracle, golden_dir, fname
         kw.update(model="uneven", terrain=np.load(os.path.join(golden_dir, "terrain_100.npy")))
     T = int(g["steps_per_episode"])
     action = str(g["action"])
-    env = TensegrityVecEnv(1, kind + "-v0", desired_action=action, desired_direction=float(g["direction"]), precision="f64",
+    env = TensegrityVecEnv(1, kind + "-v0", desired_action=action, desired_direction=float(g["direction"]), precision=prec,
                            auto_reset=False, **kw)
+    worst = dict(obs=0.0, reward=0.0, info=0.0, ring=0.0, term=0, steps=0)
     k = 0
     for ep in range(len(g["reset_theta"])):
         qpos, qvel, ctrl = g["reset_qpos"][ep], g["reset_qvel"][ep], g["reset_ctrl"][ep]
@@ -157,15 +157,16 @@ def test_reward_obs_epilogue_against_reference_fixture(oracle, golden_dir, fname
             A[0, AUX["ring_len"]] = ring_len; A[0, AUX["ring"]:AUX["ring"] + 32] = ring
             env.set_state(qpos[None], qvel[None], ctrl[None], None, A)
             obs, rew, term, trunc, _, info = [x.cpu().numpy() for x in env.step_tensors(g["actions"][k][None])]
-            np.testing.assert_allclose(obs[0], g["obs"][k], atol=2e-6, err_msg=f"{fname} step {k}")
-            assert abs(rew[0] - g["reward"][k]) < 1e-6, (fname, k, rew[0], g["reward"][k])
-            assert bool(term[0]) == bool(g["terminated"][k]), (fname, k)
+            worst["obs"] = max(worst["obs"], float(np.abs(obs[0] - g["obs"][k]).max()))
+            worst["reward"] = max(worst["reward"], abs(float(rew[0]) - float(g["reward"][k])) / max(1.0, abs(float(g["reward"][k]))))
+            worst["term"] += int(bool(term[0]) != bool(g["terminated"][k]))
             for j, name in enumerate(["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
                                       "distance_from_origin", "x_velocity", "y_velocity", "forward_reward"]):
-                assert abs(info[0, j] - g[name][k]) < 2e-6, (fname, k, name)
+                worst["info"] = max(worst["info"], abs(float(info[0, j]) - float(g[name][k])) / max(1.0, abs(float(g[name][k]))))
             aux = env.get_state()["aux"][0]
             assert int(aux[AUX["ring_len"]]) == int(g["ring_len"][k]), (fname, k)
-            np.testing.assert_allclose(aux[AUX["ring"]:AUX["ring"] + int(g["ring_len"][k])], g["ring"][k][:int(g["ring_len"][k])], atol=2e-6)
+            if int(g["ring_len"][k]):
+                worst["ring"] = max(worst["ring"], float(np.abs(aux[AUX["ring"]:AUX["ring"] + int(g["ring_len"][k])] - g["ring"][k][:int(g["ring_len"][k])]).max()))
             if kind == "tr_env":
                 assert int(aux[AUX["step_num"]]) == int(g["step_num"][k])
             qpos, qvel, ctrl, act = g["qpos"][k], g["qvel"][k], g["ctrl"][k], g["act"][k]
@@ -173,7 +174,30 @@ def test_reward_obs_epilogue_against_reference_fixture(oracle, golden_dir, fname
             ring, ring_len, step_num = g["ring"][k], int(g["ring_len"][k]), int(g["step_num"][k])
             psi_lag = float(g["psi"][k]) if action != "turn" or kind == "tr_env" else psi_lag
             k += 1
+            worst["steps"] += 1
     env.close()
+    return worst
+
+
+@pytest.mark.parametrize("fname", FIXTURES)
+def test_reward_obs_epilogue_against_reference_fixture(golden_dir, fname):
+    """fp64 HIP epilogue on the states recorded from the reference classes (tests/golden, oracle/gen_golden.py), every fixture:
+    set_state(golden state k-1, incl. the heading deque and tr_env's _step_num) ; step(golden action k) -> golden obs / reward /
+    terminated / info of step k, and the deque the reference holds afterwards (tensegrity_env.py:326-345, tr_env.py:376-378,425-446)."""
+    w = _replay_fixture(golden_dir, fname, "f64")
+    assert w["steps"] > 0 and w["term"] == 0, (fname, w)
+    assert w["obs"] < 2e-6 and w["reward"] < 1e-6 and w["info"] < 2e-6 and w["ring"] < 2e-6, (fname, w)
+
+
+@pytest.mark.parametrize("fname", FIXTURES)
+def test_fp32_handle_replays_every_reference_fixture(golden_dir, fname):
+    """The same replay on the PRODUCTION precision (fp32 handle: fp32 state and outputs, pose / kinematics / absolute positions of the env
+    layer in fp64): every step of every fixture recorded from the reference classes.  Stated tolerance: observation 2e-4 absolute (its
+    velocity entries are qvel, held to 1e-4 relative of velocities of order 1 m/s -- an fp32 observation of a tendon length of 1 m alone
+    carries 6e-8), reward and the ten info scalars 1e-4 relative to max(1, |value|), the heading deque 1e-5 rad, `terminated` identical."""
+    w = _replay_fixture(golden_dir, fname, "f32")
+    assert w["steps"] > 0 and w["term"] == 0, (fname, w)
+    assert w["obs"] < 2e-4 and w["reward"] < 1e-4 and w["info"] < 1e-4 and w["ring"] < 1e-5, (fname, w)
 
 
 @pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f64", 1e-9)])

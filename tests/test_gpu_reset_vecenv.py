@@ -313,21 +313,26 @@ def test_paced_donor_rows_settle_the_same_episodes(oracle, monkeypatch):
     env.close()
 
 
+@pytest.mark.parametrize("info_mode", ["minimal", "full"])
 @pytest.mark.parametrize("env_id,model", [("tensegrity_env-v0", "flat"), ("tr_env-v0", "flat"), ("tr_env-v0", "uneven")])
-def test_step_and_step_tensors_return_the_same_values(golden_dir, env_id, model):
+def test_step_and_step_tensors_return_the_same_values(golden_dir, env_id, model, info_mode):
     """The numpy-facing SB3 surface (step_async / step_wait: one packed device-to-host copy into a pinned mirror) against the device
     tensors of the same step: observations, rewards, dones, and for every finished env terminal_observation, TimeLimit.truncated and
-    Monitor's episode record."""
+    Monitor's episode record.  info_mode="full": every env's info is the reference's dict (tensegrity_env.py:383-398, tr_env.py:496-511),
+    handed out as a lazy SNAPSHOT mapping -- its values equal the device's info block of that step, and still do after later steps."""
     import os
     import torch
     from tensegrity_rl_amd import TensegrityVecEnv
+    from tensegrity_rl_amd import _native as N
     n = 256
     kw = dict(model="uneven", terrain=np.load(os.path.join(golden_dir, "terrain_100.npy"))) if model == "uneven" else {}
-    envs = [TensegrityVecEnv(n, env_id, seed=5, max_episode_steps=7, **kw) for _ in range(2)]
+    envs = [TensegrityVecEnv(n, env_id, seed=5, max_episode_steps=7, info_mode=info_mode, **kw) for _ in range(2)]
     o0 = envs[0].reset(); o1 = envs[1].reset_tensors().cpu().numpy()
     assert np.array_equal(o0.astype(np.float32), o1)
     rng = np.random.default_rng(1)
     finished = 0
+    tr = env_id.startswith("tr_env")
+    kept = []
     for t in range(16):
         a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
         obs, rew, dones, infos = envs[0].step(a)
@@ -341,8 +346,27 @@ def test_step_and_step_tensors_return_the_same_values(golden_dir, env_id, model)
                 assert np.array_equal(infos[i]["terminal_observation"].astype(np.float32), ttobs[i])
                 assert infos[i]["TimeLimit.truncated"] == bool(ttrunc[i] and not tterm[i])
                 assert infos[i]["episode"]["l"] == int(tinfo[i, 15]) and infos[i]["episode"]["r"] == float(tinfo[i, 14])
-            else:
+            elif info_mode == "minimal":
                 assert infos[i] == {}
+        if info_mode == "full":
+            want = set(N.INFO_KEYS) | {"total_bar_contact"} | ({"waypt", "oripoint", "tendon_length", "real_observation"} if tr else set())
+            for i in (0, 1, n // 2, n - 1):
+                d = infos[i]
+                assert want <= set(d.keys()) and (dones[i] or set(d.keys()) == want)
+                for j, k in enumerate(N.INFO_KEYS):
+                    assert d[k] == np.float64(tinfo[i, j]), (i, k)
+                assert d["total_bar_contact"] == float(tinfo[i, N.INFO_BAR_CONTACT])
+                if tr:
+                    assert np.array_equal(d["waypt"], tinfo[i, 10:12].astype(np.float64)) and np.array_equal(d["oripoint"], tinfo[i, 12:14].astype(np.float64))
+                    assert np.array_equal(d["tendon_length"], tinfo[i, 16:25].astype(np.float64)) and d["tendon_length"].dtype == np.float64
+                    # tr_env.py:507 without observation noise: the observation of the step (of its last step for an env that just finished)
+                    assert np.array_equal(d["real_observation"].astype(np.float32), ttobs[i] if dones[i] else tobs_[i])
+                assert d.get("no such key") is None and dict(d)["x_position"] == d["x_position"]
+            if t == 3:
+                kept = [(infos[5], dict(infos[5])), (infos[-1], dict(infos[-1]))]
+    for lazy, snap in kept:   # a mapping handed out at step 3 still holds step 3's values after twelve more steps
+        for k, v in snap.items():
+            assert np.array_equal(np.asarray(lazy[k]), np.asarray(v)) if not isinstance(v, dict) else lazy[k] == v
     assert finished >= n   # the 7-step time limit alone ends every episode twice
     for e in envs:
         e.close()
@@ -381,11 +405,15 @@ def test_reset_streams_hand_out_a_class_stream_in_order(oracle):
     env.close()
 
 
-@pytest.mark.parametrize("donors_per_env,limit", [(1.25, 5000), (0.25, 20)])
+@pytest.mark.parametrize("donors_per_env,limit", [(1.25, 5000), (0.25, 20), (0.0625, 5000)])
 def test_reset_streams_make_auto_reset_shard_invariant(donors_per_env, limit):
     """the same 512 global envs stepped as part of a 1024-env handle and as a 512-env shard (first_env_id = 512), auto-reset on, random
     actions, 150 steps across many resets: observations, rewards and done flags are bitwise equal at every step -- with plenty of donor
-    lanes, and with so few (and a 20-step time limit) that most resets are settled by the envs themselves."""
+    lanes; with so few (and a 20-step time limit) that most resets are settled by the envs themselves and no donor ever finishes; and with
+    16 donor lanes per class under the natural episode lengths (~47 steps): under-provisioned classes whose donors DO finish episodes while
+    the match kernel keeps re-arming the holders of starved episodes -- the case in which a donor's ready word and its re-arm command meet
+    in one launch (readiness is decided on match-side words only: a ready stamp at or below the lane's last command tag is the replaced
+    episode's)."""
     import torch
     from tensegrity_rl_amd import TensegrityVecEnv
     B, steps = 256, 150

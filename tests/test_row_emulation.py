@@ -131,3 +131,93 @@ def test_uneven_ground_mixed_precision_tolerance(oracle, golden_dir):
     assert (eq < 1e-4).mean() >= 0.99 and (ev < 1e-4).mean() >= 0.99, ((eq < 1e-4).mean(), (ev < 1e-4).mean())
     assert np.median(ev) < 5e-6
     ob.close()
+
+
+def _crossed_bars(pairs, pen, s0=0.4):
+    """qpos of three free bars far above the floor; for every (A, B) in `pairs` bar B's axis crosses over bar A's at distance 2 r - pen, both
+    at s0 from their centres -- where each carries a b-cylinder (r = 0.035 inside r = 0.0381, flat xml:77).  pen > 6.2 mm: r-r, r-b, b-r
+    AND b-b touch (three contacts besides the r-cylinders side to side)"""
+    R_CYL = 0.0381
+    yq = np.array([np.cos(np.pi / 4), 0, np.sin(np.pi / 4), 0])          # local z -> world x
+    xq = np.array([np.cos(np.pi / 4), -np.sin(np.pi / 4), 0, 0])         # local z -> world y
+    q = np.zeros((3, 7))
+    # bars parked far apart, then the crossing ones placed: bar A along x, bar B along y above it
+    for b in range(3):
+        q[b] = [3.0 * b, 0, 5.0 + 1.0 * b, *yq]
+    placed = set()
+    for (A, B) in pairs:
+        if A not in placed:
+            placed.add(A)
+        ax = q[A, :3]
+        # A's axis: along x if its quaternion is yq, along y if xq
+        alongx = np.allclose(q[A, 3:], yq)
+        if alongx:
+            q[B, :3] = ax + np.array([s0, -s0, 2 * R_CYL - pen]); q[B, 3:] = xq
+        else:
+            q[B, :3] = ax + np.array([s0, s0, 2 * R_CYL - pen]); q[B, 3:] = yq
+        placed.add(B)
+    return q.reshape(21)
+
+
+@pytest.mark.parametrize("pairs,dropped", [([(0, 1)], 0), ([(0, 2)], 0), ([(1, 2)], 0), ([(0, 1), (1, 2)], 1)])
+def test_the_roving_slot_carries_a_pairs_fourth_contact(oracle, pairs, dropped):
+    """A bar crossing deeper than 6.2 mm where both bars carry a b-cylinder touches four times (r-r, r-b, b-r, b-b); mujoco keeps every
+    geom pair.  The pair's three fixed slots (lanes 6 + 2p, 7 + 2p, 12 + p) take three, lane 15 -- the roving slot, whose bar pair is a
+    run-time value -- the fourth: fp64 row sub-steps equal the oracle's for every pair; with two pairs that deep at once the second pair's
+    fourth contact finds the slot taken and is counted."""
+    import row_emul as RE
+    O = oracle
+    m = O.default_model()
+    P = RE.params_from_oracle_model(m, 1e-10, 60)
+    n = 4
+    pens = np.array([4e-3, 7e-3, 9e-3, 12e-3])   # the first: three contacts only (b-b needs 6.2 mm)
+    q = np.stack([_crossed_bars(pairs, p_) for p_ in pens])
+    rng = np.random.default_rng(0)
+    v = rng.normal(0, 0.05, (n, 18))
+    ctrl = np.full((n, 6), -0.2)
+    trace = np.zeros((n, 24), dtype=np.uint32)
+    q2, v2, _, out = RE.step(P, q, v, ctrl, nsub=3, precision="f64", trace=trace)
+    for i in range(n):
+        d = O.new_data(m)
+        O.arr(d.qpos)[:] = q[i]; O.arr(d.qvel)[:] = v[i]; O.arr(d.ctrl)[:] = ctrl[i]
+        O.lib().tgo_step(O.C.byref(m), O.C.byref(d), 3)
+        qo, vo = O.arr(d.qpos).copy()[None], O.arr(d.qvel).copy()[None]
+        otr = np.ctypeslib.as_array(d.trace)[:3]
+        if dropped == 0 or i == 0:
+            assert rel_env(qfix(q2[i:i + 1], qo) - qo, qo, 1e-3).max() < 1e-8 and rel_env(v2[i:i + 1] - vo, vo, 1e-2).max() < 1e-6, (pairs, i)
+        assert ((trace[i, :3] ^ otr) & 0xffff).max() == 0, (pairs, i, [hex(x) for x in trace[i, :3]], [hex(x) for x in otr])
+        assert bool(trace[i, 0] & 0x8000) == (i > 0)                        # lane 15 is in use exactly where the crossing is deep enough
+    # contacts that found no slot in the last sub-step (the 7 mm crossing has been pushed back above 6.2 mm by then)
+    assert (out[0, 21] == 0) and (out[1, 21] <= dropped) and (out[2:, 21] == dropped).all(), out[:, 21]
+
+
+@pytest.mark.parametrize("pairs", [[(0, 1)], [(1, 2)]])
+def test_the_roving_slot_on_the_heightfield_model(oracle, golden_dir, pairs):
+    """MODEL = 1: lanes 12..14 carry the bars' terrain contacts, so a pair has ONE fixed slot besides the r-cylinders side to side; the roving
+    slot takes the pair's second other contact (a 4 mm crossing: r-r, r-b, b-r), a third (b-b, beyond 6.2 mm) is counted"""
+    import row_emul as RE
+    from tensegrity_rl_amd.vec_env import heights_from_image
+    O = oracle
+    h = heights_from_image(np.load(os.path.join(golden_dir, "terrain_100.npy")))
+    m = O.uneven_model(h)
+    P = RE.params_from_oracle_model(m, 1e-10, 60)
+    pens = np.array([0.5e-3, 4e-3, 9e-3])   # r-r only (the b-cylinders are 3.1 mm inside) / + r-b, b-r / + b-b
+    n = len(pens)
+    q = np.stack([_crossed_bars(pairs, p_) for p_ in pens])
+    rng = np.random.default_rng(0)
+    v = rng.normal(0, 0.05, (n, 18))
+    ctrl = np.full((n, 6), -0.2)
+    trace = np.zeros((n, 24), dtype=np.uint32)
+    # (one sub-step: this model's 1e4 N/m tendons, stretched over the metres between the parked bars, tear the crossing apart at 2 m/s)
+    q2, v2, _, out = RE.step(P, q, v, ctrl, nsub=1, precision="f64", model=1, heights=h, trace=trace)
+    for i in range(n):
+        d = O.new_data(m)
+        O.arr(d.qpos)[:] = q[i]; O.arr(d.qvel)[:] = v[i]; O.arr(d.ctrl)[:] = ctrl[i]
+        O.lib().tgo_step(O.C.byref(m), O.C.byref(d), 1)
+        qo, vo = O.arr(d.qpos).copy()[None], O.arr(d.qvel).copy()[None]
+        otr = np.ctypeslib.as_array(d.trace)[:1]
+        assert ((trace[i, :1] ^ otr) & 0x3fffff).max() == 0, (pairs, i, [hex(x) for x in trace[i, :1]], [hex(x) for x in otr])
+        if i < 2:
+            assert rel_env(qfix(q2[i:i + 1], qo) - qo, qo, 1e-3).max() < 1e-8 and rel_env(v2[i:i + 1] - vo, vo, 1e-2).max() < 1e-6, (pairs, i)
+    assert [bool(t & 0x8000) for t in trace[:, 0]] == [False, True, True]
+    assert list(out[:, 21]) == [0, 0, 1]
