@@ -225,7 +225,9 @@ int tgr_set_state(tgr_handle* h, const double* qpos, const double* qvel, const d
  * [6] lane-sub-steps that left the Newton solver at its iteration cap, [7] lane-sub-steps run (live and settling lanes) */
 int tgr_stats(tgr_handle* h, uint64_t out[8]);
 /* re-key the reset RNG and restart every lane's episode counter, so that reset(seed=s) twice gives the same episode twice; takes
- * effect for subsequent resets (follow it with a full tgr_reset: donor lanes settled under the old key are not re-drawn).
+ * effect for subsequent resets.  On a handle with donor lanes a full tgr_reset (mask = NULL) MUST follow: the donor lanes hold episodes
+ * settled under the old key, and tgr_step returns TGR_ERR_INVALID until they have been settled afresh -- it never hands them out silently.
+ * (The Python VecEnv's seed() therefore only re-keys; the reset() SB3 issues next is the one full reset.)
  * replaces: Env.reset(seed=...) (gym API; the reference's own draws at tensegrity_env.py:460,486 / tr_env.py:730,775,802,831 are unseeded) */
 int tgr_set_seed(tgr_handle* h, uint64_t seed);
 /* tr_env with use_obs_noise: step() returns observation_with_noise and puts the noise-free one into info["real_observation"]
@@ -236,10 +238,16 @@ int tgr_bind_real_observation(tgr_handle* h, void* real_obs_dev);
 /* diagnostic (accuracy classification, tests/gpu_accuracy_report.py): bind a DEVICE buffer uint32 [N][TGR_TRACE_WORDS] (caller-owned, valid
  * until unbound with NULL); every tgr_step of a row-kernel handle then records, per env and sub-step s < frame_skip, word s =
  * contact slots instantiated in the forward pass of that sub-step (bit c < 6: cap c on the floor; 6 + 2p / 7 + 2p: the r-cylinders of bar
- * pair p side to side / any other contact of the pair; 12 + b: bar b's cylinder on the terrain; 16 + c: cap c on a second facet)
- * | (Newton iterations the env itself needed so far this step, mod 256) << 22 | (the solver left this sub-step at its iteration cap) << 30.
+ * pair p side to side / any other contact of the pair; 12 + p (flat floor): a second such other contact of pair p; 12 + b (heightfield):
+ * bar b's cylinder on the terrain; 15: the roving slot -- the next other contact (flat floor: the third, heightfield: the second) of the
+ * first bar pair that has one; 16 + c: cap c on a second facet)
+ * | (Newton iterations the env itself needed so far this step, mod 256) << 22 | (the solver left this sub-step at its iteration cap) << 30
+ * | (its line search stalled at working precision) << 31;
+ * and (heightfield model) word 24 + s = WHICH facets and grid edges those terrain contacts touch, hashed: low 16 bits the caps' facets
+ * ((col * 128 + row) * 2 + triangle of the cell), high 16 bits the grid edges under the bars' cylinders ((col * 128 + row) * 3 + k) -- a
+ * change of facet under a cap leaves the mask of word s unchanged; the CPU checker hashes its own contacts the same way.
  * replaces: reads of env.data.contact / data.solver_iter after mj_step (run.py:154-161 reads data.contact the same way) */
-#define TGR_TRACE_WORDS 24
+#define TGR_TRACE_WORDS 48
 int tgr_bind_substep_trace(tgr_handle* h, uint32_t* trace_dev);
 /* measurement (bench.py's roofline): keep HIP events around the launch of the dominant kernel -- the step kernel over the live rows (with
  * the donor stream) or over all rows (fused launch) -- in a ring of n_slots pairs, recorded on the stream the kernel is launched on;

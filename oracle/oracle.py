@@ -37,7 +37,7 @@ class Model(C.Structure):
 class Contact(C.Structure):
     _fields_ = [("pos", d * 3), ("frame", d * 9), ("dist", d), ("body1", C.c_int), ("body2", C.c_int),
                 ("geom1", C.c_int), ("geom2", C.c_int), ("J", (d * NV) * 6), ("aref", d * 6), ("R", d * 6),
-                ("D", d * 6), ("mu", d), ("force", d * 6), ("zone", C.c_int)]
+                ("D", d * 6), ("mu", d), ("force", d * 6), ("zone", C.c_int), ("feature", C.c_int)]
 
 
 class Data(C.Structure):
@@ -48,7 +48,7 @@ class Data(C.Structure):
                 ("qfrc_actuator", d * NV), ("qfrc_bias", d * NV), ("qfrc_smooth", d * NV), ("qacc_smooth", d * NV),
                 ("qfrc_constraint", d * NV), ("qacc", d * NV), ("ncon", C.c_int), ("con", Contact * MAXCON),
                 ("cfrc_ext", (d * 6) * 4), ("solver_iter", C.c_int), ("flags", C.c_int), ("act", d * NU), ("act_dot", d * NU),
-                ("trace_n", C.c_int), ("trace", C.c_uint32 * 32)]
+                ("trace_n", C.c_int), ("trace", C.c_uint32 * 32), ("trace_id", C.c_uint32 * 32)]
 
 
 class EnvCfg(C.Structure):

@@ -415,6 +415,7 @@ static void hfield_caps(const tgo_model* m, tgo_data* d) {
     /* the two deepest triangles touched (MuJoCo emits one contact per prism the sphere penetrates; two is what a cap resting
      * in a fold of the terrain needs, and what it gets on the shared diagonal of a flat cell) */
     double bd[2] = {0, 0}, bq[2][3] = {{0, 0, 0}, {0, 0, 0}}; int have = 0;
+    int bf[2] = {0, 0}; /* which facet: (col * 128 + row) * 2 + tri */
     for (int r = r0; r <= r1; r++)
       for (int c = c0; c <= c1; c++) {
         double v[4][3]; /* (c,r) (c,r+1) (c+1,r) (c+1,r+1) */
@@ -428,12 +429,13 @@ static void hfield_caps(const tgo_model* m, tgo_data* d) {
           double dif[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
           double dist = norm3(dif) - rad;
           if (!(dist < 0)) continue;
+          const int fid = (c * 128 + r) * 2 + tri;
           if (have < 1 || dist < bd[0]) {
-            bd[1] = bd[0]; memcpy(bq[1], bq[0], 24);
-            bd[0] = dist; memcpy(bq[0], q, 24);
+            bd[1] = bd[0]; memcpy(bq[1], bq[0], 24); bf[1] = bf[0];
+            bd[0] = dist; memcpy(bq[0], q, 24); bf[0] = fid;
             have = have < 2 ? have + 1 : 2;
           } else if (have < 2 || dist < bd[1]) {
-            bd[1] = dist; memcpy(bq[1], q, 24);
+            bd[1] = dist; memcpy(bq[1], q, 24); bf[1] = fid;
             have = 2;
           }
         }
@@ -446,6 +448,7 @@ static void hfield_caps(const tgo_model* m, tgo_data* d) {
       double pos[3];
       for (int i = 0; i < 3; i++) pos[i] = cw[i] - n[i] * (rad + 0.5 * bd[j]);
       add_contact(d, pos, n, bd[j], -1, k / 2, 0, 1 + 5 * (k / 2) + 1 + (k % 2));
+      d->con[d->ncon - 1].feature = bf[j];
     }
   }
 }
@@ -472,7 +475,7 @@ static void hfield_bars(const tgo_model* m, tgo_data* d) {
     if (r0 < 0) r0 = 0;
     if (c1 > nc - 1) c1 = nc - 1;
     if (r1 > nr - 1) r1 = nr - 1;
-    double best = 0, bpa[3] = {0, 0, 0}, bpb[3] = {0, 0, 0}; int have = 0;
+    double best = 0, bpa[3] = {0, 0, 0}, bpb[3] = {0, 0, 0}; int have = 0, bedge = 0;
     for (int r = r0; r <= r1; r++)
       for (int cc = c0; cc <= c1; cc++) {
         /* edges starting at vertex (cc, r): to (cc+1, r), to (cc, r+1), and the strip diagonal (cc, r+1)-(cc+1, r) */
@@ -492,7 +495,7 @@ static void hfield_bars(const tgo_model* m, tgo_data* d) {
           double pa[3], pb[3], df[3];
           for (int i = 0; i < 3; i++) { pa[i] = c[i] + s_ * a[i]; pb[i] = mid[i] + t_ * ed[i]; df[i] = pa[i] - pb[i]; }
           double dist = norm3(df) - rad;
-          if (dist < 0 && (!have || dist < best)) { have = 1; best = dist; memcpy(bpa, pa, 24); memcpy(bpb, pb, 24); }
+          if (dist < 0 && (!have || dist < best)) { have = 1; best = dist; memcpy(bpa, pa, 24); memcpy(bpb, pb, 24); bedge = (cc * 128 + r) * 3 + k; }
         }
       }
     if (!have) continue;
@@ -503,6 +506,7 @@ static void hfield_bars(const tgo_model* m, tgo_data* d) {
     double pos[3];
     for (int i = 0; i < 3; i++) pos[i] = bpa[i] + m->hf_pos[i] - n[i] * (rad + 0.5 * best);
     add_contact(d, pos, n, best, -1, b, 0, 1 + 5 * b);
+    d->con[d->ncon - 1].feature = bedge;
   }
 }
 
@@ -991,10 +995,27 @@ uint32_t tgo_contact_mask(const tgo_model* m, const tgo_data* d) {
   return mask;
 }
 
+/* which facets / grid edges the heightfield contacts touch, as the row kernels hash them (tgr_row.h, sub-step trace): low 16 bits the caps
+ * (a cap's facets enter symmetrically: which of two is "the first" does not matter), high 16 bits the bars' cylinders */
+static uint32_t mix_id(uint32_t id) { uint32_t x = (id + 1u) * 2654435761u; return x ^ (x >> 15); }
+uint32_t tgo_feature_hash(const tgo_model* m, const tgo_data* d) {
+  if (!m->hf_data) return 0;
+  uint32_t caps = 0, rods = 0;
+  for (int ci = 0; ci < d->ncon; ci++) {
+    const tgo_contact* c = &d->con[ci];
+    if (c->body1 >= 0) continue;
+    const int g = c->geom2 - 1 - 5 * c->body2; /* 0 r-cylinder, 1 cap +z, 2 cap -z */
+    if (g == 0) rods += (uint32_t)(c->body2 + 1) * mix_id((uint32_t)c->feature);
+    else if (g == 1 || g == 2) caps += (uint32_t)(2 * c->body2 + (g - 1) + 1) * mix_id((uint32_t)c->feature);
+  }
+  return ((caps ^ (caps >> 16)) & 0xffffu) | (((rods ^ (rods >> 16)) & 0xffffu) << 16);
+}
+
 void tgo_step(const tgo_model* m, tgo_data* d, int nstep) {
   d->trace_n = 0;
   for (int i = 0; i < nstep; i++) {
     tgo_forward(m, d);
+    if (d->trace_n < TGO_TRACE) d->trace_id[d->trace_n] = tgo_feature_hash(m, d);
     if (d->trace_n < TGO_TRACE)
       d->trace[d->trace_n++] = tgo_contact_mask(m, d) | ((uint32_t)(d->solver_iter & 0xff) << 22) | ((d->flags & TGO_FLAG_NOCONV) ? 1u << 30 : 0u);
     implicitfast_advance(m, d);

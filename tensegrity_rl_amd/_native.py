@@ -13,7 +13,7 @@ PRECISION = {"f32": 0, "f64": 1, "float32": 0, "float64": 1}
 KERNEL_LAYOUT = {"auto": 0, "block": 1, "row": 2}
 INFO_K, AUX_K, NQ, NV, NU = 26, 56, 21, 18, 6
 AUX_RING, RING_CAPACITY = 23, 32
-TRACE_WORDS = 24
+TRACE_WORDS = 48
 INFO_TENDON_LENGTH, INFO_BAR_CONTACT = 16, 25
 INFO_KEYS = ["reward_forward", "reward_ctrl", "reward_survive", "x_position", "y_position", "psi",
              "distance_from_origin", "x_velocity", "y_velocity", "forward_reward"]

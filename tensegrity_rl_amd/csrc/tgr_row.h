@@ -34,6 +34,16 @@ template <typename S> struct RParams {
   S hf_rx, hf_ry, hf_ez, hf_x0, hf_y0, hf_z0, hf_dx, hf_dy;
   int hf_nrow, hf_ncol;
   const float* hf;
+  // derived on the host (derive()): reciprocals and products of the above.  Formed inside the kernel they are divisions of uniform values --
+  // an IEEE division is ten instructions, twice that in fp64 -- repeated wherever the compiler does not keep the quotient in an SGPR
+  S imass, iIxx, iIzz, iimp_width, iimp_mid, iimp_1m, mu, rf0, dmf, dtf, ihf_dx, ihf_dy;
+  void derive() {
+    imass = S(1) / mass; iIxx = S(1) / Ixx; iIzz = S(1) / Izz;
+    iimp_width = S(1) / imp_width; iimp_mid = S(1) / imp_mid; iimp_1m = S(1) / (S(1) - imp_mid);
+    mu = f0 / std::sqrt(impratio); rf0 = S(1) / (f0 * f0);
+    dmf = S(1) / (mu * mu * (S(1) + mu * mu)); dtf = impratio / (f0 * f0);
+    ihf_dx = S(1) / hf_dx; ihf_dy = S(1) / hf_dy;
+  }
 };
 
 // static model tables (3prism_jonathan_steady_side.xml:82-87,127-164; ..._uneven_ground.xml:76-81,122-158)
@@ -74,7 +84,15 @@ template <typename K, typename F> struct RLag {
   F n_unconv;   // sub-steps this environment left the solver at the iteration cap
   F n_own;      // Newton iterations this environment itself still needed (the wavefront runs until its slowest one is done)
   int n_it, n_ls;
+#ifdef TGR_ROW_STAMPS  // diagnostic build: shader cycles per phase of the sub-step (s_memtime), summed over the wavefront's sub-steps
+  unsigned long long stamp[24], t_last;
+#endif
 };
+#if defined(TGR_ROW_STAMPS) && !defined(TGR_ROW_EMUL)
+#define TGR_RSTAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); lag.stamp[i] += _t - lag.t_last; lag.t_last = _t; } while (0)
+#else
+#define TGR_RSTAMP(i) ((void)0)
+#endif
 template <typename F> struct Rot { V3<F> ex, ey, ez; };
 
 template <typename F> TGR_RDEV void normalize_quat(F* q) {
@@ -95,7 +113,7 @@ template <typename F> TGR_RDEV Rot<F> quat_rot(const F* q) {
 template <typename F> TGR_RDEV V3<F> rot_apply(const Rot<F>& R, V3<F> l) { return l.x * R.ex + (l.y * R.ey + l.z * R.ez); }
 template <typename F> TGR_RDEV V3<F> rot_applyT(const Rot<F>& R, V3<F> g) { return mk<F>(dot(R.ex, g), dot(R.ey, g), dot(R.ez, g)); }
 template <typename F, typename S> TGR_RDEV V3<F> inv_inertia(const RParams<S>& P, V3<F> z, V3<F> t) {
-  const S iI = S(1) / P.Ixx, d = S(1) / P.Izz - iI;
+  const S iI = P.iIxx, d = P.iIzz - iI;
   return iI * t + (d * dot(z, t)) * z;
 }
 template <typename F, typename S> TGR_RDEV V3<F> inertia_mul(const RParams<S>& P, V3<F> z, V3<F> a) {
@@ -191,8 +209,8 @@ template <typename F> struct RContact {
   B active;
 };
 template <typename F, typename S> TGR_RDEV F impedance(const RParams<S>& P, F dist) {
-  F xx = abs_(dist) * (S(1) / P.imp_width);
-  F y = sel(xx >= S(1), F(S(1)), sel(xx <= P.imp_mid, xx * xx * (S(1) / P.imp_mid), S(1) - (S(1) - xx) * (S(1) - xx) * (S(1) / (S(1) - P.imp_mid))));
+  F xx = abs_(dist) * P.iimp_width;
+  F y = sel(xx >= S(1), F(S(1)), sel(xx <= P.imp_mid, xx * xx * P.iimp_mid, S(1) - (S(1) - xx) * (S(1) - xx) * P.iimp_1m));
   return P.imp0 + y * (P.imp1 - P.imp0);
 }
 template <typename F, typename S> TGR_RDEV void contact_params(const RParams<S>& P, F dist, S nbody, F& c0, F& Dn) {
@@ -210,8 +228,8 @@ template <typename F> struct RCone {
 // cone force and Hessian ("isotropic + rank-1" form) of one contact at jar = (jl, ja); same algebra as tgr_device.h cone_eval
 template <typename F, typename S> TGR_RDEV RCone<F> cone_eval(const RParams<S>& P, const RContact<F>& c, V3<F> jl, V3<F> ja) {
   RCone<F> o;
-  const S mu = P.f0 / std::sqrt(P.impratio);
-  const S rf0 = S(1) / (P.f0 * P.f0);
+  const S mu = P.mu;
+  const S rf0 = P.rf0;
   F Dt = c.Dn * P.impratio;
   F Do = Dt * (P.f3sq * rf0), Dr = Dt * (P.f4sq * rf0);
   F jn = dot(c.n, jl);
@@ -219,15 +237,16 @@ template <typename F, typename S> TGR_RDEV RCone<F> cone_eval(const RParams<S>& 
   F jo = dot(c.n, ja);
   V3<F> jr = ja - jo * c.n;
   F tt = P.f1sq * dot(jt, jt) + P.f3sq * jo * jo + P.f4sq * dot(jr, jr);
-  F Tn = sqrt_(tt);
+  // |T| and 1 / |T| from ONE transcendental (rsq): sqrt followed by rcp of its result is two, one waiting for the other
+  const F rT = rsqrt_(max_(tt, F(S(1e-36))));
+  F Tn = tt * rT;
   F N = mu * jn;
   auto top = (N >= mu * Tn) | !c.active;
   auto bottom = !top & (mu * N + Tn <= S(0));
   auto middle = !top & !bottom;
   V3<F> flB = -((c.Dn * jn) * c.n + Dt * jt);
   V3<F> faB = -((Do * jo) * c.n + Dr * jr);
-  F rT = rcp_(max_(Tn, F(S(1e-30))));
-  F Dm = c.Dn * (S(1) / (mu * mu * (S(1) + mu * mu)));
+  F Dm = c.Dn * P.dmf;
   F NT = N - mu * Tn;
   F fn = -Dm * NT * mu;
   V3<F> wl = P.f1sq * jt;
@@ -448,12 +467,12 @@ template <typename F, typename I, typename S> TGR_RDEV F hf_at(const RParams<S>&
 // cells under it.  dist >= 0: no contact.  Same rules as tgr_device.h hfield_cap; coordinates are taken relative to the corner of the first
 // cell before they become F, so that a robot 30 m from the origin resolves its contact distance as well as one at the origin.
 template <typename K, typename F, typename SK, typename S>
-TGR_RDEV void hfield_cap(const RParams<SK>& PK, const RParams<S>& P, F rad, V3<K> pk, F* dist_out, V3<F>* n_out) {
+TGR_RDEV void hfield_cap(const RParams<SK>& PK, const RParams<S>& P, F rad, V3<K> pk, F* dist_out, V3<F>* n_out, typename LaneTraits<F>::I* id_out) {
   typedef typename LaneTraits<F>::I I;
   const F zero = F(S(0));
   const F px = cvt<F>(pk.x), py = cvt<F>(pk.y), pz = cvt<F>(pk.z);
   const auto inb = !((px < -P.hf_rx - rad) | (px > P.hf_rx + rad) | (py < -P.hf_ry - rad) | (py > P.hf_ry + rad) | (pz > P.hf_ez + rad));
-  const S idx = S(1) / P.hf_dx, idy = S(1) / P.hf_dy;
+  const S idx = P.ihf_dx, idy = P.ihf_dy;
   I c0 = to_int(floor_((px - rad + P.hf_rx) * idx)), c1 = to_int(floor_((px + rad + P.hf_rx) * idx));
   I r0 = to_int(floor_((py - rad + P.hf_ry) * idy)), r1 = to_int(floor_((py + rad + P.hf_ry) * idy));
   c0 = clampi(c0, 0, P.hf_ncol - 2); r0 = clampi(r0, 0, P.hf_nrow - 2);   // (an out-of-range cap is masked by inb)
@@ -467,6 +486,7 @@ TGR_RDEV void hfield_cap(const RParams<SK>& PK, const RParams<S>& P, F rad, V3<K
   const V3<F> p = mk<F>(cvt<F>(pxk), cvt<F>(pyk), pz);
   F bd0 = F(S(1)), bd1 = F(S(1));
   V3<F> bq0 = p, bq1 = p;
+  I bi0 = I(0), bi1 = I(0);  // WHICH facets: (col * 128 + row) * 2 + tri (for the sub-step trace)
   for (int j = 0; j < 2; j++)
     for (int i = 0; i < 2; i++) {
       const auto cell = inb & ((c0 + i) <= c1) & ((r0 + j) <= r1);
@@ -496,6 +516,8 @@ TGR_RDEV void hfield_cap(const RParams<SK>& PK, const RParams<S>& P, F rad, V3<K
         const auto first = hit & (dist < bd0), second = hit & !(dist < bd0) & (dist < bd1);
         bd1 = sel(first, bd0, sel(second, dist, bd1)); bq1 = sel3(first, bq0, sel3(second, q, bq1));
         bd0 = sel(first, dist, bd0); bq0 = sel3(first, q, bq0);
+        const I fid = ((c0 + i) * 128 + (r0 + j)) * 2 + tri;
+        bi1 = sel(first, bi0, sel(second, fid, bi1)); bi0 = sel(first, fid, bi0);
       }
     }
   {
@@ -510,6 +532,7 @@ TGR_RDEV void hfield_cap(const RParams<SK>& PK, const RParams<S>& P, F rad, V3<K
     const auto ok = (bd1 < S(0)) & (nn > S(1e-12));
     dist_out[1] = sel(ok, bd1, F(S(1))); n_out[1] = sel3(ok, rcp_(max_(nn, F(S(1e-30)))) * df, mk<F>(zero, zero, F(S(1))));
   }
+  id_out[0] = bi0; id_out[1] = bi1;
 }
 // closest points of two segments c + s a (|s| <= ha) and c2 + t a2 (|t| <= hb), unit axes (Ericson 5.1.9), select form
 template <typename F, typename S> TGR_RDEV void seg_seg_closest(V3<F> ca, V3<F> aa, S ha, V3<F> cb, V3<F> ab, F hb, F& s_out, F& t_out) {
@@ -531,7 +554,8 @@ template <typename F, typename S> TGR_RDEV void seg_seg_closest(V3<F> ca, V3<F> 
 // edges l and l + 16) and the winner comes back through the row: 2 tests per lane instead of 27.  Returns dist (>= 0: none), normal,
 // arm -- replicated.  (azk: the bar's axis in K.)
 template <typename K, typename F, typename SK, typename S>
-TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, V3<K> azk, V3<F>& n_out, V3<F>& arm_out, V3<F>& off_out) {
+TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, V3<K> azk, V3<F>& n_out, V3<F>& arm_out, V3<F>& off_out,
+                          typename LaneTraits<F>::I& id_out) {
   typedef typename LaneTraits<F>::I I;
   const S rad = P.rcyl_r, H = P.bar_half, near = S(2e-5);
   const V3<F> az = cvt3<F>(azk);
@@ -541,7 +565,7 @@ TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, 
   const F ex = abs_(az.x) * H + rad, ey = abs_(az.y) * H + rad;
   auto inb = !((cx + ex < -P.hf_rx) | (cx - ex > P.hf_rx) | (cy + ey < -P.hf_ry) | (cy - ey > P.hf_ry));
   inb = inb & !(cz - abs_(az.z) * H - rad > P.hf_ez);
-  const S idx = S(1) / P.hf_dx, idy = S(1) / P.hf_dy;
+  const S idx = P.ihf_dx, idy = P.ihf_dy;
   I c0 = to_int(floor_((cx - ex + P.hf_rx) * idx)), c1 = to_int(floor_((cx + ex + P.hf_rx) * idx));
   I r0 = to_int(floor_((cy - ey + P.hf_ry) * idy)), r1 = to_int(floor_((cy + ey + P.hf_ry) * idy));
   c0 = clampi(c0, 0, P.hf_ncol - 2); r0 = clampi(r0, 0, P.hf_nrow - 2);
@@ -583,6 +607,7 @@ TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, 
   const I tw = sel(some, to_int(tmin), I(0));
   const I j = (tw * 57) >> 9, rem = tw - j * 9, i = (rem * 43) >> 7, k = rem - i * 3;
   const I ia = i, ja = j + sel(k == 2, I(1), I(0)), ib = i + sel(k == 1, I(0), I(1)), jb = j + sel(k == 1, I(1), I(0));
+  id_out = ((c0 + i) * 128 + (r0 + j)) * 3 + k;  // WHICH grid edge: the k-th edge starting at vertex (col, row) (for the sub-step trace)
   const V3<K> vaK = mk<K>(cvt<K>(from_int(ia, F())) * PK.hf_dx, cvt<K>(from_int(ja, F())) * PK.hf_dy, cvt<K>(hf_at<F>(P, c0 + ia, r0 + ja)));
   const V3<K> vbK = mk<K>(cvt<K>(from_int(ib, F())) * PK.hf_dx, cvt<K>(from_int(jb, F())) * PK.hf_dy, cvt<K>(hf_at<F>(P, c0 + ib, r0 + jb)));
   const V3<K> cK = mk<K>(ck.x - x0, ck.y - y0, ck.z);
@@ -715,13 +740,14 @@ template <typename F> TGR_RDEV RLSlot<F> ls_make(const RContact<F>& c, V3<F> jl,
   return s;
 }
 template <typename F, typename S> TGR_RDEV void ls_slot(const RParams<S>& P, const RLSlot<F>& s, F alpha, F& d1, F& d2) {
-  const S mu = P.f0 / std::sqrt(P.impratio);
-  F Dtf = s.Dn * (P.impratio / (P.f0 * P.f0));
+  const S mu = P.mu;
+  F Dtf = s.Dn * P.dtf;
   F jn = s.jn0 + alpha * s.qn, jo = s.jo0 + alpha * s.qo;
   F jl2 = s.A0 + alpha * (S(2) * s.A1 + alpha * s.A2), ja2 = s.B0 + alpha * (S(2) * s.B1 + alpha * s.B2);
   F jlq = s.A1 + alpha * s.A2, jaq = s.B1 + alpha * s.B2;
   F tt = P.f1sq * (jl2 - jn * jn) + P.f3sq * jo * jo + P.f4sq * (ja2 - jo * jo);
-  F Tn = sqrt_(max_(tt, F(S(0))));
+  const F rT = rsqrt_(max_(tt, F(S(1e-36))));
+  F Tn = max_(tt, F(S(0))) * rT;
   F wq = P.f1sq * (jlq - jn * s.qn) + P.f3sq * jo * s.qo + P.f4sq * (jaq - jo * s.qo);
   F qtt = P.f1sq * (s.A2 - s.qn * s.qn) + P.f3sq * s.qo * s.qo + P.f4sq * (s.B2 - s.qo * s.qo);
   F N = mu * jn;
@@ -729,8 +755,7 @@ template <typename F, typename S> TGR_RDEV void ls_slot(const RParams<S>& P, con
   auto bottom = !top & (mu * N + Tn <= S(0));
   F b1 = s.Dn * jn * s.qn + Dtf * wq;
   F b2 = s.Dn * s.qn * s.qn + Dtf * qtt;
-  F rT = rcp_(max_(Tn, F(S(1e-30))));
-  F Dm = s.Dn * (S(1) / (mu * mu * (S(1) + mu * mu)));
+  F Dm = s.Dn * P.dmf;
   F NT = N - mu * Tn;
   F gq = mu * (s.qn - wq * rT);
   F kap = -Dm * mu * NT * rT;
@@ -773,14 +798,15 @@ template <typename F> TGR_RDEV void row_acc(F* R, V3<F> wl, V3<F> wa, V3<F> arm,
 template <typename F> struct RHess { F D[3][6]; F O10[6], O20[6], O21[6]; };
 template <typename F> TGR_RDEV F* hess_off(RHess<F>& H, int a, int b) { return (a == 0 && b == 1) ? H.O10 : ((a == 0 && b == 2) ? H.O20 : H.O21); }
 
+// am / cm: the wavefront's ballots of (slot active) and (slot in the middle zone of its cone), taken once per iteration
 template <int MODEL, int PAGE, int C, typename F>
-TGR_RDEV void hess_add_slot(RHess<F>& H, const DofC<F>& d, const RContact<F>& c, const RCone<F>& o) {
+TGR_RDEV void hess_add_slot(RHess<F>& H, const DofC<F>& d, const RContact<F>& c, const RCone<F>& o, BMask am, BMask cm) {
   typedef typename LaneTraits<F>::S S;
-  if (!any_slot<C>(c.active)) return;
+  if (!slot_in<C>(am)) return;
   SlotB<F> s;
   s.n = bcast3<C>(c.n); s.rA = bcast3<C>(c.rA); s.rB = bcast3<C>(c.rB);
   s.a1 = bcast<C>(o.a1); s.a2 = bcast<C>(o.a2); s.b1 = bcast<C>(o.b1); s.b2 = bcast<C>(o.b2);
-  const bool cone = any_slot<C>(o.cg != S(0));
+  const bool cone = slot_in<C>(cm);
   if (cone) { s.cg = bcast<C>(o.cg); s.cw = bcast<C>(o.cw); s.gl = bcast3<C>(o.gl); s.ga = bcast3<C>(o.ga); s.wl = bcast3<C>(o.wl); s.wa = bcast3<C>(o.wa); }
   constexpr int A = slot_bar_a<MODEL>(PAGE, C), Bb = slot_bar_b<MODEL>(PAGE, C);
   static_assert(Bb >= 0, "slot without a body");
@@ -803,13 +829,13 @@ template <typename F> TGR_RDEV void row_acc_masked(F* R, V3<F> wl, V3<F> wa, V3<
   R[0] = R[0] + m * wl.x; R[1] = R[1] + m * wl.y; R[2] = R[2] + m * wl.z; R[3] = R[3] + m * t.x; R[4] = R[4] + m * t.y; R[5] = R[5] + m * t.z;
 }
 template <typename F, typename I>
-TGR_RDEV void hess_add_roving(RHess<F>& H, const DofC<F>& d, const RContact<F>& c, const RCone<F>& o, I p15) {
+TGR_RDEV void hess_add_roving(RHess<F>& H, const DofC<F>& d, const RContact<F>& c, const RCone<F>& o, I p15, BMask cm) {
   typedef typename LaneTraits<F>::S S;
   constexpr int C = 15;
   SlotB<F> s;
   s.n = bcast3<C>(c.n); s.rA = bcast3<C>(c.rA); s.rB = bcast3<C>(c.rB);
   s.a1 = bcast<C>(o.a1); s.a2 = bcast<C>(o.a2); s.b1 = bcast<C>(o.b1); s.b2 = bcast<C>(o.b2);
-  const bool cone = any_slot<C>(o.cg != S(0));
+  const bool cone = slot_in<C>(cm);
   if (cone) { s.cg = bcast<C>(o.cg); s.cw = bcast<C>(o.cw); s.gl = bcast3<C>(o.gl); s.ga = bcast3<C>(o.ga); s.wl = bcast3<C>(o.wl); s.wa = bcast3<C>(o.wa); }
   V3<F> ulB, uaB, wlB, waB, ulA, uaA, wlA, waA;
   dof_col(d, s.rB, ulB, uaB);
@@ -955,7 +981,8 @@ constexpr int lidx(int i) { return (i % 10) * 16 + i / 10; }
 #endif
 // dbg: optional sub-step trace of this environment (null in production; tgr_bind_substep_trace): word s = contact slots active in sub-step s
 // (bits 0..15 page 0, 16..21 page 1) | (Newton iterations the environment itself needed so far, mod 256) << 22 | (left at the cap or stalled) << 30 | (stalled) << 31
-constexpr int TRACE_WORDS = 24;
+// words TRACE_SUB + s (MODEL 1): which facets / grid edges the terrain contacts of sub-step s touch (see the contact stage)
+constexpr int TRACE_SUB = 24, TRACE_WORDS = 48;
 template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> td; Slab<K> rd; Slab<K> ad; Slab<F> cd; Slab<F> hd; Slab<F> lp; Slab<K> lc; Slab<F> xs; unsigned* dbg; };
 
 #ifndef TGR_IMPLICIT_K
@@ -963,16 +990,31 @@ template <typename K, typename F> struct RMem { Slab<K> kd; Slab<F> fd; Slab<F> 
 #endif
 // `LAST`: what only the last sub-step of a control period records (lagged kinematics, tendon lengths, contact wrench).
 // K / PK: lane and scalar type of the pose, the kinematics, the tendon geometry and the smooth forces; F / P: of the rest.
+// argPK / argP: where the model constants (K and F copies) sit in the kernel's argument block.  TGR_REARG() re-reads them through a fresh
+// pointer at the head of the stages OUTSIDE the Newton loop (and once before it), so that a stage holds only its own constants in SGPRs:
+// 0 spilled SGPRs (196 before: parked in VGPR lanes, fetched back with v_readlane -- 5 % of the instruction stream), 0 spilled VGPRs, 238
+// VGPRs.  Worth +1 % (profiles/round4_ab_sgpr.log) -- and only once every quotient of model constants (1 / mass, 1 / Izz in fp64 ...) came
+// precomputed from the host (RParams::derive): formed in the kernel from re-read values they were IEEE divisions repeated per stage,
+// which made the first attempt 4 % slower.
 template <typename K, typename F, typename SK, typename S, int MODEL, bool LAST>
-TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, F>& M, RLag<K, F>& lag, int sidx = 0) {
+TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> argP, const RMem<K, F>& M, RLag<K, F>& lag, int sidx = 0) {
   typedef typename LaneTraits<F>::I I;
   typedef typename LaneTraits<F>::B B;
+  const RParams<SK>* PKp = argPK.ptr_same();
+  const RParams<S>* Pp = argP.ptr_same();
+#define PK (*PKp)
+#define P (*Pp)
+#ifndef TGR_NO_REARG
+#define TGR_REARG() do { PKp = argPK.ptr(); Pp = argP.ptr(); } while (0)
+#else
+#define TGR_REARG() ((void)0)
+#endif
   const F zero = F(S(0));
   const K kzero = K(SK(0));
   const V3<F> z3 = mk<F>(zero, zero, zero);
   const V3<K> kz3 = mk<K>(kzero, kzero, kzero);
-  const S im = S(1) / P.mass;
-  const SK imk = SK(1) / PK.mass;
+#define im (P.imass)
+#define imk (PK.imass)
   typename LaneTraits<F>::B any1 = typename LaneTraits<F>::B(false);  // MODEL 1: my page-1 slot (a cap's second terrain contact) is active
   RContact<F> c;
   V3<F> jl0, ja0;  // my slot's residual at the unconstrained acceleration: J (a0 + B v) + c0 n
@@ -986,22 +1028,24 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   // lane-sub-steps unconverged at tol 1e-5, everything else together 5 %).  e is small, and J d_ref is folded into the residual once, in K.
   constexpr bool SHIFT = MODEL != 0;
   V3<K> ten_u = kz3, ten_ma = kz3, ten_mb = kz3;
+  TGR_RSTAMP(15);  // (between sub-steps: loop overhead)
   {
     TGR_PHASE(0);
     const Roles<F> Ro = lane_roles<F, MODEL>();
-    // ---- kinematics (replicated): normalised orientation and bar axis of every bar, back into the slabs
-    static_for<3>([&](auto bc) {  // (unrolled: lag.x[b] with a run-time b would put the lagged pose into scratch memory)
-      constexpr int b = decltype(bc)::value;
-      K q[4] = {M.kd.ld(KQ + 4 * b), M.kd.ld(KQ + 4 * b + 1), M.kd.ld(KQ + 4 * b + 2), M.kd.ld(KQ + 4 * b + 3)};
+    // ---- kinematics: normalised orientation and bar axis of every bar, back into the slabs.  Lane b works on bar b (lanes 3.. repeat bar 0)
+    // and stores ITS bar: nobody needs the result in registers -- every later stage reads the slabs
+    {
+      const I bi = sel(Ro.r == 1, I(1), sel(Ro.r == 2, I(2), I(0)));
+      K q[4] = {M.kd.ld(KQ + 4 * bi), M.kd.ld(KQ + 4 * bi + 1), M.kd.ld(KQ + 4 * bi + 2), M.kd.ld(KQ + 4 * bi + 3)};
       normalize_quat(q);
-      for (int i = 0; i < 4; i++) M.kd.st(KQ + 4 * b + i, q[i]);
+      for (int i = 0; i < 4; i++) M.kd.st_rep(KQ + 4 * bi + i, q[i]);
       const V3<K> kz = mk<K>(SK(2) * (q[1] * q[3] + q[0] * q[2]), SK(2) * (q[2] * q[3] - q[0] * q[1]), q[0] * q[0] - q[1] * q[1] - q[2] * q[2] + q[3] * q[3]);
-      st3(M.kd, KEZ + 3 * b, kz);
-      st3(M.fd, FEZ + 3 * b, cvt3<F>(kz));
-      if (LAST) {
-        for (int i = 0; i < 4; i++) M.lp.st(lidx(LPQ + 4 * b + i), cvt<F>(q[i]));
-      }
-    });
+      st3_rep(M.kd, KEZ + 3 * bi, kz);
+      st3_rep(M.fd, FEZ + 3 * bi, cvt3<F>(kz));
+    }
+    if (LAST) {  // the lagged orientations (what the observation is built from), and
+      for (int i = 0; i < 12; i++) M.lp.st(lidx(LPQ + i), cvt<F>(M.kd.ld(KQ + i)));
+    }
     if (LAST) {  // the lagged bar positions, relative to their centre (K); the centre itself stays in K (lc)
       const V3<K> x0 = ld3(M.kd, KX), x1 = ld3(M.kd, KX + 3), x2 = ld3(M.kd, KX + 6);
       const V3<K> com = SK(1.0 / 3.0) * ((x0 + x1) + x2);
@@ -1011,7 +1055,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       M.lp.st(lidx(LPX + 3), l1.x); M.lp.st(lidx(LPX + 4), l1.y); M.lp.st(lidx(LPX + 5), l1.z);
       M.lp.st(lidx(LPX + 6), l2.x); M.lp.st(lidx(LPX + 7), l2.y); M.lp.st(lidx(LPX + 8), l2.z);
     }
-    TGR_PHASE(1);
+    TGR_RSTAMP(0);
+    TGR_PHASE(1); TGR_REARG();
     // ---- tendons (tendon role): geometry, force, Jacobian pieces; smooth wrench per bar (replicated).  Each lane reads the pose of
     // ITS two bars straight from the slab (a lane-dependent LDS address), so no lane ever holds all three bars
     {
@@ -1087,7 +1132,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
         TGR_SCHED();
       });
     }
-    TGR_PHASE(2);
+    TGR_RSTAMP(1);
+    TGR_PHASE(2); TGR_REARG();
     // ---- contacts (slot role)
     I jb = sel(Ro.sB >= 0, Ro.sB, I(0)), ja_ = sel(Ro.sA >= 0, Ro.sA, I(0));  // my slot's bars (a missing one reads bar 0 and is masked)
     auto hasA = Ro.sA >= 0;
@@ -1105,16 +1151,18 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
         // heightfield floor (uneven xml:48,56): caps get their two deepest triangles (page 0 / page 1), a bar's r-cylinder one edge
         const V3<K> org = mk<K>(K(PK.hf_x0), K(PK.hf_y0), K(PK.hf_z0));
         F d2[2]; V3<F> n2[2];
+        I fid[2], eid = I(0);
         V3<F> rn, rarm, roff = z3;
-        hfield_cap<K, F>(PK, P, capr, (kxc + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc) - org, d2, n2);
+        hfield_cap<K, F>(PK, P, capr, (kxc + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc) - org, d2, n2, fid);
         F rd = F(S(1));
         rn = mk<F>(zero, zero, F(S(1))); rarm = z3;
         static_for<3>([&](auto bc_) {  // (every bar's cylinder: the whole row works on it, lane 12 + b keeps the outcome)
           constexpr int b = decltype(bc_)::value;
           V3<F> bn, barm, boff;
-          const F bd = hfield_rod_row<K, F>(PK, P, ld3(M.kd, KX + 3 * b) - org, ld3(M.kd, KEZ + 3 * b), bn, barm, boff);
+          I be;
+          const F bd = hfield_rod_row<K, F>(PK, P, ld3(M.kd, KX + 3 * b) - org, ld3(M.kd, KEZ + 3 * b), bn, barm, boff, be);
           const auto mine = Ro.r == 12 + b;
-          rd = sel(mine, bd, rd); rn = sel3(mine, bn, rn); rarm = sel3(mine, barm, rarm); roff = sel3(mine, boff, roff);
+          rd = sel(mine, bd, rd); rn = sel3(mine, bn, rn); rarm = sel3(mine, barm, rarm); roff = sel3(mine, boff, roff); eid = sel(mine, be, eid);
         });
         const auto hit0 = sel(Ro.is_cap, d2[0] < S(0), sel(Ro.is_rod, rd < S(0), false));
         dist = sel(hit0, sel(Ro.is_cap, d2[0], rd), zero);
@@ -1135,6 +1183,17 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
         const V3<F> ylB1 = cvt3<F>(ld3(M.kd, KL0 + 3 * jb)) + P.B * ld3(M.fd, FV + 3 * jb), yaB1 = cvt3<F>(ld3(M.kd, KA0 + 3 * jb)) + P.B * ld3(M.fd, FW + 3 * jb);
         st3(M.cd, C_SLAB + CJL0, (ylB1 + cross(yaB1, rB1)) + cc1 * n2[1]); st3(M.cd, C_SLAB + CJA0, yaB1);
         any1 = hit1;
+        if (M.dbg && sidx < TRACE_SUB) {
+          // trace, second word of the sub-step: WHICH facets / grid edges the terrain contacts touch (the mask of active slots does not
+          // say) -- low 16 bits: the caps (a cap's two facets enter symmetrically), high 16 bits: the bars' cylinders; the oracle hashes its
+          // own contacts the same way (tgo_feature_hash)
+          auto mix = [&](I id) { return xshr(wmul(id + 1, I((int)2654435761u)), 15); };
+          const I zi = I(0);
+          const I capterm = sel(Ro.is_cap, wmul(Ro.r + 1, wadd(sel(hit0, mix(fid[0]), zi), sel(hit1, mix(fid[1]), zi))), zi);
+          const I rodterm = sel(Ro.is_rod & hit0, wmul(Ro.r - 11, mix(eid)), zi);
+          const I caps = rowsum_w(capterm), rods = rowsum_w(rodterm);
+          M.dbg[TRACE_SUB + sidx] = ((unsigned)lane0(xshr(caps, 16)) & 0xffffu) | (((unsigned)lane0(xshr(rods, 16)) & 0xffffu) << 16);
+        }
       } else {
         const K kdist = kxc.z + (cvt<K>(Ro.cap_sign) * PK.bar_half) * kzc.z - (PK.cap_r + cvt<K>(M.fd.ld(FCAPD)));
         dist = cvt<F>(kdist);
@@ -1234,6 +1293,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       ja0 = yaB - yaA;
     }
   }
+  TGR_RSTAMP(2);
   if (LAST) lag.overflow = rowsum(dropped);
   const auto any_contact = rowsum(sel(c.active | any1, F(S(1)), zero)) > S(0);
   // MODEL 1: does any cap of the wavefront rest on two facets?  (uniform; the whole second page is skipped otherwise -- the common case)
@@ -1305,6 +1365,8 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   F bar_force = zero;
   int n_it = 0, n_ls = 0;
   TGR_FENCE();
+  TGR_RSTAMP(3);  // Newton set-up (warm start, slot into the slab)
+  TGR_REARG();
   for (int it = 0;; it++) {
     TGR_PHASE(3);
     const I p15 = to_int(M.xs.ld(XP15));  // (the roving slot's pair; -1: none)
@@ -1332,6 +1394,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       ja1 = ld3(M.cd, C_SLAB + CJA0) + ld3(M.cd, CDAB);
       o1 = cone_eval(P, cs1, jl1, ja1);
     }
+    TGR_RSTAMP(4);  // residual + cone
     TGR_PHASE(4);
     // ---- constraint wrench per bar, gradient (dof role: component r of each bar's residual)
     V3<F> fB = o.fl, tB = cross(cs.rB, o.fl) + o.fa;
@@ -1353,8 +1416,9 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     const V3<F> PfB = mk<F>(pairsum(fB.x), pairsum(fB.y), pairsum(fB.z)), PtB = mk<F>(pairsum(tB.x), pairsum(tB.y), pairsum(tB.z)),
                 PtA = mk<F>(pairsum(tA.x), pairsum(tA.y), pairsum(tA.z));
     const K PkB = pairsum(tauB), PkA = pairsum(tauA);
-    const bool third = !MODEL && any_slots<0x7000u>(cs.active);
-    const bool rove = any_slot<15>(cs.active);
+    const BMask am = ballot_of(cs.active);  // which slots are in use anywhere in the wavefront (once per iteration)
+    const bool third = !MODEL && slots_in<0x7000u>(am);
+    const bool rove = slot_in<15>(am);
     K gn = kzero;  // g^T M^-1 g
     F dn = zero;   // d^T M d: the scale of the forces the gradient is the difference of
     F gd[3];
@@ -1378,7 +1442,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       // M-norm of the residual: force and transverse torque in F, the axial torque from K
       const K gax = PK.Izz * dot(kez, SHIFT ? cvt3<K>(ra) + cvt3<K>(da) : cvt3<K>(da)) - tax;
       const F gz = dot(ezb, ga);
-      gn = gn + cvt<K>(im * dot(gl, gl) + (dot(ga, ga) - gz * gz) * (S(1) / P.Ixx)) + gax * gax * (SK(1) / PK.Izz);
+      gn = gn + cvt<K>(im * dot(gl, gl) + (dot(ga, ga) - gz * gz) * P.iIxx) + gax * gax * PK.iIzz;
       ga = ga + (cvt<F>(gax) - gz) * ezb;  // the direction is solved for the same axial residual the test looks at
       gd[b] = sel(Ro.is_dof, sel(Ro.is_ang, pick_comp(Ro.k, ga), pick_comp(Ro.k, gl)), zero);
     });
@@ -1389,6 +1453,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
 #ifdef TGR_ROW_TRACE
     std::fprintf(stderr, "it %d gn %.3e conv %d\n", it, (double)gn.v[0], (int)conv.v[0]);
 #endif
+    TGR_RSTAMP(5);  // wrench, bar sums, gradient, convergence test
     if (!any_lane(!conv) || it >= P.max_iter) break;
     n_it++;
     lag.n_own = lag.n_own + sel(conv, zero, F(S(1)));
@@ -1404,18 +1469,23 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       H.D[b][0] = lin.x; H.D[b][1] = lin.y; H.D[b][2] = lin.z; H.D[b][3] = ang.x; H.D[b][4] = ang.y; H.D[b][5] = ang.z;
     }
     for (int i = 0; i < 6; i++) { H.O10[i] = zero; H.O20[i] = zero; H.O21[i] = zero; }
-    static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<MODEL, 0, decltype(cc)::value>(H, dc, cs, o); });
-    if (page1) static_for<6>([&](auto cc) { hess_add_slot<MODEL, 1, decltype(cc)::value>(H, dc, cs1, o1); });
-    if (rove) hess_add_roving(H, dc, cs, o, p15);
+    const BMask cm = ballot_of(o.cg != S(0));
+    static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<MODEL, 0, decltype(cc)::value>(H, dc, cs, o, am, cm); });
+    if (page1) {
+      const BMask am1 = ballot_of(cs1.active), cm1 = ballot_of(o1.cg != S(0));
+      static_for<6>([&](auto cc) { hess_add_slot<MODEL, 1, decltype(cc)::value>(H, dc, cs1, o1, am1, cm1); });
+    }
+    if (rove) hess_add_roving(H, dc, cs, o, p15, cm);
     // which bar pairs does any environment of the wavefront couple?  (uniform: lets the factorisation skip zero blocks)
-    bool cp0 = any_slots<MODEL ? 0x00c0u : 0x10c0u>(cs.active), cp1 = any_slots<MODEL ? 0x0300u : 0x2300u>(cs.active),
-         cp2 = any_slots<MODEL ? 0x0c00u : 0x4c00u>(cs.active);
+    bool cp0 = slots_in<MODEL ? 0x00c0u : 0x10c0u>(am), cp1 = slots_in<MODEL ? 0x0300u : 0x2300u>(am), cp2 = slots_in<MODEL ? 0x0c00u : 0x4c00u>(am);
     if (rove) { cp0 = cp0 || any_lane(Ro.is_rove & cs.active & (p15 == 0)); cp1 = cp1 || any_lane(Ro.is_rove & cs.active & (p15 == 1)); cp2 = cp2 || any_lane(Ro.is_rove & cs.active & (p15 == 2)); }
+    TGR_RSTAMP(6);  // Hessian rows
     TGR_PHASE(6);
     // ---- direction p = -H^-1 g
     F pr[3][6], gHg;
     newton_direction(H, gd, pr, gHg, cp0, cp1, cp2);
     const F d0 = sel(conv, zero, -gHg);  // p . g = -g^T H^-1 g
+    TGR_RSTAMP(7);  // direction
     TGR_PHASE(7);
     // ---- line search: Gauss part (replicated), cone part (slot role)
     V3<F> pl[3], pa[3];
@@ -1436,6 +1506,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     if (page1) ls1 = ls_make(cs1, jl1, ja1, plB + cross(paB, cs1.rB), paB);
     conv = conv | !(abs_(d0) >= P.tol * P.tol);  // Newton decrement g^T H^-1 g (<= g^T M^-1 g) below tolerance
     conv = conv | !(d0 < S(0));                  // no descent left at working precision
+    TGR_RSTAMP(8);  // line search set-up
     if (!any_lane(!conv)) break;                 // (the iterate stays where the wrench above was taken)
     TGR_CENSUS(10);
     F alpha = sel(conv, zero, F(S(1))), lo = zero, hi = F(S(-1));
@@ -1464,6 +1535,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
       alpha = sel(go, na, alpha);
       if (!any_lane(!ls_done) || k + 1 >= P.ls_iter) break;
     }
+    TGR_RSTAMP(9);  // line search evaluations
     TGR_CENSUS(11);
     {
       // every trial step pointed uphill although the Newton decrement promises descent: the slope at the iterate is below what the
@@ -1484,9 +1556,11 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     st3(M.cd, CDLA, ld3(M.cd, CDLA) + alpha * plA); st3(M.cd, CDAA, ld3(M.cd, CDAA) + alpha * paA);
     st3(M.cd, CDLB, ld3(M.cd, CDLB) + alpha * plB); st3(M.cd, CDAB, ld3(M.cd, CDAB) + alpha * paB);
     TGR_FENCE();
+    TGR_RSTAMP(10);  // iterate update
     if (!any_lane(!conv)) break;  // (only stalled rows were left: their iterate has not moved, the wrench above is the one of the iterate)
   }
-  TGR_PHASE(8);
+  TGR_RSTAMP(11);  // (leaving the loop)
+  TGR_PHASE(8); TGR_REARG();
   TGR_FENCE();
   if (SHIFT)
     for (int b = 0; b < 3; b++) {  // back to d = d_ref + e: what the next sub-step starts from and what the export calls qacc - a0
@@ -1495,7 +1569,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     }
   lag.n_it += n_it; lag.n_ls += n_ls;
   lag.n_unconv = lag.n_unconv + sel(conv & !stall, zero, F(S(1)));
-  if (M.dbg && sidx < TRACE_WORDS) {  // (every lane of the row stores the same word)
+  if (M.dbg && sidx < TRACE_SUB) {  // (every lane of the row stores the same word)
     unsigned w = row_bits(M.cd.ld(CACT) != S(0));
     if (MODEL) w |= (row_bits(M.cd.ld(C_SLAB + CACT) != S(0)) & 0x3fu) << 16;
     w |= ((unsigned)(int)lane0(lag.n_own) & 0xffu) << 22;
@@ -1521,11 +1595,12 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
   // W: the arithmetic of this stage.  F for the flat-floor model; K for the uneven-ground model, whose nine tendons carry 1e4 N/m and
   // 1e3 N s/m (uneven xml:38): accelerations of 1e3 m/s^2 that cancel to the few m/s^2 the robot really does -- in F that cancellation left
   // 1e-4 m/s^2 of rounding in every sub-step, 0.4 % of tr_env env-steps outside the 1e-4 bound on qvel with no contact flip to blame.
+  TGR_RSTAMP(12);  // trace, last sub-step read-outs
   constexpr bool WK = (MODEL != 0) && TGR_IMPLICIT_K;
   typedef typename std::conditional<WK, K, F>::type W;
   typedef typename std::conditional<WK, SK, S>::type SW;
   const RParams<SW>& PW = pick_params<WK>(PK, P);
-  const SW imw = SW(1) / PW.mass;
+  const SW imw = PW.imass;
   const W wzero = W(SW(0));
   const V3<W> wz3 = mk<W>(wzero, wzero, wzero);
   V3<W> yl[3], ya[3];    // the damping correction
@@ -1535,7 +1610,7 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     auto accel = [&](I bar, V3<W>& al_, V3<W>& aa_) {
       const V3<K> kz = ld3(M.kd, KEZ + 3 * bar);
       const V3<K> kf = cvt3<K>(ld3(M.fd, FFCA + 3 * bar));
-      const V3<K> yak = (SK(1) / PK.Ixx) * kf + (M.kd.ld(KTAX + bar) * (SK(1) / PK.Izz) - dot(kz, kf) * (SK(1) / PK.Ixx)) * kz;
+      const V3<K> yak = PK.iIxx * kf + (M.kd.ld(KTAX + bar) * PK.iIzz - dot(kz, kf) * PK.iIxx) * kz;
       if (WK) al_ = cvt3<W>(ld3(M.kd, KL0 + 3 * bar) + imk * cvt3<K>(ld3(M.fd, FFCL + 3 * bar)));
       else al_ = cvt3<W>(cvt3<F>(ld3(M.kd, KL0 + 3 * bar)) + im * ld3(M.fd, FFCL + 3 * bar));
       aa_ = cvt3<W>(ld3(M.kd, KA0 + 3 * bar) + yak);
@@ -1597,19 +1672,22 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     }
     (void)wz3;
   }
-  TGR_PHASE(9);
-  // ---- advance: v += h a ; x += h v ; q <- exp(h w / 2) * q   (world-frame w: left multiplication)
-  for (int b = 0; b < 3; b++) {
+  TGR_RSTAMP(13);  // implicitfast
+  TGR_PHASE(9); TGR_REARG();
+  // ---- advance: v += h a ; x += h v ; q <- exp(h w / 2) * q   (world-frame w: left multiplication).  Lane b advances bar b (lanes 3..
+  // repeat bar 0) and stores it: a third of the instructions of doing all three bars on every lane, most of them fp64
+  {
+    const Roles<F> Ro = lane_roles<F, MODEL>();
+    const I bi = sel(Ro.r == 1, I(1), sel(Ro.r == 2, I(2), I(0)));
     // acceleration = unconstrained (K) + by the constraint wrench (force and transverse torque from the F sums, axial torque from K) + damping
-    const V3<K> kz = ld3(M.kd, KEZ + 3 * b);
-    const V3<K> kf = cvt3<K>(ld3(M.fd, FFCA + 3 * b));
-    const V3<K> yak = (SK(1) / PK.Ixx) * kf + (M.kd.ld(KTAX + b) * (SK(1) / PK.Izz) - dot(kz, kf) * (SK(1) / PK.Ixx)) * kz;
-    const V3<K> vk = cvt3<K>(ld3(M.fd, FV + 3 * b)) + PK.h * (WK ? (ld3(M.kd, KL0 + 3 * b) + imk * cvt3<K>(ld3(M.fd, FFCL + 3 * b))) + cvt3<K>(yl[b])
-                                                                        : ld3(M.kd, KL0 + 3 * b) + cvt3<K>(cvt3<W>(im * ld3(M.fd, FFCL + 3 * b)) + yl[b]));
-    const V3<K> wk = cvt3<K>(ld3(M.fd, FW + 3 * b)) + PK.h * ((ld3(M.kd, KA0 + 3 * b) + yak) + cvt3<K>(ya[b]));
-    st3(M.fd, FV + 3 * b, cvt3<F>(vk));
-    st3(M.fd, FW + 3 * b, cvt3<F>(wk));
-    st3(M.kd, KX + 3 * b, ld3(M.kd, KX + 3 * b) + PK.h * vk);
+    const V3<K> kz = ld3(M.kd, KEZ + 3 * bi);
+    const V3<K> kf = cvt3<K>(ld3(M.fd, FFCA + 3 * bi));
+    const V3<K> yak = PK.iIxx * kf + (M.kd.ld(KTAX + bi) * PK.iIzz - dot(kz, kf) * PK.iIxx) * kz;
+    const V3<W> ylb = pick_bar(bi, yl), yab = pick_bar(bi, ya);
+    const V3<K> vk = cvt3<K>(ld3(M.fd, FV + 3 * bi)) + PK.h * (WK ? (ld3(M.kd, KL0 + 3 * bi) + imk * cvt3<K>(ld3(M.fd, FFCL + 3 * bi))) + cvt3<K>(ylb)
+                                                                       : ld3(M.kd, KL0 + 3 * bi) + cvt3<K>(cvt3<W>(im * ld3(M.fd, FFCL + 3 * bi)) + ylb));
+    const V3<K> wk = cvt3<K>(ld3(M.fd, FW + 3 * bi)) + PK.h * ((ld3(M.kd, KA0 + 3 * bi) + yak) + cvt3<K>(yab));
+    const V3<K> xk = ld3(M.kd, KX + 3 * bi) + PK.h * vk;
     const V3<K> w = wk;
     const SK hh = SK(0.5) * PK.h;
     const K x2 = (hh * hh) * dot(w, w);
@@ -1618,19 +1696,28 @@ TGR_RDEV void substep(const RParams<SK>& PK, const RParams<S>& P, const RMem<K, 
     const K cs = SK(1) + x2 * (SK(-0.5) + x2 * (SK(1.0 / 24) + x2 * (SK(-1.0 / 720) + x2 * (SK(1.0 / 40320) + x2 * (SK(-1.0 / 3628800) + x2 * SK(1.0 / 479001600))))));
     const K k = hh * sinc;
     const K rw = cs, rx = k * w.x, ry = k * w.y, rz = k * w.z;
-    const K q[4] = {M.kd.ld(KQ + 4 * b), M.kd.ld(KQ + 4 * b + 1), M.kd.ld(KQ + 4 * b + 2), M.kd.ld(KQ + 4 * b + 3)};  // (normalised at the start)
-    M.kd.st(KQ + 4 * b, rw * q[0] - rx * q[1] - ry * q[2] - rz * q[3]);
-    M.kd.st(KQ + 4 * b + 1, rw * q[1] + rx * q[0] + ry * q[3] - rz * q[2]);
-    M.kd.st(KQ + 4 * b + 2, rw * q[2] - rx * q[3] + ry * q[0] + rz * q[1]);
-    M.kd.st(KQ + 4 * b + 3, rw * q[3] + rx * q[2] - ry * q[1] + rz * q[0]);
-  }
-  if (MODEL) {
-    for (int a = 0; a < 6; a++) {
-      // (in K: the actuator gain is 15000 N per unit of activation, and twenty fp32 roundings of the activation are 1e-3 N)
-      const K ac = M.kd.ld(KACT + a);
-      M.kd.st(KACT + a, ac + PK.h * (cvt<K>(clamp_(M.fd.ld(FCTRL + a), F(P.ctrl_lo), F(P.ctrl_hi))) - ac) * PK.act_itau);
+    const K q[4] = {M.kd.ld(KQ + 4 * bi), M.kd.ld(KQ + 4 * bi + 1), M.kd.ld(KQ + 4 * bi + 2), M.kd.ld(KQ + 4 * bi + 3)};  // (normalised at the start)
+    TGR_SCHED();  // (every read of the old state is above, every store below: lanes 3.. write bar 0's words a second time)
+    st3_rep(M.fd, FV + 3 * bi, cvt3<F>(vk));
+    st3_rep(M.fd, FW + 3 * bi, cvt3<F>(wk));
+    st3_rep(M.kd, KX + 3 * bi, xk);
+    M.kd.st_rep(KQ + 4 * bi, rw * q[0] - rx * q[1] - ry * q[2] - rz * q[3]);
+    M.kd.st_rep(KQ + 4 * bi + 1, rw * q[1] + rx * q[0] + ry * q[3] - rz * q[2]);
+    M.kd.st_rep(KQ + 4 * bi + 2, rw * q[2] - rx * q[3] + ry * q[0] + rz * q[1]);
+    M.kd.st_rep(KQ + 4 * bi + 3, rw * q[3] + rx * q[2] - ry * q[1] + rz * q[0]);
+    if (MODEL) {
+      // actuator a on lane a (in K: the actuator gain is 15000 N per unit of activation, and twenty fp32 roundings of the activation are 1e-3 N)
+      const I ai = sel(Ro.r < 6, Ro.r, I(0));
+      const K ac = M.kd.ld(KACT + ai);
+      M.kd.st_rep(KACT + ai, ac + PK.h * (cvt<K>(clamp_(M.fd.ld(FCTRL + ai), F(P.ctrl_lo), F(P.ctrl_hi))) - ac) * PK.act_itau);
     }
   }
+  TGR_RSTAMP(14);  // advance
+#undef PK
+#undef P
+#undef im
+#undef imk
+#undef TGR_REARG
 }
 }  // namespace row
 }  // namespace tgr

@@ -845,6 +845,17 @@ template <int MODEL> constexpr int k_slab() { return MODEL ? row::K_SLAB : row::
 #endif
 
 template <typename T, typename TK> struct RowArgs { row::RParams<T> P; row::RParams<TK> PK; };
+// the ONE argument of the row kernels: its members' byte offsets in the kernarg segment are what the kernels re-read their arguments by
+// (row::kernarg_again: nothing loaded at kernel entry is held in SGPRs across the sub-steps)
+template <typename T, typename TK> struct RowKArgs { KArgs<T> k; RowArgs<T, TK> ra; };
+template <typename T, typename TK> TGR_DEV row::ArgRef<row::RParams<T>> arg_P() {
+  typedef RowKArgs<T, TK> A; typedef RowArgs<T, TK> R;
+  return row::ArgRef<row::RParams<T>>{(unsigned)(__builtin_offsetof(A, ra) + __builtin_offsetof(R, P))};
+}
+template <typename T, typename TK> TGR_DEV row::ArgRef<row::RParams<TK>> arg_PK() {
+  typedef RowKArgs<T, TK> A; typedef RowArgs<T, TK> R;
+  return row::ArgRef<row::RParams<TK>>{(unsigned)(__builtin_offsetof(A, ra) + __builtin_offsetof(R, PK))};
+}
 
 // the row's state slabs in shared memory (tgr_row.h RMem): written and read by the 16 lanes of the row alone, so no barrier guards them
 template <typename T, typename TK, int MODEL> struct RowShared {
@@ -959,12 +970,19 @@ template <typename T, typename TK> TGR_DEV void row_store_pose(const row::RMem<T
 template <typename T, typename TK> TGR_DEV void row_lag_init(row::RLag<TK, T>& rl) {
   // (cfrc_absmax, cfrc_clip_sq, bar_contact, overflow are assigned by the last sub-step, not accumulated: nothing to initialise)
   rl.n_unconv = T(0); rl.n_own = T(0); rl.n_it = 0; rl.n_ls = 0;
+#ifdef TGR_ROW_STAMPS
+  for (int i = 0; i < 24; i++) rl.stamp[i] = 0ull;
+  rl.t_last = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 #ifdef TGR_WAVE_TIMES  // development aid: start / end time, iterations of every wavefront of the last step launch
 __device__ unsigned long long g_wave_times[4 * 16384];
 #endif
-template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 * row_envs<T, MODEL>()), (TGR_ROW_WAVES(T, MODEL))) void step_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
+template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 * row_envs<T, MODEL>()), (TGR_ROW_WAVES(T, MODEL))) void step_kernel_row(RowKArgs<T, TK> args) {
+  typedef RowKArgs<T, TK> RowKArgsT;
+  const KArgs<T>& k = args.k;
+  const RowArgs<T, TK>& ra = args.ra;
   constexpr int ROW_ENVS = row_envs<T, MODEL>();
 #ifdef TGR_WAVE_TIMES
   const unsigned long long wt0 = wall_clock64();
@@ -1033,8 +1051,14 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
     }
     row::store_role_consts<TK, T, TK, MODEL>(ra.PK, M.rd);
 #pragma unroll 1
-    for (int s = 0; s + 1 < nsub; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, M, rl, s);
-    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, M, rl, nsub - 1);
+    for (int s = 0; s + 1 < nsub; s++) row::substep<TK, T, TK, T, MODEL, false>(arg_PK<T, TK>(), arg_P<T, TK>(), M, rl, s);
+    row::substep<TK, T, TK, T, MODEL, true>(arg_PK<T, TK>(), arg_P<T, TK>(), M, rl, nsub - 1);
+#ifdef TGR_ROW_STAMPS
+    if ((threadIdx.x & 63u) == 0 && live) {  // live-row wavefronts only: phase cycles, and the wavefront count in slot 23
+      for (int i = 0; i < 16; i++) atomicAdd(&k.counters[8 + i], rl.stamp[i]);
+      atomicAdd(&k.counters[8 + 23], 1ull);
+    }
+#endif
   }
   // Who this row is gets worked out a second time, from laundered thread and block numbers: carried through the twenty sub-steps in
   // registers it was spilled (a dozen dwords per lane: 6 MB of scratch stores per launch), recomputed it is ten instructions.
@@ -1043,6 +1067,11 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   asm volatile("" : "+v"(tx2));
   asm volatile("" : "+s"(bx2));
   {
+    // ... and so are the kernel's arguments: k is read AGAIN from the kernarg segment through a pointer the compiler cannot connect with the
+    // loads at the top of the kernel.  Held in SGPRs across the sub-steps for the sake of this epilogue, the two dozen pointers and the env
+    // configuration of KArgs were most of ~200 spilled SGPRs -- parked in VGPR lanes and fetched back with v_readlane (5 % of the
+    // instruction stream, and four VGPRs of a budget that has none to spare).
+    const KArgs<T>& k = *row::kernarg_again<KArgs<T>>((unsigned)__builtin_offsetof(RowKArgsT, k));
     const int r = (int)(tx2 & 15u), slot = (int)(tx2 >> 4);
     const int lb = (int)((bx2 & ~63u) | ((bx2 & 7u) << 3) | ((bx2 >> 3) & 7u));
     const int gid = k.lane_base + lb * ROW_ENVS + slot;
@@ -1115,69 +1144,114 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   }
 }
 
-// reset_model() in one go, row layout: one row per entry of list[] (tgr_reset, and live envs that found no ready donor)
-template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 * row_envs<T, MODEL>()), (TGR_ROW_WAVES(T, MODEL))) void settle_kernel_row(KArgs<T> k, RowArgs<T, TK> ra) {
+// reset_model() in one go, row layout: one row per entry of list[] (tgr_reset, and live envs that found no ready donor).
+// Nothing of an environment's bookkeeping lives in registers across the twenty sub-steps of a settle period: who the row is gets worked out
+// again after them (as in step_kernel_row), and what reset_model() carries from period to period -- heading deque, _step_num, reset_psi,
+// way-point, the lagged centre -- goes through the env's own words in global memory, which the reset rewrites anyway.  (Carried in
+// registers through the 50 x 20 sub-steps it cost 111 spilled VGPRs, 324 B of scratch per lane.)
+template <typename T> struct SettleRow { int e, klane, episode; bool valid; unsigned long long key; };
+template <typename T> TGR_DEV SettleRow<T> settle_row_of(const KArgs<T>& k, int li, int count) {
+  SettleRow<T> w;
+  w.valid = li < count;
+  const int idx = w.valid ? li : count - 1;
+  w.e = k.list[idx];
+  // reset streams: a live env that found its stream episode not settled yet settles it here itself -- same (class key, episode), same state
+  const int sep = k.list_ep ? k.list_ep[idx] : -1;
+  w.klane = sep >= 0 ? k.n + (w.e / k.E.stream_envs) * k.E.stream_donors : w.e;  // the lane whose key the episode is drawn under
+  w.episode = sep >= 0 ? sep : k.ist[I_EPISODE * k.m + w.e];
+  w.key = lane_key(k.E, k.n, w.klane);
+  return w;
+}
+template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 * row_envs<T, MODEL>()), (TGR_ROW_WAVES(T, MODEL))) void settle_kernel_row(RowKArgs<T, TK> args) {
+  const KArgs<T>& k = args.k;
+  const RowArgs<T, TK>& ra = args.ra;
   constexpr int ROW_ENVS = row_envs<T, MODEL>();
   __shared__ RowShared<T, TK, MODEL> sh;
-  const int r = (int)(threadIdx.x & 15u);
-  const int slot = (int)(threadIdx.x >> 4);
   const int count = *k.list_count;
   if (blockIdx.x * ROW_ENVS >= count) return;
-  const int li = blockIdx.x * ROW_ENVS + slot;
-  const bool valid = li < count;
-  if (!__any(valid)) return;  // (no barrier follows in this kernel)
-  const int e = k.list[valid ? li : count - 1];
-  const int n = k.n, m = k.m;
-  const EnvCfg<T>& E = k.E;
-  const Params<T>& P = k.P;
-  // reset streams: a live env that found its stream episode not settled yet settles it here itself -- same (class key, episode), same state
-  const int sep = k.list_ep ? k.list_ep[valid ? li : count - 1] : -1;
-  const int klane = sep >= 0 ? n + (e / E.stream_envs) * E.stream_donors : e;  // the lane whose key the episode is drawn under
-  const int episode = sep >= 0 ? sep : k.ist[I_EPISODE * m + e];
-  const unsigned long long key = lane_key(E, n, klane);
-  Sim<T> S;
-  init_episode(E, key, (unsigned long long)(unsigned)episode, S, (double*)(sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16)));
-  const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
-  row_import<T, TK, MODEL>(S, M);
-  RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
-  ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
-  int step_num = 0;
-  const int total = settle_total(E);
-  row::store_role_consts<TK, T, TK, MODEL>(ra.PK, M.rd);
+  if (!__any((int)(blockIdx.x * ROW_ENVS + (threadIdx.x >> 4)) < count)) return;  // (no barrier follows in this kernel)
+  const int total = settle_total(k.E);
+  {
+    const int r = (int)(threadIdx.x & 15u), slot = (int)(threadIdx.x >> 4);
+    const SettleRow<T> w = settle_row_of(k, blockIdx.x * ROW_ENVS + slot, count);
+    Sim<T> S;
+    init_episode(k.E, w.key, (unsigned long long)(unsigned)w.episode, S, (double*)(sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16)));
+    const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
+    row_import<T, TK, MODEL>(S, M);
+    row::store_role_consts<TK, T, TK, MODEL>(ra.PK, M.rd);
+    if (w.valid && r == 0) {  // what the periods below read back
+      k.ist[I_STEPNUM * k.m + w.e] = 0;
+      k.st[F_RESETPSI * k.m + w.e] = T(0);
+      aux_st(k, HP_XYLAG, F_XYLAG, w.e, 0.0); aux_st(k, HP_XYLAG + 1, F_XYLAG + 1, w.e, 0.0);
+    }
+  }
   row::RLag<TK, T> rl;
   row_lag_init<T, TK>(rl);
-  Lag<T> lag;
-  T reset_psi = T(0);
-  ModeState<T> ms = load_modes(k, e);
-  double xy_prev[2] = {0.0, 0.0};
-  const bool w0 = valid && r == 0;
 #pragma unroll 1
   for (int st = 0; st < total; st++) {
+    {
+      const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, (int)(threadIdx.x >> 4), (int)(threadIdx.x & 15u));
 #pragma unroll 1
-    for (int s = 0; s + 1 < E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(ra.PK, ra.P, M, rl);
-    row::substep<TK, T, TK, T, MODEL, true>(ra.PK, ra.P, M, rl);
-    row_export<T, TK, MODEL>(M, rl, S, lag);
-    // the heading deque lives in global memory: one lane of the row pushes (the others would push the same value again)
-    if (w0) settle_period_done(P, E, lag, st, ring, step_num, reset_psi, ms, xy_prev, key, (unsigned long long)(unsigned)episode);
+      for (int s = 0; s + 1 < k.E.frame_skip; s++) row::substep<TK, T, TK, T, MODEL, false>(arg_PK<T, TK>(), arg_P<T, TK>(), M, rl);
+      row::substep<TK, T, TK, T, MODEL, true>(arg_PK<T, TK>(), arg_P<T, TK>(), M, rl);
+    }
+    // the period's bookkeeping (tensegrity_env.py:495-510, tr_env.py:811-866): one lane of the row, through global memory
+    unsigned tx2 = TGR_ROW_ENVS == 4 ? __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : threadIdx.x, bx2 = blockIdx.x;
+    asm volatile("" : "+v"(tx2));
+    asm volatile("" : "+s"(bx2));
+    const int r = (int)(tx2 & 15u), slot = (int)(tx2 >> 4);
+    const SettleRow<T> w = settle_row_of(k, (int)bx2 * ROW_ENVS + slot, *k.list_count);
+    if (w.valid && r == 0) {
+      const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
+      Sim<T> S;
+      Lag<T> lag;
+      row_export<T, TK, MODEL>(M, rl, S, lag);
+      const int m = k.m, e = w.e;
+      RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
+      ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
+      int step_num = k.ist[I_STEPNUM * m + e];
+      T reset_psi = k.st[F_RESETPSI * m + e];
+      ModeState<T> ms = load_modes(k, e);
+      double xy_prev[2] = {aux_ld(k, HP_XYLAG, F_XYLAG, e), aux_ld(k, HP_XYLAG + 1, F_XYLAG + 1, e)};
+      settle_period_done(k.P, k.E, lag, st, ring, step_num, reset_psi, ms, xy_prev, w.key, (unsigned long long)(unsigned)w.episode);
+      k.ist[I_RINGLEN * m + e] = ring.len; k.ist[I_RINGHEAD * m + e] = ring.head;
+      k.ist[I_STEPNUM * m + e] = step_num;
+      k.st[F_RESETPSI * m + e] = reset_psi;
+      store_modes(k, e, ms);
+      aux_st(k, HP_XYLAG, F_XYLAG, e, xy_prev[0]); aux_st(k, HP_XYLAG + 1, F_XYLAG + 1, e, xy_prev[1]);
+    }
   }
-  if (!w0) return;
+  unsigned tx2 = TGR_ROW_ENVS == 4 ? __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : threadIdx.x, bx2 = blockIdx.x;
+  asm volatile("" : "+v"(tx2));
+  asm volatile("" : "+s"(bx2));
+  const int r = (int)(tx2 & 15u), slot = (int)(tx2 >> 4);
+  const SettleRow<T> w = settle_row_of(k, (int)bx2 * ROW_ENVS + slot, *k.list_count);
+  if (!(w.valid && r == 0)) return;
+  const int n = k.n, m = k.m, e = w.e;
+  const row::RMem<TK, T> M = row_mem<T, TK, MODEL>(sh, slot, r);
+  Sim<T> S;
+  Lag<T> lag;
+  row_export<T, TK, MODEL>(M, rl, S, lag);
   V3<T> wb[3];
   store_sim(k.st, m, e, S, lag, wb);
   if (k.hp) row_store_pose<T, TK>(M, k.hp, m, e);
-  store_reset_aux(k, e, lag, reset_psi, step_num, ring);
-  store_modes(k, e, ms);
+  RingRef<T> ring; ring.ring = k.ring; ring.n = m; ring.e = e;
+  ring.len = k.ist[I_RINGLEN * m + e]; ring.head = k.ist[I_RINGHEAD * m + e];
+  const int step_num = k.ist[I_STEPNUM * m + e];
+  store_reset_aux(k, e, lag, k.st[F_RESETPSI * m + e], step_num, ring);
+  ModeState<T> ms = load_modes(k, e);
   ms.step_num = step_num;
-  k.ist[I_SRC * m + e] = klane;
-  k.ist[I_SRCEP * m + e] = episode;
-  if (sep < 0) k.ist[I_EPISODE * m + e] = episode + 1;  // (a stream episode does not advance the env's own counter of explicit resets)
+  k.ist[I_SRC * m + e] = w.klane;
+  k.ist[I_SRCEP * m + e] = w.episode;
+  if (w.klane == e) k.ist[I_EPISODE * m + e] = w.episode + 1;  // (a stream episode does not advance the env's own counter of explicit resets)
   k.ist[I_PHASE * m + e] = e < n ? PH_LIVE : PH_READY;
   if (k.async && e >= n) { k.dready[e] = k.launch_idx; k.consumed[e] = 0; k.dcmd[e] = 0ull; k.dapplied[e] = 0; }  // (full reset: the streams are idle)
   atomicAdd(&k.counters[1], 1ull);
   if (lag.overflow) atomicAdd(&k.counters[0], (unsigned long long)lag.overflow);
-  const int D = E.obs_dim;
+  const int D = k.E.obs_dim;
   T* orow = sh.cd + slot * (row::C_SLAB * row::n_pages<MODEL>() * 16);
-  make_obs(P, E, S, lag, wb, ms, orow);
-  if (E.use_obs_noise) apply_obs_noise<T, true>(E, key, (unsigned)episode, 0, orow, orow + 64);
+  make_obs(k.P, k.E, S, lag, wb, ms, orow);
+  if (k.E.use_obs_noise) apply_obs_noise<T, true>(k.E, w.key, (unsigned)w.episode, 0, orow, orow + 64);
   T* op = e < n ? (k.obs_reset ? k.obs_reset + (size_t)e * D : nullptr) : k.dobs + (size_t)(e - n) * D;
   if (op)
     for (int i = 0; i < D; i++) op[i] = orow[i];
@@ -1806,6 +1880,7 @@ template <typename T> static void params_to_row(const Params<T>& P, const tgr_co
   R.rtol = T(c.solver_rel_tolerance > 0 ? c.solver_rel_tolerance : (c.solver_rel_tolerance < 0 ? 0.0 : (f32 ? (c.model_kind ? 5e-6 : 2e-5) : 0.0)));
   R.max_iter = c.solver_iterations > 0 ? c.solver_iterations : (f32 ? 16 : 40);
   R.ls_iter = f32 ? 6 : 50;
+  R.derive();
 }
 template <typename T> static void fill_row_args(const tgr_handle* h, const KArgs<T>& k, RowArgs<T, double>& ra) {
   params_to_row<T>(k.P, h->cfg, ra.P);
@@ -1977,6 +2052,14 @@ extern "C" int tgr_kernel_times_ms(tgr_handle* h, float* out_ms, int n) {
 extern "C" int tgr_stats(tgr_handle* h, uint64_t out[8]) {
   if (!h || !out) return TGR_ERR_INVALID;
   unsigned long long tmp[8];
+#ifdef TGR_ROW_STAMPS
+  { unsigned long long t2[160]; (void)hipDeviceSynchronize(); (void)hipMemcpy(t2, h->counters, sizeof(t2), hipMemcpyDeviceToHost);
+    const char* nm[16] = {"kinematics", "tendons", "contacts", "newton set-up", "residual+cone", "wrench+sums+gradient", "hessian", "direction", "ls set-up", "ls evals",
+                          "iterate update", "loop exit", "read-outs", "implicitfast", "advance", "between"};
+    double tot = 0; for (int i = 0; i < 16; i++) tot += (double)t2[8 + i];
+    printf("row stamps: %llu live wavefront-steps, %.0f cycles each\n", t2[8 + 23], tot / (double)(t2[8 + 23] ? t2[8 + 23] : 1));
+    for (int i = 0; i < 16; i++) printf("  %-22s %6.2f %%  %9.0f cycles per wavefront-step\n", nm[i], 100.0 * (double)t2[8 + i] / tot, (double)t2[8 + i] / (double)(t2[8 + 23] ? t2[8 + 23] : 1)); }
+#endif
 #ifdef TGR_STAMPS
   { unsigned long long t2[160]; (void)hipDeviceSynchronize(); (void)hipMemcpy(t2, h->counters, sizeof(t2), hipMemcpyDeviceToHost);
     for (int w = 0; w < 4; w++) { printf("wave %d Mcycles:", w); for (int i = 0; i < 32; i++) printf(" %6llu", t2[8 + w * 32 + i] / 1000000ull); printf("\n"); } }
@@ -1992,10 +2075,10 @@ extern "C" int tgr_stats(tgr_handle* h, uint64_t out[8]) {
 template <typename T> static void launch_settle_row(const tgr_handle* h, int cnt, hipStream_t s, const KArgs<T>& k, const RowArgs<T, double>& ra) {
   if (h->cfg.model_kind) {
     constexpr int NE = row_envs<T, 1>();
-    hipLaunchKernelGGL((settle_kernel_row<T, double, 1>), dim3((cnt + NE - 1) / NE), dim3(16 * NE), 0, s, k, ra);
+    hipLaunchKernelGGL((settle_kernel_row<T, double, 1>), dim3((cnt + NE - 1) / NE), dim3(16 * NE), 0, s, RowKArgs<T, double>{k, ra});
   } else {
     constexpr int NE = row_envs<T, 0>();
-    hipLaunchKernelGGL((settle_kernel_row<T, double, 0>), dim3((cnt + NE - 1) / NE), dim3(16 * NE), 0, s, k, ra);
+    hipLaunchKernelGGL((settle_kernel_row<T, double, 0>), dim3((cnt + NE - 1) / NE), dim3(16 * NE), 0, s, RowKArgs<T, double>{k, ra});
   }
 }
 
@@ -2103,10 +2186,10 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
     auto launch_rows = [&](const KArgs<T>& kk, int lanes, hipStream_t st) {
       if (h->cfg.model_kind) {
         constexpr int NE = row_envs<T, 1>();
-        hipLaunchKernelGGL((step_kernel_row<T, double, 1>), dim3((((lanes + NE - 1) / NE + 63) / 64) * 64), dim3(16 * NE), 0, st, kk, ra);
+        hipLaunchKernelGGL((step_kernel_row<T, double, 1>), dim3((((lanes + NE - 1) / NE + 63) / 64) * 64), dim3(16 * NE), 0, st, RowKArgs<T, double>{kk, ra});
       } else {
         constexpr int NE = row_envs<T, 0>();
-        hipLaunchKernelGGL((step_kernel_row<T, double, 0>), dim3((((lanes + NE - 1) / NE + 63) / 64) * 64), dim3(16 * NE), 0, st, kk, ra);
+        hipLaunchKernelGGL((step_kernel_row<T, double, 0>), dim3((((lanes + NE - 1) / NE + 63) / 64) * 64), dim3(16 * NE), 0, st, RowKArgs<T, double>{kk, ra});
       }
     };
     if (h->async) {

@@ -49,6 +49,26 @@ template <> struct LaneTraits<float> { typedef float S; typedef int I; typedef b
 template <> struct LaneTraits<double> { typedef double S; typedef int I; typedef bool B; };
 
 TGR_RDEV int lane_id() { return (int)(threadIdx.x & 15u); }
+// A kernel's argument block read AGAIN: a pointer into the kernarg segment (constant address space: scalar loads) that the compiler cannot
+// connect with earlier loads of the same arguments, so nothing loaded before this point is kept alive for the sake of what follows.
+// ArgRef<A>: "the A at this byte offset of the kernarg segment"; every ptr() is a fresh, unconnected pointer.  The row kernels take their
+// model constants through it once per STAGE of the sub-step: loaded at kernel entry and held across the Newton loop they were ~200 spilled
+// SGPRs -- parked in VGPR lanes, fetched back with v_readlane (5 % of the instruction stream).
+template <typename A> TGR_RDEV const A* kernarg_again(unsigned byte_offset) {
+  typedef const __attribute__((address_space(4))) char* P4;
+  P4 p = (P4)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return (const A*)(p + byte_offset);
+}
+template <typename A> struct ArgRef {
+  unsigned off;
+  TGR_RDEV const A* ptr() const { return kernarg_again<A>(off); }
+  // the same block WITHOUT cutting the connection to earlier loads (the compiler may keep what it has loaded)
+  TGR_RDEV const A* ptr_same() const {
+    typedef const __attribute__((address_space(4))) char* P4;
+    return (const A*)((P4)__builtin_amdgcn_kernarg_segment_ptr() + off);
+  }
+};
 template <typename T> TGR_RDEV T sel(bool c, T a, T b) { return c ? a : b; }
 TGR_RDEV bool any_lane(bool c) { return __any(c) != 0; }  // over the wavefront: a superset of the row, only ever used to skip work
 TGR_RDEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -61,6 +81,16 @@ TGR_RDEV float floor_(float x) { return floorf(x); }
 TGR_RDEV double floor_(double x) { return floor(x); }
 template <typename T> TGR_RDEV int to_int(T x) { return (int)x; }
 template <typename T> TGR_RDEV T from_int(int x, T) { return (T)x; }
+// |x|, max, min, clamp as the machine has them (a source modifier, v_max / v_min / v_med3) -- the generic select forms further down cost a
+// compare and a v_cndmask each (a tenth of the row kernels' instruction stream was v_cndmask).  Same values except for NaN operands.
+TGR_RDEV float abs_(float x) { return __builtin_fabsf(x); }
+TGR_RDEV double abs_(double x) { return __builtin_fabs(x); }
+TGR_RDEV float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+TGR_RDEV double max_(double a, double b) { return __builtin_fmax(a, b); }
+TGR_RDEV float min_(float a, float b) { return __builtin_fminf(a, b); }
+TGR_RDEV double min_(double a, double b) { return __builtin_fmin(a, b); }
+TGR_RDEV float clamp_(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
+TGR_RDEV double clamp_(double x, double lo, double hi) { return __builtin_fmin(__builtin_fmax(x, lo), hi); }
 
 template <int CTRL> TGR_RDEV int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
 template <int CTRL> TGR_RDEV float dpp_(float x) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, x))); }
@@ -99,13 +129,33 @@ TGR_RDEV unsigned row_bits(bool flag) {
   return (unsigned)((__ballot(flag) >> (l & 48u)) & 0xffffull);
 }
 template <typename T> TGR_RDEV T lane0(T x) { return x; }
+// the flags of the whole wavefront taken ONCE (one v_cmp), then tested slot by slot with scalar instructions: any_slot<K>(flag) in a chain of
+// fifteen slots re-issued the compare every time (the ballot is convergent: the compiler does not merge them across the branches between)
+typedef unsigned long long BMask;
+TGR_RDEV BMask ballot_of(bool flag) { return __ballot(flag); }
+template <int K> TGR_RDEV bool slot_in(BMask m) { return (m & (0x0001000100010001ull << K)) != 0ull; }
+template <unsigned MASK> TGR_RDEV bool slots_in(BMask m) { return (m & (0x0001000100010001ull * (unsigned long long)MASK)) != 0ull; }
 // ... or the flag of any of the slots in MASK (bit K = slot K)
 template <unsigned MASK> TGR_RDEV bool any_slots(bool flag) { return (__ballot(flag) & (0x0001000100010001ull * (unsigned long long)MASK)) != 0ull; }
 template <typename To, typename From> TGR_RDEV To cvt(From x) { return (To)x; }
+// wrapping 32-bit integer arithmetic on lane values (the sub-step trace hashes facet / edge identities with it): multiply, add,
+// x ^ (x >>> s), and the row sum of such values
+TGR_RDEV int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+TGR_RDEV int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+TGR_RDEV int xshr(int x, int s) { return (int)((unsigned)x ^ ((unsigned)x >> s)); }
+TGR_RDEV int rowsum_w(int x) {
+  x = wadd(x, dpp_<0x128>(x)); x = wadd(x, dpp_<0x124>(x)); x = wadd(x, dpp_<0x122>(x)); x = wadd(x, dpp_<0x121>(x));
+  return x;
+}
 TGR_RDEV float gather_f(const float* base, int idx) { return base[idx]; }
 TGR_RDEV int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 #else
 // ------------------------------------------------------------------ host emulation: a lane value is the 16 scalars of a row
+template <typename A> struct ArgRef {  // (host emulation: a plain pointer)
+  const A* p;
+  const A* ptr() const { return p; }
+  const A* ptr_same() const { return p; }
+};
 template <typename T> struct Ln {
   T v[ROW];
   Ln() {}
@@ -192,9 +242,18 @@ template <int K> inline bool any_slot(const Ln<bool>& flag) { return flag.v[K]; 
 template <unsigned MASK> inline bool any_slots(const Ln<bool>& flag) { for (int i = 0; i < ROW; i++) if (((MASK >> i) & 1u) && flag.v[i]) return true; return false; }
 inline unsigned row_bits(const Ln<bool>& f) { unsigned m = 0; for (int i = 0; i < ROW; i++) m |= f.v[i] ? 1u << i : 0u; return m; }
 template <typename T> inline T lane0(const Ln<T>& x) { return x.v[0]; }
+typedef unsigned BMask;
+inline BMask ballot_of(const Ln<bool>& f) { return row_bits(f); }
+template <int K> inline bool slot_in(BMask m) { return ((m >> K) & 1u) != 0u; }
+template <unsigned MASK> inline bool slots_in(BMask m) { return (m & MASK) != 0u; }
 inline Ln<float> gather_f(const float* base, const Ln<int>& idx) { Ln<float> r; for (int i = 0; i < ROW; i++) r.v[i] = base[idx.v[i]]; return r; }
 inline Ln<int> clampi(const Ln<int>& x, int lo, int hi) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = x.v[i] < lo ? lo : (x.v[i] > hi ? hi : x.v[i]); return r; }
 template <typename To, typename T> inline To cvt(const Ln<T>& x) { To r; for (int i = 0; i < ROW; i++) r.v[i] = (decltype(r.v[0] + 0))x.v[i]; return r; }
+inline Ln<int> wmul(const Ln<int>& a, const Ln<int>& b) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = (int)((unsigned)a.v[i] * (unsigned)b.v[i]); return r; }
+inline Ln<int> wmul(const Ln<int>& a, int b) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = (int)((unsigned)a.v[i] * (unsigned)b); return r; }
+inline Ln<int> wadd(const Ln<int>& a, const Ln<int>& b) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = (int)((unsigned)a.v[i] + (unsigned)b.v[i]); return r; }
+inline Ln<int> xshr(const Ln<int>& x, int s) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = (int)((unsigned)x.v[i] ^ ((unsigned)x.v[i] >> s)); return r; }
+inline Ln<int> rowsum_w(const Ln<int>& x) { unsigned t = 0; for (int i = 0; i < ROW; i++) t += (unsigned)x.v[i]; return Ln<int>((int)t); }
 #endif
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1 (bcast<K> needs K as a constant)
@@ -209,9 +268,17 @@ template <typename L> struct Slab {
   L* p; int stride, off;
   TGR_RDEV L ld(int i) const { return p[i * stride + off]; }
   TGR_RDEV void st(int i, L v) const { p[i * stride + off] = v; }
+  // A REPLICATED slab written with a lane-varying index: lane l stores ITS value at ITS index, and whoever reads that index afterwards --
+  // any lane of the row -- sees it.  This is how work on a replicated quantity is dealt out over lanes (lane b advances bar b) instead of
+  // being repeated by all sixteen: the state lives in the slab, not in registers, so nothing has to be broadcast back.  Lanes that share
+  // an index must store the same value.
+  TGR_RDEV void st_rep(int i, L v) const { p[i * stride + off] = v; }
 #ifdef TGR_ROW_EMUL
   // lane-varying index (on the GPU that is the same ld(): every lane computes its own LDS address)
   L ld(const Ln<int>& i) const { L r; for (int l = 0; l < ROW; l++) r.v[l] = p[i.v[l] * stride + off].v[l]; return r; }
+  void st_rep(const Ln<int>& i, L v) const {
+    for (int l = 0; l < ROW; l++) { L b; for (int k = 0; k < ROW; k++) b.v[k] = v.v[l]; p[i.v[l] * stride + off] = b; }
+  }
 #endif
 };
 template <typename L, typename Ix> TGR_RDEV V3<L> ld3(const Slab<L>& s, Ix i);
@@ -237,6 +304,7 @@ template <typename F> TGR_RDEV V3<F> rowsum3(V3<F> a) { return mk<F>(rowsum(a.x)
 template <typename To, typename From> TGR_RDEV V3<To> cvt3(V3<From> a) { return mk<To>(cvt<To>(a.x), cvt<To>(a.y), cvt<To>(a.z)); }
 template <typename L, typename Ix> TGR_RDEV V3<L> ld3(const Slab<L>& s, Ix i) { return mk<L>(s.ld(i), s.ld(i + 1), s.ld(i + 2)); }
 template <typename L> TGR_RDEV void st3(const Slab<L>& s, int i, V3<L> v) { s.st(i, v.x); s.st(i + 1, v.y); s.st(i + 2, v.z); }
+template <typename L, typename Ix> TGR_RDEV void st3_rep(const Slab<L>& s, Ix i, V3<L> v) { s.st_rep(i, v.x); s.st_rep(i + 1, v.y); s.st_rep(i + 2, v.z); }
 
 }  // namespace row
 }  // namespace tgr

@@ -182,7 +182,10 @@ class LazyInfoList(list):
         self._frame, self._extras = frame, extras
 
     def _make(self, i):
-        x = LazyInfo(self._frame, i, self._extras.get(i))
+        # (no frame: info_mode="minimal" -- an empty dict, or what VecEnv semantics add for an env that finished)
+        x = LazyInfo(self._frame, i, self._extras.get(i)) if self._frame is not None else self._extras.get(i, None)
+        if x is None:
+            x = {}
         list.__setitem__(self, i, x)
         return x
 
@@ -359,17 +362,17 @@ class TensegrityVecEnv:
                     if fin.size and self.cfg.auto_reset:
                         rh[fin] = self._h_tobs[fin]
             frame = _InfoFrame(ih.copy(), rh, tr)
-            extras = {}
-            infos = LazyInfoList(n, frame, extras)
         else:
-            infos = [{} for _ in range(n)]
+            frame = None
+        extras = {}
+        infos = LazyInfoList(n, frame, extras)
         idx = np.nonzero(dones)[0]
         if idx.size:
             th = self._h_tobs[idx].astype(np.float64)  # (a copy: the mirror is overwritten by the next step)
             ep = ih[idx, 14:16]
             now = round(time.time() - self._t0, 6)
             for j, i in enumerate(idx):
-                d = extras.setdefault(int(i), {}) if full else infos[i]
+                d = extras.setdefault(int(i), {})
                 d["terminal_observation"] = th[j]
                 d["TimeLimit.truncated"] = bool(trunc_h[i] and not term_h[i])
                 d["episode"] = {"r": float(ep[j, 0]), "l": int(ep[j, 1]), "t": now}

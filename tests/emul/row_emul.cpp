@@ -28,6 +28,7 @@ template <typename T> static void fill_params(const double* p, RParams<T>& P, co
   P.hf_rx = T(p[i++]); P.hf_ry = T(p[i++]); P.hf_ez = T(p[i++]); P.hf_x0 = T(p[i++]); P.hf_y0 = T(p[i++]); P.hf_z0 = T(p[i++]);
   P.hf = hf; P.hf_nrow = nrow; P.hf_ncol = ncol;
   P.hf_dx = T(ncol > 1 ? 2 * p[i - 6] / (ncol - 1) : 1.0); P.hf_dy = T(nrow > 1 ? 2 * p[i - 5] / (nrow - 1) : 1.0);
+  P.derive();
 }
 
 // every lane of the row must hold the same bits of a replicated value
@@ -80,8 +81,10 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
     fd[FCAPD] = F(T(capd ? capd[e] : 0.0));
     for (int i = 0; i < H_SLAB; i++) hd[i] = F(T(0));
     lag.n_it = 0; lag.n_ls = 0; lag.n_unconv = F(T(0)); lag.n_own = F(T(0)); lag.cfrc_absmax = F(T(0)); lag.cfrc_clip_sq = F(T(0)); lag.bar_contact = F(T(0)); lag.overflow = F(T(0));
-    for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(PK, P, M, lag, s);
-    substep<K, F, TK, T, MODEL, true>(PK, P, M, lag, nsub - 1);
+    const ArgRef<RParams<TK>> pkr{&PK};
+    const ArgRef<RParams<T>> pr{&P};
+    for (int s = 0; s + 1 < nsub; s++) substep<K, F, TK, T, MODEL, false>(pkr, pr, M, lag, s);
+    substep<K, F, TK, T, MODEL, true>(pkr, pr, M, lag, nsub - 1);
     for (int b = 0; b < 3; b++) {
       K qq[4] = {kd[KQ + 4 * b], kd[KQ + 4 * b + 1], kd[KQ + 4 * b + 2], kd[KQ + 4 * b + 3]};
       normalize_quat(qq);

@@ -107,7 +107,7 @@ def main():
         print("# rounded | axial spin error rad/s: median / p90 | linear velocity error m/s: median | lane-sub-steps left unconverged in the last sub-step | own iterations so far")
         for bits in [[]] + [[b] for b in range(len(NAMES))] + [list(range(len(NAMES)))]:
             L.tgr_probe_set(sum(1 << b for b in bits))
-            trg = np.zeros((n, 24), dtype=np.uint32)
+            trg = np.zeros((n, 48), dtype=np.uint32)
             q2, v2, _, out = RE.step(P, q, v, ctrl, act=act0, nsub=nsub, precision="f64", trace=trg, **kw)
             d = np.abs(v2 - v3).reshape(n, 3, 6)
             ax = d[:, :, 5].max(axis=1); lin = d[:, :, :3].max(axis=(1, 2))

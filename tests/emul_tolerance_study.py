@@ -59,7 +59,7 @@ def main():
             for name, r32, tol, cap, rt in VARIANTS:
                 P = RE.params_from_oracle_model(ob.env(0).model, tol, cap, 6, rtol=rt)
                 qi = q.astype(np.float32).astype(np.float64) if r32 else q
-                trg = np.zeros((n, 24), dtype=np.uint32)
+                trg = np.zeros((n, 48), dtype=np.uint32)
                 q2, v2, _, out = RE.step(P, qi, v, ctrl, act=act0, nsub=20, precision="mixed", trace=trg, model=int(uneven), heights=H)
                 A = acc[name]
                 A["eq"].append(rel_env(qfix(q2, qo) - qo, qo, 1e-3)); A["ev"].append(rel_env(v2 - vo, vo, 1e-2))

@@ -16,7 +16,13 @@ from gpu_common import oracle_to_gpu_state, qfix, rel_env
 
 
 def oracle_trace(ob):
-    return np.array([np.ctypeslib.as_array(ob.env(i).data.trace)[:20].copy() for i in range(ob.n)], dtype=np.uint32)
+    """[n, 48] like the device's: words 0..19 the contact masks of the twenty sub-steps, words 24..43 the hashed facet / grid-edge identities"""
+    out = np.zeros((ob.n, 48), dtype=np.uint32)
+    for i in range(ob.n):
+        d = ob.env(i).data
+        out[i, :20] = np.ctypeslib.as_array(d.trace)[:20]
+        out[i, 24:44] = np.ctypeslib.as_array(d.trace_id)[:20]
+    return out
 
 
 FLIP_CLASSES = {"cap on the floor": 0x00003f, "bar pair": 0x000fc0, "lanes 12-14 (pair's third slot / bar on the terrain)": 0x007000,
@@ -24,14 +30,21 @@ FLIP_CLASSES = {"cap on the floor": 0x00003f, "bar pair": 0x000fc0, "lanes 12-14
 
 
 def classify(trg, tro):
-    """per env: (flip, capped, first) from the device trace [n, 24] and the oracle trace [n, 20] of the same env-step; first = the bits in
-    which the first differing sub-step differs (0 where there is no flip)"""
-    trg = np.asarray(trg).astype(np.uint32)[:, :20]
-    diff = (trg & 0x3fffff) ^ (np.asarray(tro, dtype=np.uint32)[:, :20] & 0x3fffff)
+    """per env: (flip, capped, first, ident) from the device trace [n, 48] and the oracle trace [n, 48] of the same env-step; first = the bits
+    in which the first differing sub-step differs (0 where there is no flip); ident (heightfield): 0 = the terrain contacts touch the same
+    facets and grid edges in every sub-step, bit 0 = a cap rests on a different facet than the oracle's in some sub-step, bit 1 = a bar's
+    cylinder on a different grid edge -- with the same mask of active slots"""
+    tg_all = np.asarray(trg).astype(np.uint32)
+    to_all = np.asarray(tro, dtype=np.uint32)
+    trg = tg_all[:, :20]
+    diff = (trg & 0x3fffff) ^ (to_all[:, :20] & 0x3fffff)
     flip = (diff != 0).any(axis=1)
     capped = ((trg >> 30) & 1).astype(bool).any(axis=1)
     first = diff[np.arange(diff.shape[0]), np.argmax(diff != 0, axis=1)]
-    return flip, capped, first
+    idd = tg_all[:, 24:44] ^ to_all[:, 24:44]
+    same_mask = diff == 0
+    ident = (((idd & 0xffff) != 0) & same_mask).any(axis=1).astype(np.uint8) | ((((idd >> 16) != 0) & same_mask).any(axis=1).astype(np.uint8) << 1)
+    return flip, capped, first, ident
 
 
 def run_case(kind, uneven, n, steps, img, action="straight", offset=(0.0, 0.0), **kw):
@@ -55,7 +68,7 @@ def run_case(kind, uneven, n, steps, img, action="straight", offset=(0.0, 0.0), 
     env = TensegrityVecEnv(n, kind + "-v0", desired_action=action, precision="f32", auto_reset=False, seed=1234, **gkw, **kw)
     trace = env.bind_substep_trace()
     rng = np.random.default_rng(0)
-    cols = {k: [] for k in ("eq", "ev", "flip", "capped", "first", "obs", "obs_rel", "rew", "rew_rel", "vel", "term", "oterm", "info")}
+    cols = {k: [] for k in ("eq", "ev", "flip", "capped", "first", "ident", "obs", "obs_rel", "rew", "rew_rel", "vel", "term", "oterm", "info")}
     for t in range(steps):
         oracle_to_gpu_state(ob, env)
         a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
@@ -64,8 +77,8 @@ def run_case(kind, uneven, n, steps, img, action="straight", offset=(0.0, 0.0), 
         st = env.get_state()
         q2, v2 = ob.get_state()[:2]
         cols["eq"].append(rel_env(qfix(st["qpos"], q2) - q2, q2, 1e-3)); cols["ev"].append(rel_env(st["qvel"] - v2, v2, 1e-2))
-        f, c, b = classify(trace.cpu().numpy(), oracle_trace(ob))
-        cols["flip"].append(f); cols["capped"].append(c); cols["first"].append(b)
+        f, c, b, idn = classify(trace.cpu().numpy(), oracle_trace(ob))
+        cols["flip"].append(f); cols["capped"].append(c); cols["first"].append(b); cols["ident"].append(idn)
         # the env layer: observation (absolute, and relative to the env's largest velocity entry like qvel: most of an observation IS qvel),
         # reward, x / y velocity (info 7, 8), the ten scalar info entries, terminated
         eo = np.abs(g_obs - o_obs).max(axis=1)
@@ -86,6 +99,8 @@ def summary(r):
     eq, ev, fl, cp, s = r["eq"], r["ev"], r["flip"], r["capped"], r["stats"]
     finite = np.isfinite(eq) & np.isfinite(ev)
     bad = ~finite | (eq >= 1e-4) | (ev >= 1e-4)
+    idn = r["ident"] != 0
+    fl = fl | idn        # a change of facet / grid edge is a flip too: the contact set differs, though not the mask of active slots
     nf = bad & ~fl
     worst = lambda m: float(max(np.nanmax(eq[m]), np.nanmax(ev[m]))) if m.any() else 0.0
     kinds = {name: int(((r["first"][bad & fl] & mask) != 0).sum()) for name, mask in FLIP_CLASSES.items()}
@@ -93,6 +108,7 @@ def summary(r):
     ok = ~fl & finite  # env-steps whose twenty sub-steps instantiated the oracle's contacts: where the env layer is held to its bounds
     return dict(flip_kinds=kinds, n=int(eq.size), qpos_in=float((eq < 1e-4).mean()), qvel_in=float((ev < 1e-4).mean()), both_in=float((~bad).mean()),
                 outliers=int(bad.sum()), flip=int((bad & fl).sum()), capped=int((nf & cp).sum()), neither=int((nf & ~cp).sum()),
+                facet_change=int((bad & idn & ((r["ident"] & 1) != 0) & ~r["flip"]).sum()), edge_change=int((bad & idn & ((r["ident"] & 2) != 0) & ~r["flip"]).sum()),
                 nonfinite=int((~finite).sum()), worst_flip=worst(bad & fl), worst_nonflip=worst(nf), flips_inside_bound=int((~bad & fl).sum()),
                 flips=int(fl.sum()),
                 median_qpos=float(np.median(eq)), median_qvel=float(np.median(ev)), p99_qvel=float(np.percentile(ev, 99)), p999_qvel=float(np.percentile(ev, 99.9)),
@@ -116,10 +132,11 @@ def env_layer_line(tag, u):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if "=" not in a]
+    base_only = "--base-only" in sys.argv
+    args = [a for a in sys.argv[1:] if "=" not in a and not a.startswith("--")]
     kw = {}
     for a in sys.argv[1:]:
-        if "=" in a:
+        if "=" in a and not a.startswith("--"):
             k_, v_ = a.split("=")
             kw[k_] = float(v_) if "." in v_ or "e" in v_ else int(v_)
     n = int(args[0]) if len(args) > 0 else 2048
@@ -130,11 +147,13 @@ if __name__ == "__main__":
     print("# case | qpos<1e-4 | qvel<1e-4 | outliers: flip / capped / neither | worst flip / non-flip | median qvel | p99.9 qvel | wave it/sub-step | unconverged")
     for kind, uneven in (("tensegrity_env", False), ("tr_env", False), ("tensegrity_env", True), ("tr_env", True)):
         u = summary(run_case(kind, uneven, n, steps, img, **kw))
-        print(f"{kind:15s} {'uneven' if uneven else 'flat  '} | {100*u['qpos_in']:.3f} % | {100*u['qvel_in']:.3f} % | {u['outliers']:4d}: {u['flip']:4d} / {u['capped']:3d} / {u['neither']:3d} "
+        print(f"{kind:15s} {'uneven' if uneven else 'flat  '} | {100*u['qpos_in']:.3f} % | {100*u['qvel_in']:.3f} % | {u['outliers']:4d}: {u['flip']:4d} (of them {u['facet_change']} a cap on another facet, {u['edge_change']} a bar on another grid edge, same mask) / {u['capped']:3d} / {u['neither']:3d} "
               f"(non-finite {u['nonfinite']}) | {u['worst_flip']:.1e} / {u['worst_nonflip']:.1e} | {u['median_qvel']:.1e} | {u['p999_qvel']:.1e} | "
               f"{u['wave_iters_per_substep']:.2f} | {100*u['unconverged_fraction']:.3f} %", flush=True)
         if u["flip"]:
             print("#    what flipped first in the outliers that are flips: " + ", ".join(f"{k}: {v}" for k, v in u["flip_kinds"].items() if v), flush=True)
+    if base_only:
+        sys.exit(0)
     print("# env layer of the fp32 handles (observation / reward / x, y velocity / info / terminated against the oracle), every mode, at the origin and 30 m away")
     for kind, action in MODES:
         for off in ((0.0, 0.0), (30.0, -20.0)):

@@ -93,10 +93,16 @@ def test_uneven_ground_fp64_row_substeps_match_the_oracle(oracle, golden_dir, ki
         q, v, c, w, aux = ob.get_state()
         a = rng.uniform(-0.45, 0.15, (n, 6)).astype(np.float32)
         act0 = ob.last_act.copy()
-        q2, v2, act, out = RE.step(P, q, v, _ctrl(kind, c, a), act=act0, nsub=20, precision="f64", model=1, heights=h)
+        trace = np.zeros((n, 48), dtype=np.uint32)
+        q2, v2, act, out = RE.step(P, q, v, _ctrl(kind, c, a), act=act0, nsub=20, precision="f64", model=1, heights=h, trace=trace)
         ob.step(a, auto_reset=False)
         qo, vo = ob.get_state()[:2]
         assert rel_env(qfix(q2, qo) - qo, qo, 1e-3).max() < 1e-8 and rel_env(v2 - vo, vo, 1e-2).max() < 1e-6
+        # the sub-step trace: the same contact slots in every sub-step, touching the same facets and grid edges (hashed identities)
+        otr = np.array([np.ctypeslib.as_array(ob.env(i).data.trace)[:20] for i in range(n)], dtype=np.uint32)
+        oid = np.array([np.ctypeslib.as_array(ob.env(i).data.trace_id)[:20] for i in range(n)], dtype=np.uint32)
+        assert (((trace[:, :20] ^ otr) & 0x3fffff) == 0).all() and (trace[:, 24:44] == oid).all()
+        nid = locals().get("nid", 0) + int((oid != 0).sum())
         assert np.abs(act - ob.last_act).max() < 1e-12          # activations: act += h (ctrl - act) / tau
         for i in range(n):
             dd = ob.env(i).data
@@ -105,6 +111,7 @@ def test_uneven_ground_fp64_row_substeps_match_the_oracle(oracle, golden_dir, ki
             nrod += sum(1 for g in floor if (g - 1) % 5 == 0)
             ntwo += len(floor) - len(set(floor))
     assert ncon > n and nrod > 0 and ntwo > 0   # caps on one and on two facets, and bars across ridges, were all exercised
+    assert nid > 0
     ob.close()
 
 
@@ -175,7 +182,7 @@ def test_the_roving_slot_carries_a_pairs_fourth_contact(oracle, pairs, dropped):
     rng = np.random.default_rng(0)
     v = rng.normal(0, 0.05, (n, 18))
     ctrl = np.full((n, 6), -0.2)
-    trace = np.zeros((n, 24), dtype=np.uint32)
+    trace = np.zeros((n, 48), dtype=np.uint32)
     q2, v2, _, out = RE.step(P, q, v, ctrl, nsub=3, precision="f64", trace=trace)
     for i in range(n):
         d = O.new_data(m)
@@ -207,7 +214,7 @@ def test_the_roving_slot_on_the_heightfield_model(oracle, golden_dir, pairs):
     rng = np.random.default_rng(0)
     v = rng.normal(0, 0.05, (n, 18))
     ctrl = np.full((n, 6), -0.2)
-    trace = np.zeros((n, 24), dtype=np.uint32)
+    trace = np.zeros((n, 48), dtype=np.uint32)
     # (one sub-step: this model's 1e4 N/m tendons, stretched over the metres between the parked bars, tear the crossing apart at 2 m/s)
     q2, v2, _, out = RE.step(P, q, v, ctrl, nsub=1, precision="f64", model=1, heights=h, trace=trace)
     for i in range(n):
