@@ -316,13 +316,22 @@ def main():
                        "envs_per_gpu": n_local, "donor_lanes_per_gpu": donors,
                        "kernel_layout": "row (one env per 16-lane DPP row; fp32 with pose / kinematics / tendon geometry / axial torques in fp64; qpos kept in fp64 in HBM)" if row_layout
                                         else "block (64 envs x 4 wavefronts, LDS columns; fp32 throughout)",
-                       "gather_every": args.gather_every if world > 1 else None,
+                       "gather_every": args.gather_every if (world > 1 or force_dist) else None,
+                       "collective_backend": (dist.get_backend() if (world > 1 or force_dist) else None),
+                       "all_gathers_issued": (gather.collectives if gather is not None else 0),
                        "resets_per_step_rank0": resets / args.steps,
                        "newton_iters_per_substep": stats1["newton_iters_per_substep"],
                        "unconverged_lane_substeps_per_env_step": (stats1["unconverged_lane_substeps"] - stats0["unconverged_lane_substeps"]) / (n_local * args.steps),
                        "unconverged_fraction_of_lane_substeps": (stats1["unconverged_lane_substeps"] - stats0["unconverged_lane_substeps"]) / lane_sub,
                        "dropped_contacts_per_env_step": (stats1["dropped_contacts"] - stats0["dropped_contacts"]) / (n_local * args.steps),
-                       "starved_resets_rank0": stats1["settle_kernel_resets"] - stats0["settle_kernel_resets"]},
+                       "starved_resets_rank0": stats1["settle_kernel_resets"] - stats0["settle_kernel_resets"],
+                       # a donor lane needs 51 launches to settle its first episode: a timed window that starts before ~100 steps sees the
+                       # pool's start-up transient (more Newton iterations per sub-step, ~5 % below the steady state of the 8(d) protocol)
+                       "donor_pool_warm": bool(args.warmup >= 100),
+                       # what "1e-4 relative" means wherever this repo quotes it (tests/gpu_common.py rel_env): per env-step and per env,
+                       # max_i |err_i| / max(max_i |ref_i|, floor) over the 21 qpos (floor 1e-3) or the 18 qvel (floor 1e-2) components
+                       "parity_tolerance": "per env-step: |err|_inf / max(|ref|_inf, floor), floor 1e-3 (qpos) / 1e-2 (qvel); >= 99.9 % of env-steps "
+                                           "inside 1e-4, the rest classified contact flips (tests/test_gpu_parity.py, tests/test_gpu_uneven.py)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": prof["traffic"], "traffic_source": prof["source"],
                          "note": "step kernel: 674 algorithmic B per env-step x envs per launch / mean duration of the launch that steps the live "

@@ -573,7 +573,7 @@ TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, 
   c1 = sel(c1 > c0 + 2, c0 + 2, c1); r1 = sel(r1 > r0 + 2, r0 + 2, r1);
   const K x0 = cvt<K>(from_int(c0, F())) * PK.hf_dx - PK.hf_rx, y0 = cvt<K>(from_int(r0, F())) * PK.hf_dy - PK.hf_ry;
   const V3<F> c = mk<F>(cvt<F>(ck.x - x0), cvt<F>(ck.y - y0), cz);
-  F best = F(S(1)), bt = F(S(99));
+  F dh[2], th[2];  // my two edges: distance (1: none) and index
   const I l = lane_id();
   for (int h = 0; h < 2; h++) {
     // my edge t = (j * 3 + i) * 3 + k of cell (c0 + i, r0 + j): k = 0: (c,r)-(c+1,r), 1: (c,r)-(c,r+1), 2: the strip diagonal (c,r+1)-(c+1,r)
@@ -592,42 +592,142 @@ TGR_RDEV F hfield_rod_row(const RParams<SK>& PK, const RParams<S>& P, V3<K> ck, 
     const V3<F> pa = c + s_ * az, pb = mid + t_ * ed;
     const V3<F> df = pa - pb;
     const F dist = sqrt_(dot(df, df)) - rad;
-    const auto take = cell & (dist < near) & (dist < best);
-    best = sel(take, dist, best); bt = sel(take, from_int(t, F()), bt);
+    const auto take = cell & (dist < near);
+    dh[h] = sel(take, dist, F(S(1))); th[h] = sel(take, from_int(t, F()), F(S(99)));
   }
-  // the deepest edge of the row; of equally deep ones the first in the order of the plain loop
+  // the deepest edge of the row (of equally deep ones the first in the order of the plain loop) -- and the runner-up
+  const auto swap = dh[1] < dh[0];
+  const F best = sel(swap, dh[1], dh[0]), bt = sel(swap, th[1], th[0]), worse = sel(swap, dh[0], dh[1]), wt = sel(swap, th[0], th[1]);
   const F dmin = -rowmax(-best);
   const auto cand = (best == dmin) & (best < near);
   const F tmin = -rowmax(-sel(cand, bt, F(S(99))));
+  const auto mine = bt == tmin;   // (the lane that holds the winner offers its other edge as runner-up)
+  const F dx = sel(mine, worse, best), tx = sel(mine, wt, bt);
+  const F d2 = -rowmax(-dx);
+  const F t2 = -rowmax(-sel((dx == d2) & (dx < near), tx, F(S(99))));
   // The search above is F and only NAMES the edge; whether the bar touches it, how deep, and where, is formed again in K for that one edge
   // (every lane the same): over the metre-sized cells an F distance carries 2e-7 m of rounding, which moved a bar across dist = 0 in one
   // env-step in a thousand (profiles/round3_accuracy_classified.log: most of the uneven model's contact flips were these).  Candidates
   // are therefore kept up to `near` above the surface, and the K distance decides.
+  // WHICH edge, too, is decided in K when the two deepest are closer than F resolves (a bar lying across two ridges): round 4's identity
+  // trace (word 24 + s of the sub-step trace) showed the remaining non-flip outliers of size 0.1 .. 1 on the heightfield to be exactly these
+  // -- the same mask of active slots, another grid edge under the bar (profiles/round4_accuracy_classified_4096x16.log)
   const auto some = tmin < S(27);
-  const I tw = sel(some, to_int(tmin), I(0));
-  const I j = (tw * 57) >> 9, rem = tw - j * 9, i = (rem * 43) >> 7, k = rem - i * 3;
-  const I ia = i, ja = j + sel(k == 2, I(1), I(0)), ib = i + sel(k == 1, I(0), I(1)), jb = j + sel(k == 1, I(1), I(0));
-  id_out = ((c0 + i) * 128 + (r0 + j)) * 3 + k;  // WHICH grid edge: the k-th edge starting at vertex (col, row) (for the sub-step trace)
-  const V3<K> vaK = mk<K>(cvt<K>(from_int(ia, F())) * PK.hf_dx, cvt<K>(from_int(ja, F())) * PK.hf_dy, cvt<K>(hf_at<F>(P, c0 + ia, r0 + ja)));
-  const V3<K> vbK = mk<K>(cvt<K>(from_int(ib, F())) * PK.hf_dx, cvt<K>(from_int(jb, F())) * PK.hf_dy, cvt<K>(hf_at<F>(P, c0 + ib, r0 + jb)));
+  struct EdgeK { K dist, nn; V3<K> df, arm; I id; };
   const V3<K> cK = mk<K>(ck.x - x0, ck.y - y0, ck.z);
-  V3<K> edK = vbK - vaK;
-  const K elK = sqrt_(dot(edK, edK));
-  edK = (K(SK(1)) / elK) * edK;
-  const V3<K> midK = SK(0.5) * (vaK + vbK);
-  K sK, tK;
-  seg_seg_closest(cK, azk, PK.bar_half, midK, edK, SK(0.5) * elK, sK, tK);
-  const V3<K> armK = sK * azk;
-  const V3<K> dfK = (cK + armK) - (midK + tK * edK);
-  const K nnK = sqrt_(dot(dfK, dfK));
-  const K distK = nnK - PK.rcyl_r;
-  const auto ok = some & (distK < SK(0)) & (nnK > SK(1e-12));
-  const F dist = cvt<F>(distK);
-  n_out = sel3(ok, cvt3<F>((K(SK(1)) / max_(nnK, K(SK(1e-30)))) * dfK), mk<F>(zero, zero, F(S(1))));
+  auto evalK = [&](I tw) {
+    EdgeK e;
+    const I j = (tw * 57) >> 9, rem = tw - j * 9, i = (rem * 43) >> 7, k = rem - i * 3;
+    const I ia = i, ja = j + sel(k == 2, I(1), I(0)), ib = i + sel(k == 1, I(0), I(1)), jb = j + sel(k == 1, I(1), I(0));
+    e.id = ((c0 + i) * 128 + (r0 + j)) * 3 + k;  // WHICH grid edge: the k-th edge starting at vertex (col, row) (for the sub-step trace)
+    const V3<K> vaK = mk<K>(cvt<K>(from_int(ia, F())) * PK.hf_dx, cvt<K>(from_int(ja, F())) * PK.hf_dy, cvt<K>(hf_at<F>(P, c0 + ia, r0 + ja)));
+    const V3<K> vbK = mk<K>(cvt<K>(from_int(ib, F())) * PK.hf_dx, cvt<K>(from_int(jb, F())) * PK.hf_dy, cvt<K>(hf_at<F>(P, c0 + ib, r0 + jb)));
+    V3<K> edK = vbK - vaK;
+    const K elK = sqrt_(dot(edK, edK));
+    edK = (K(SK(1)) / elK) * edK;
+    const V3<K> midK = SK(0.5) * (vaK + vbK);
+    K sK, tK;
+    seg_seg_closest(cK, azk, PK.bar_half, midK, edK, SK(0.5) * elK, sK, tK);
+    e.arm = sK * azk;
+    e.df = (cK + e.arm) - (midK + tK * edK);
+    e.nn = sqrt_(dot(e.df, e.df));
+    e.dist = e.nn - PK.rcyl_r;
+    return e;
+  };
+  EdgeK e = evalK(sel(some, to_int(tmin), I(0)));
+  const auto close = some & (t2 < S(27)) & (d2 - dmin < S(2e-6));
+  if (any_lane(close)) {
+    const EdgeK e2 = evalK(sel(close, to_int(t2), I(0)));
+    const auto second = close & ((e2.dist < e.dist) | ((e2.dist == e.dist) & (t2 < tmin)));
+    e.dist = sel(second, e2.dist, e.dist); e.nn = sel(second, e2.nn, e.nn); e.df = sel3(second, e2.df, e.df); e.arm = sel3(second, e2.arm, e.arm);
+    e.id = sel(second, e2.id, e.id);
+  }
+  id_out = e.id;
+  const auto ok = some & (e.dist < SK(0)) & (e.nn > SK(1e-12));
+  const F dist = cvt<F>(e.dist);
+  n_out = sel3(ok, cvt3<F>((K(SK(1)) / max_(e.nn, K(SK(1e-30)))) * e.df), mk<F>(zero, zero, F(S(1))));
   off_out = sel3(ok, -(rad + S(0.5) * dist) * n_out, z3);  // from the point of the axis the contact sits under to the contact
-  arm_out = sel3(ok, cvt3<F>(armK) + off_out, z3);
+  arm_out = sel3(ok, cvt3<F>(e.arm) + off_out, z3);
   return sel(ok, dist, F(S(1)));
 }
+
+// ------------------------------------------------------------------ multiply-add with a broadcast operand in ONE instruction
+// acc + bcast<L>(x) * m is what the factorisations below are made of.  The compiler emits it as v_mov_b32_dpp + v_fma_f32: its DPP combiner
+// folds row_newbcast into v_mul / v_add but not into v_fmac, and an fma with a negated operand is VOP3, which has no DPP form on this
+// machine.  v_fmac_f32 with a DPP source 0 and a NEGATED source 1 exists (VOP2 DPP carries source modifiers), so the multiply-adds go
+// out as inline assembly, several to a block.  A VALU write of a register needs two wait states before a DPP read of it, and the hazard
+// recogniser does not look into inline assembly: every block opens with s_nop 1 (which covers whatever was written before it), and inside a
+// block no DPP source is a register the block writes.  fp32 on the device only; everything else takes the plain form.
+#if !defined(TGR_ROW_EMUL) && !defined(TGR_NO_DPP_ASM)
+#define TGR_DPP_ASM 1
+#define TGR_FM(acc, src, mul, lane) "v_fmac_f32_dpp " acc ", " src ", " mul " row_newbcast:" lane " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+// a[k] += bcast<L>(a[k]) * m for up to five registers (column update of the Cholesky factorisation: m = -L_ij / L_jj)
+template <int L> TGR_RDEV void fm_self(float m, float& a0) { asm("s_nop 1\n\t" TGR_FM("%0", "%0", "%1", "%2") : "+v"(a0) : "v"(m), "n"(L)); }
+template <int L> TGR_RDEV void fm_self(float m, float& a0, float& a1) {
+  asm("s_nop 1\n\t" TGR_FM("%0", "%0", "%2", "%3") TGR_FM("%1", "%1", "%2", "%3") : "+v"(a0), "+v"(a1) : "v"(m), "n"(L));
+}
+template <int L> TGR_RDEV void fm_self(float m, float& a0, float& a1, float& a2) {
+  asm("s_nop 1\n\t" TGR_FM("%0", "%0", "%3", "%4") TGR_FM("%1", "%1", "%3", "%4") TGR_FM("%2", "%2", "%3", "%4") : "+v"(a0), "+v"(a1), "+v"(a2) : "v"(m), "n"(L));
+}
+template <int L> TGR_RDEV void fm_self(float m, float& a0, float& a1, float& a2, float& a3) {
+  asm("s_nop 1\n\t" TGR_FM("%0", "%0", "%4", "%5") TGR_FM("%1", "%1", "%4", "%5") TGR_FM("%2", "%2", "%4", "%5") TGR_FM("%3", "%3", "%4", "%5")
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m), "n"(L));
+}
+template <int L> TGR_RDEV void fm_self(float m, float& a0, float& a1, float& a2, float& a3, float& a4) {
+  asm("s_nop 1\n\t" TGR_FM("%0", "%0", "%5", "%6") TGR_FM("%1", "%1", "%5", "%6") TGR_FM("%2", "%2", "%5", "%6") TGR_FM("%3", "%3", "%5", "%6") TGR_FM("%4", "%4", "%5", "%6")
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : "v"(m), "n"(L));
+}
+// ... for N registers a[0..N), in blocks of up to five
+template <int L, int N> TGR_RDEV void fm_self_n(float m, float* a) {
+  if constexpr (N >= 5) { fm_self<L>(m, a[0], a[1], a[2], a[3], a[4]); if constexpr (N > 5) fm_self_n<L, N - 5>(m, a + 5); }
+  else if constexpr (N == 4) fm_self<L>(m, a[0], a[1], a[2], a[3]);
+  else if constexpr (N == 3) fm_self<L>(m, a[0], a[1], a[2]);
+  else if constexpr (N == 2) fm_self<L>(m, a[0], a[1]);
+  else if constexpr (N == 1) fm_self<L>(m, a[0]);
+}
+// acc -= sum_{i < N} x[i] * bcast<L>(y[i])  (one accumulator, N <= 6 terms: a row of C - X Y^T, a step of a triangular solve)
+template <int L, int N> TGR_RDEV void fm_dot(float& acc, const float* y, const float* x) {
+  static_assert(N >= 1 && N <= 6, "fm_dot");
+  if constexpr (N == 1) asm("s_nop 1\n\t" TGR_FM("%0", "%1", "-%2", "%3") : "+v"(acc) : "v"(y[0]), "v"(x[0]), "n"(L));
+  else if constexpr (N == 2) asm("s_nop 1\n\t" TGR_FM("%0", "%1", "-%3", "%5") TGR_FM("%0", "%2", "-%4", "%5") : "+v"(acc) : "v"(y[0]), "v"(y[1]), "v"(x[0]), "v"(x[1]), "n"(L));
+  else if constexpr (N == 3) asm("s_nop 1\n\t" TGR_FM("%0", "%1", "-%4", "%7") TGR_FM("%0", "%2", "-%5", "%7") TGR_FM("%0", "%3", "-%6", "%7")
+                                 : "+v"(acc) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "n"(L));
+  else if constexpr (N == 4) asm("s_nop 1\n\t" TGR_FM("%0", "%1", "-%5", "%9") TGR_FM("%0", "%2", "-%6", "%9") TGR_FM("%0", "%3", "-%7", "%9") TGR_FM("%0", "%4", "-%8", "%9")
+                                 : "+v"(acc) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "n"(L));
+  else if constexpr (N == 5) asm("s_nop 1\n\t" TGR_FM("%0", "%1", "-%6", "%11") TGR_FM("%0", "%2", "-%7", "%11") TGR_FM("%0", "%3", "-%8", "%11") TGR_FM("%0", "%4", "-%9", "%11")
+                                 TGR_FM("%0", "%5", "-%10", "%11")
+                                 : "+v"(acc) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "n"(L));
+  else asm("s_nop 1\n\t" TGR_FM("%0", "%1", "-%7", "%13") TGR_FM("%0", "%2", "-%8", "%13") TGR_FM("%0", "%3", "-%9", "%13") TGR_FM("%0", "%4", "-%10", "%13")
+           TGR_FM("%0", "%5", "-%11", "%13") TGR_FM("%0", "%6", "-%12", "%13")
+           : "+v"(acc) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "n"(L));
+}
+// two such accumulators side by side (their chains interleave): acc0 -= sum x[i] bcast<L0>(y[i]), acc1 -= sum x[i] bcast<L1>(y[i]), six terms each
+template <int L0, int L1> TGR_RDEV void fm_dot6x2(float& acc0, float& acc1, const float* y, const float* x) {
+  asm("s_nop 1\n\t" TGR_FM("%0", "%2", "-%8", "%14") TGR_FM("%1", "%2", "-%8", "%15") TGR_FM("%0", "%3", "-%9", "%14") TGR_FM("%1", "%3", "-%9", "%15")
+      TGR_FM("%0", "%4", "-%10", "%14") TGR_FM("%1", "%4", "-%10", "%15") TGR_FM("%0", "%5", "-%11", "%14") TGR_FM("%1", "%5", "-%11", "%15")
+      TGR_FM("%0", "%6", "-%12", "%14") TGR_FM("%1", "%6", "-%12", "%15") TGR_FM("%0", "%7", "-%13", "%14") TGR_FM("%1", "%7", "-%13", "%15")
+      : "+v"(acc0), "+v"(acc1)
+      : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "n"(L0), "n"(L1));
+}
+// acc[j] += bcast<L>(src[j]) * m for j < N <= 5 (independent accumulators, one shared multiplier: a column of the replicated back-substitution)
+template <int L, int N> TGR_RDEV void fm_cols(float* acc, const float* src, float m) {
+  static_assert(N >= 1 && N <= 5, "fm_cols");
+  if constexpr (N == 1) asm("s_nop 1\n\t" TGR_FM("%0", "%1", "%2", "%3") : "+v"(acc[0]) : "v"(src[0]), "v"(m), "n"(L));
+  else if constexpr (N == 2) asm("s_nop 1\n\t" TGR_FM("%0", "%2", "%4", "%5") TGR_FM("%1", "%3", "%4", "%5") : "+v"(acc[0]), "+v"(acc[1]) : "v"(src[0]), "v"(src[1]), "v"(m), "n"(L));
+  else if constexpr (N == 3) asm("s_nop 1\n\t" TGR_FM("%0", "%3", "%6", "%7") TGR_FM("%1", "%4", "%6", "%7") TGR_FM("%2", "%5", "%6", "%7")
+                                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(m), "n"(L));
+  else if constexpr (N == 4) asm("s_nop 1\n\t" TGR_FM("%0", "%4", "%8", "%9") TGR_FM("%1", "%5", "%8", "%9") TGR_FM("%2", "%6", "%8", "%9") TGR_FM("%3", "%7", "%8", "%9")
+                                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(m), "n"(L));
+  else asm("s_nop 1\n\t" TGR_FM("%0", "%5", "%10", "%11") TGR_FM("%1", "%6", "%10", "%11") TGR_FM("%2", "%7", "%10", "%11") TGR_FM("%3", "%8", "%10", "%11") TGR_FM("%4", "%9", "%10", "%11")
+           : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(m), "n"(L));
+}
+template <int L, int N> TGR_RDEV void fm_cols_n(float* acc, const float* src, float m) {
+  if constexpr (N > 5) { fm_cols<L, 5>(acc, src, m); fm_cols_n<L, N - 5>(acc + 5, src + 5, m); }
+  else if constexpr (N >= 1) fm_cols<L, N>(acc, src, m);
+}
+#else
+#define TGR_DPP_ASM 0
+#endif
 
 // ------------------------------------------------------------------ row-distributed dense algebra (lane i holds row i)
 // In-place Cholesky of an N x N SPD matrix whose row i lives in A[0..N) of lane i (full rows, both triangles).  Afterwards the
@@ -645,6 +745,11 @@ template <int N, typename F> TGR_RDEV void rchol(F* A, F* il) {
     const F ilj = rsqrt_(d);
     il[j] = ilj;
     const F t = A[j] * (ilj * ilj);  // L_ij / L_jj
+#if TGR_DPP_ASM
+    if constexpr (std::is_same<F, float>::value) {
+      fm_self_n<j, N - 1 - j>(-t, A + j + 1);
+    } else
+#endif
     static_for<N - 1 - j>([&](auto kc) {
       constexpr int k = j + 1 + decltype(kc)::value;
       A[k] = A[k] - t * bcast<j>(A[k]);
@@ -657,12 +762,23 @@ template <int N, typename F> TGR_RDEV void rtrsm(const F* Lr, const F* il, F* X)
   static_for<N>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     F s = X[j];
+#if TGR_DPP_ASM
+    if constexpr (N == 6 && std::is_same<F, float>::value) {
+      if constexpr (j > 0) fm_dot<j, j>(s, Lr, X);
+    } else
+#endif
     static_for<j>([&](auto kc) { constexpr int k = decltype(kc)::value; s = s - X[k] * bcast<j>(Lr[k]); });
     X[j] = s * il[j];
   });
 }
 // C <- C - X Y^T  (row i of C: C[k] -= sum_m X_i[m] Y_k[m]); rows of X, Y, C distributed, N columns
 template <int N, typename F> TGR_RDEV void rsyrk(F* C, const F* X, const F* Y) {
+#if TGR_DPP_ASM
+  if constexpr (N == 6 && std::is_same<F, float>::value) {
+    fm_dot6x2<0, 1>(C[0], C[1], Y, X); fm_dot6x2<2, 3>(C[2], C[3], Y, X); fm_dot6x2<4, 5>(C[4], C[5], Y, X);
+    return;
+  }
+#endif
   static_for<N>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     F s = C[k];
@@ -710,6 +826,11 @@ template <int N, typename F> TGR_RDEV void rbwd_rep(const F* Lr, const F* il, F*
     constexpr int i = N - 1 - decltype(ic)::value;
     const F xi = yr[i] * il[i];
     xr[i] = xi;
+#if TGR_DPP_ASM
+    if constexpr (std::is_same<F, float>::value) {
+      fm_cols_n<i, i>(yr, Lr, -xi);
+    } else
+#endif
     static_for<i>([&](auto jc) { constexpr int j = decltype(jc)::value; yr[j] = yr[j] - bcast<i>(Lr[j]) * xi; });
   });
 }
@@ -955,7 +1076,9 @@ constexpr int FV = 0, FW = 9, FCTRL = 18, FDL = 30, FDA = 39, FEZ = 48, FFCL = 5
 constexpr int FRL = 76, FRA = 85, FGA = 94;
 template <int MODEL> constexpr int f_slab() { return MODEL ? 103 : F_SLAB; }
 constexpr int TU = 0, TMA = 3, TMB = 6, TDAMP = 9, T_SLAB = 10;
-constexpr int CN = 0, CRA = 3, CRB = 6, CC0 = 9, CDN = 10, CACT = 11, CJL0 = 12, CJA0 = 15, CDLA = 18, CDAA = 21, CDLB = 24, CDAB = 27, C_SLAB = 30;  // cd (F, per lane): my contact slot
+// cd (F, per lane): my contact slot.  (The iterate of my slot's two bars is NOT kept here: a lane reads it from the replicated iterate in fd
+// with its own bar numbers as index -- copies per slot cost twelve loads, fmas and stores per lane and iteration to keep up to date.)
+constexpr int CN = 0, CRA = 3, CRB = 6, CC0 = 9, CDN = 10, CACT = 11, CJL0 = 12, CJA0 = 15, C_SLAB = 18;
 constexpr int AMB = 0, AMA = 3, AZB = 6, AZA = 9, A_SLAB = 12;  // ad (K, per lane): my slot's axial levers z x r and axes z of its two bars
 constexpr int RSA = 0, RSB = 3, RTK = 6, RTB = 7, RTL0 = 8, R_SLAB = 9;
 // hd (F, replicated): the solver's history -- the iterate d the sub-step before last ended on (18) and whether the last two sub-steps
@@ -1090,9 +1213,9 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
         f = sel(Ro.actuated, PK.gain * M.kd.ld(KACT + ti), kzero) + passive;
         damp = tb;
       } else {
-        const K cc = clamp_(cvt<K>(M.fd.ld(FCTRL + ti)), K(PK.ctrl_lo), K(PK.ctrl_hi));
+        const K cc = clamp_nan_(cvt<K>(M.fd.ld(FCTRL + ti)), K(PK.ctrl_lo), K(PK.ctrl_hi));
         const K fr = PK.gain * cc + PK.bias0 + PK.bias1 * L + PK.bias2 * Ld;
-        const K fa = clamp_(fr, K(PK.force_lo), K(PK.force_hi));
+        const K fa = clamp_nan_(fr, K(PK.force_lo), K(PK.force_hi));  // (NaN-propagating: a non-finite action must reach the state)
         const auto clamped = (fa <= PK.force_lo) | (fa >= PK.force_hi);
         K dact = K(-PK.bias2);
         if (PK.skip_clamped) dact = sel(clamped, kzero, dact);
@@ -1353,10 +1476,7 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
         st3(M.cd, C_SLAB + CJL0, cvt3<F>((ylB + cross(yaB, rB1)) + cvt<K>(M.cd.ld(C_SLAB + CC0)) * n1));
         st3(M.cd, C_SLAB + CJA0, cvt3<F>(yaB));
       }
-      st3(M.cd, CDLA, z3); st3(M.cd, CDAA, z3); st3(M.cd, CDLB, z3); st3(M.cd, CDAB, z3);
     } else {
-      st3(M.cd, CDLA, pick_bar0(Ro.sA, dl)); st3(M.cd, CDAA, pick_bar0(Ro.sA, da));
-      st3(M.cd, CDLB, pick_bar0(Ro.sB, dl)); st3(M.cd, CDAB, pick_bar0(Ro.sB, da));
       st3(M.cd, CJL0, jl0); st3(M.cd, CJA0, ja0);
     }
   }
@@ -1378,8 +1498,14 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     RContact<F> cs;
     cs.n = ld3(M.cd, CN); cs.rA = ld3(M.cd, CRA); cs.rB = ld3(M.cd, CRB);
     cs.c0 = M.cd.ld(CC0); cs.Dn = M.cd.ld(CDN); cs.active = M.cd.ld(CACT) != S(0);
-    const V3<F> jl = ld3(M.cd, CJL0) + ((ld3(M.cd, CDLB) + cross(ld3(M.cd, CDAB), cs.rB)) - (ld3(M.cd, CDLA) + cross(ld3(M.cd, CDAA), cs.rA)));
-    const V3<F> ja = ld3(M.cd, CJA0) + (ld3(M.cd, CDAB) - ld3(M.cd, CDAA));
+    // (the iterate at my slot's two bars, straight from the replicated iterate: a lane-dependent LDS address; a slot without a bar A -- floor
+    // contacts -- takes zero there, an idle lane reads bar 0 and is masked by its inactive slot)
+    const I jbi = sel(Ro.sB >= 0, Ro.sB, I(0)), jai = sel(Ro.sA >= 0, Ro.sA, I(0));
+    const auto hasAi = Ro.sA >= 0;
+    const V3<F> dLB = ld3(M.fd, FDL + 3 * jbi), dAB = ld3(M.fd, FDA + 3 * jbi);
+    const V3<F> dLA = sel3(hasAi, ld3(M.fd, FDL + 3 * jai), z3), dAA = sel3(hasAi, ld3(M.fd, FDA + 3 * jai), z3);
+    const V3<F> jl = ld3(M.cd, CJL0) + ((dLB + cross(dAB, cs.rB)) - (dLA + cross(dAA, cs.rA)));
+    const V3<F> ja = ld3(M.cd, CJA0) + (dAB - dAA);
     const RCone<F> o = cone_eval(P, cs, jl, ja);
     // MODEL 1, page 1: a cap's second terrain contact (same bar, no body A)
     RContact<F> cs1;
@@ -1390,8 +1516,8 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     if (page1) {
       cs1.n = ld3(M.cd, C_SLAB + CN); cs1.rA = z3; cs1.rB = ld3(M.cd, C_SLAB + CRB);
       cs1.c0 = M.cd.ld(C_SLAB + CC0); cs1.Dn = M.cd.ld(C_SLAB + CDN); cs1.active = M.cd.ld(C_SLAB + CACT) != S(0);
-      jl1 = ld3(M.cd, C_SLAB + CJL0) + (ld3(M.cd, CDLB) + cross(ld3(M.cd, CDAB), cs1.rB));
-      ja1 = ld3(M.cd, C_SLAB + CJA0) + ld3(M.cd, CDAB);
+      jl1 = ld3(M.cd, C_SLAB + CJL0) + (dLB + cross(dAB, cs1.rB));
+      ja1 = ld3(M.cd, C_SLAB + CJA0) + dAB;
       o1 = cone_eval(P, cs1, jl1, ja1);
     }
     TGR_RSTAMP(4);  // residual + cone
@@ -1549,12 +1675,13 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
 #ifdef TGR_ROW_TRACE
     std::fprintf(stderr, "      d0 %.3e alpha %.6f lo %.4f hi %.4f g1 %.3e g2 %.3e ls_done %d n_ls %d\n", (double)d0.v[0], (double)alpha.v[0], (double)lo.v[0], (double)hi.v[0], (double)g1.v[0], (double)g2.v[0], (int)ls_done.v[0], n_ls);
 #endif
-    for (int b = 0; b < 3; b++) {
-      st3(M.fd, FDL + 3 * b, ld3(M.fd, FDL + 3 * b) + alpha * pl[b]);
-      st3(M.fd, FDA + 3 * b, ld3(M.fd, FDA + 3 * b) + alpha * pa[b]);
+    {
+      // the iterate moves: lane b updates bar b (lanes 3.. repeat bar 0) and stores it -- every reader takes it from the slab
+      const I bi = sel(Ro.r == 1, I(1), sel(Ro.r == 2, I(2), I(0)));
+      const V3<F> plb = pick_bar(bi, pl), pab = pick_bar(bi, pa);
+      const V3<F> nl = ld3(M.fd, FDL + 3 * bi) + alpha * plb, na_ = ld3(M.fd, FDA + 3 * bi) + alpha * pab;
+      st3_rep(M.fd, FDL + 3 * bi, nl); st3_rep(M.fd, FDA + 3 * bi, na_);
     }
-    st3(M.cd, CDLA, ld3(M.cd, CDLA) + alpha * plA); st3(M.cd, CDAA, ld3(M.cd, CDAA) + alpha * paA);
-    st3(M.cd, CDLB, ld3(M.cd, CDLB) + alpha * plB); st3(M.cd, CDAB, ld3(M.cd, CDAB) + alpha * paB);
     TGR_FENCE();
     TGR_RSTAMP(10);  // iterate update
     if (!any_lane(!conv)) break;  // (only stalled rows were left: their iterate has not moved, the wrench above is the one of the iterate)
@@ -1709,7 +1836,7 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
       // actuator a on lane a (in K: the actuator gain is 15000 N per unit of activation, and twenty fp32 roundings of the activation are 1e-3 N)
       const I ai = sel(Ro.r < 6, Ro.r, I(0));
       const K ac = M.kd.ld(KACT + ai);
-      M.kd.st_rep(KACT + ai, ac + PK.h * (cvt<K>(clamp_(M.fd.ld(FCTRL + ai), F(P.ctrl_lo), F(P.ctrl_hi))) - ac) * PK.act_itau);
+      M.kd.st_rep(KACT + ai, ac + PK.h * (cvt<K>(clamp_nan_(M.fd.ld(FCTRL + ai), F(P.ctrl_lo), F(P.ctrl_hi))) - ac) * PK.act_itau);
     }
   }
   TGR_RSTAMP(14);  // advance

@@ -289,6 +289,9 @@ template <typename F> TGR_RDEV F abs_(F x) { return sel(x < typename LaneTraits<
 template <typename F> TGR_RDEV F max_(F a, F b) { return sel(a > b, a, b); }
 template <typename F> TGR_RDEV F min_(F a, F b) { return sel(a < b, a, b); }
 template <typename F> TGR_RDEV F clamp_(F x, F lo, F hi) { return sel(x < lo, lo, sel(x > hi, hi, x)); }
+// the same as selects on every target: a NaN input stays NaN (v_max / v_min return the other operand).  For the control input: a non-finite
+// action must poison the state, so that the env terminates and restarts the way the reference does after mujoco's bad-qacc reset
+template <typename F> TGR_RDEV F clamp_nan_(F x, F lo, F hi) { return sel(x < lo, lo, sel(x > hi, hi, x)); }
 
 template <typename F> struct V3 { F x, y, z; };
 template <typename F> TGR_RDEV V3<F> mk(F x, F y, F z) { V3<F> r; r.x = x; r.y = y; r.z = z; return r; }

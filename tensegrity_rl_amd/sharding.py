@@ -48,6 +48,7 @@ class RolloutGatherer:
                 b["g_rew"] = torch.zeros((self.world * chunk, n_local), dtype=dtype, device=device)
                 b["g_done"] = torch.zeros((self.world * chunk, n_local), dtype=torch.uint8, device=device)
             self.sets.append(b)
+        self.collectives = 0  # all-gathers issued so far
         # the synchronous interface of earlier revisions
         self.obs, self.rew, self.done = self.sets[0]["obs"], self.sets[0]["rew"], self.sets[0]["done"]
 
@@ -80,10 +81,12 @@ class RolloutGatherer:
         if "g_obs" not in b:
             return self._views(b)
         if not self.overlap:
+            self.collectives += 3
             dist.all_gather_into_tensor(b["g_obs"], b["obs"])
             dist.all_gather_into_tensor(b["g_rew"], b["rew"])
             dist.all_gather_into_tensor(b["g_done"], b["done"])
             return self._views(b)
+        self.collectives += 3
         b["work"] = [dist.all_gather_into_tensor(b["g_obs"], b["obs"], async_op=True),
                      dist.all_gather_into_tensor(b["g_rew"], b["rew"], async_op=True),
                      dist.all_gather_into_tensor(b["g_done"], b["done"], async_op=True)]

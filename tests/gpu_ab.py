@@ -8,4 +8,4 @@ for rep in range(2):
         env = dict(os.environ, TGR_LIB=os.path.abspath(lib))
         out = subprocess.run([sys.executable, os.path.join(here, "gpu_quickbench.py"), "4096", "tensegrity_env-v0", "150", "1"], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("n=")]
-        print(os.path.basename(lib), line[-1][:160] if line else out.stderr[-300:], flush=True)
+        print(os.path.basename(lib), line[-1][:230] if line else out.stderr[-300:], flush=True)

@@ -145,7 +145,10 @@ if __name__ == "__main__":
     img = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "terrain_100.npy"))
     print(f"# fp32 handles vs the oracle on identical (state, action): {n} envs x {steps} steps per case, kwargs {kw}")
     print("# case | qpos<1e-4 | qvel<1e-4 | outliers: flip / capped / neither | worst flip / non-flip | median qvel | p99.9 qvel | wave it/sub-step | unconverged")
-    for kind, uneven in (("tensegrity_env", False), ("tr_env", False), ("tensegrity_env", True), ("tr_env", True)):
+    cases = (("tensegrity_env", False), ("tr_env", False), ("tensegrity_env", True), ("tr_env", True))
+    if "--uneven-only" in sys.argv:
+        cases = cases[2:]
+    for kind, uneven in cases:
         u = summary(run_case(kind, uneven, n, steps, img, **kw))
         print(f"{kind:15s} {'uneven' if uneven else 'flat  '} | {100*u['qpos_in']:.3f} % | {100*u['qvel_in']:.3f} % | {u['outliers']:4d}: {u['flip']:4d} (of them {u['facet_change']} a cap on another facet, {u['edge_change']} a bar on another grid edge, same mask) / {u['capped']:3d} / {u['neither']:3d} "
               f"(non-finite {u['nonfinite']}) | {u['worst_flip']:.1e} / {u['worst_nonflip']:.1e} | {u['median_qvel']:.1e} | {u['p999_qvel']:.1e} | "

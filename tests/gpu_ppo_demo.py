@@ -1,7 +1,8 @@
 """Learnability check (diagnostic driver, not a test and not the product): a plain-torch PPO on top of the GPU-resident rollout
 buffers (tensegrity_rl_amd/rollout.py) trains tr_env-v0 "straight" with 4096 envs on one MI355X.  Everything stays on the device:
 policy -> step_tensors -> DeviceRolloutBuffer -> GAE -> minibatch updates.  Prints mean forward reward per env-step before/after.
-usage: python tests/gpu_ppo_demo.py [iterations] [n_envs] [n_steps]"""
+Behavioural evidence for BASELINE configs #3 / #4 (SB3 itself is not installable here or on the GPU box): the reward a learner sees goes up.
+usage: python tests/gpu_ppo_demo.py [iterations] [n_envs] [n_steps] [--uneven] [--env-id tr_env-v0|tensegrity_env-v0]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,12 +10,20 @@ import torch.nn as nn
 from tensegrity_rl_amd import TensegrityVecEnv
 from tensegrity_rl_amd.rollout import DeviceRolloutBuffer, collect
 
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-T = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+pos = [a for a in sys.argv[1:] if not a.startswith("--") and (sys.argv[sys.argv.index(a) - 1] != "--env-id")]
+iters = int(pos[0]) if len(pos) > 0 else 60
+n = int(pos[1]) if len(pos) > 1 else 4096
+T = int(pos[2]) if len(pos) > 2 else 32
+uneven = "--uneven" in sys.argv
+env_id = sys.argv[sys.argv.index("--env-id") + 1] if "--env-id" in sys.argv else "tr_env-v0"
 dev = torch.device("cuda")
 torch.manual_seed(0)
-env = TensegrityVecEnv(n, "tr_env-v0", desired_action="straight", desired_direction=1, seed=1)
+kw = {}
+if uneven:
+    import numpy as np
+    kw = dict(model="uneven", terrain=np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "terrain_100.npy")))
+env = TensegrityVecEnv(n, env_id, desired_action="straight", desired_direction=1, seed=1, **kw)
+print(f"# PPO (plain torch, everything on the device) on {env_id} straight/+1, {'uneven-ground heightfield' if uneven else 'flat floor'}, {n} envs x {T} steps per iteration, {iters} iterations", flush=True)
 D = env.obs_dim
 lo, hi = -0.45, 0.15
 
@@ -65,6 +74,7 @@ def value(obs):
 buf = DeviceRolloutBuffer(T, n, D, device=dev, gamma=0.99, gae_lambda=0.95)
 raw_actions = torch.zeros(T, n, 6, device=dev)
 obs = env.reset_tensors().clone()
+first_rew = 0.0
 t0 = time.time()
 for it in range(iters):
     buf.reset()
@@ -94,7 +104,11 @@ for it in range(iters):
             opt.zero_grad(); loss.backward()
             nn.utils.clip_grad_norm_(list(pi.parameters()) + list(vf.parameters()), 0.5)
             opt.step()
+    first_rew = buf.rewards.mean().item() if it == 0 else first_rew
     if it % 5 == 0 or it == iters - 1:
         print(f"iter {it:3d}  env-steps {(it + 1) * n * T / 1e6:6.2f} M  wall {time.time() - t0:6.1f} s  mean reward/step {buf.rewards.mean().item():+.4f}  "
               f"episodes {stats['episodes']}  mean len {stats['mean_length']:.0f}  std {log_std.exp().mean().item():.3f}", flush=True)
+wall = time.time() - t0
+print(f"# mean reward per env-step: first iteration {first_rew:+.4f} -> last {buf.rewards.mean().item():+.4f};  {iters * n * T / wall / 1e6:.2f} M env-steps/s with the learner in the loop "
+      f"({iters * n * T / 1e6:.1f} M env-steps in {wall:.0f} s)", flush=True)
 env.close()

@@ -27,4 +27,9 @@ for i in range(steps):
     o, r, te, tr, _, _ = env.step_tensors(acts[i % 16])
     dones += int((te | tr).sum().item()) if i % 10 == 0 else 0
 torch.cuda.synchronize(); dt = time.time() - t0
-print(f"n={n} {kind} auto={auto} {kw} reset {t_reset*1e3:.1f} ms; {steps} steps {dt*1e3:.1f} ms -> {dt/steps*1e3:.3f} ms/step, {n*steps/dt/1e6:.3f} M env-steps/s; dones sampled {dones}; stats {env.stats()}", flush=True)
+# the dominant kernel alone (the launch that steps the live rows), HIP events recorded by the library on its stream: less noisy than the wall clock
+env.time_kernels(128)
+for i in range(128): env.step_tensors(acts[i % 16])
+kt = sorted(env.kernel_times_ms(128)); env.time_kernels(0)
+kern = f"live-row kernel {sum(kt)/len(kt):.4f} ms mean / {kt[len(kt)//2]:.4f} median" if kt else ""
+print(f"n={n} {kind} auto={auto} {kw} reset {t_reset*1e3:.1f} ms; {steps} steps {dt*1e3:.1f} ms -> {dt/steps*1e3:.3f} ms/step, {n*steps/dt/1e6:.3f} M env-steps/s; {kern}; dones sampled {dones}; stats {env.stats()}", flush=True)

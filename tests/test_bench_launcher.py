@@ -48,3 +48,17 @@ def test_bare_two_rank_rehearsal_on_one_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["envs_per_gpu"] == 512 and d["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_the_multi_rank_code_path_runs_over_rccl_on_one_gpu():
+    """TGR_BENCH_FORCE_DIST=1: world size 1, but everything the N > 1 path does is done -- a process group over RCCL (backend "nccl"), the
+    asynchronous all-gathers of RolloutGatherer every K steps, the barrier and the max-reduce of the elapsed time.  No 8-GPU node is ever
+    available to the tests: this is what keeps RCCL and the gather in the driver-run suite (a scaling curve it is not)."""
+    out = _run({"TGR_BENCH_FORCE_DIST": "1"}, "--gpus", "1", "--steps", "40", "--warmup", "10", "--envs-per-gpu", "1024", "--no-cpu-baseline", "--no-vecenv")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["gather_every"] is not None
+    assert d["config"].get("collective_backend") == "nccl" and d["config"].get("all_gathers_issued", 0) >= 2, d["config"]

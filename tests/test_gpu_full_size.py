@@ -65,7 +65,9 @@ def test_full_size_tr_env_uneven_rollout_crosses_resets(golden_dir):
     outs, bad, dones, s0, s1, st = a
     assert bad == 0 and dones >= 3 * n
     lane = s1["lane_substeps"] - s0["lane_substeps"]
-    assert s1["unconverged_lane_substeps"] - s0["unconverged_lane_substeps"] < 0.02 * lane, s1
+    # (heightfield: 2-3 % of lane-sub-steps leave the solver by the stall exit of the fp32 line search since the default stopping rule went to
+    # (7e-5, 3.5e-6) in round 4 -- counted; tests/test_gpu_uneven.py shows them harmless for the 1e-4 bound)
+    assert s1["unconverged_lane_substeps"] - s0["unconverged_lane_substeps"] < 0.04 * lane, s1
     assert s1["donor_resets"] - s0["donor_resets"] >= 2 * n, s1
     z = st["qpos"].reshape(n, 3, 7)[:, :, 2]
     assert z.max() < 0.6 and z.min() > -1.3 and np.isfinite(st["qpos"]).all()   # standing on the terrain (z in [-1, 0]), not on a z = 0 plane

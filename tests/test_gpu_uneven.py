@@ -111,21 +111,26 @@ def test_uneven_fp32_close_to_oracle(oracle, golden_dir):
     env.close(); ob.close()
 
 
-@pytest.mark.parametrize("kind,qv_min,nonflip_max", [("tensegrity_env", 0.999, 0.0005), ("tr_env", 0.999, 0.0005)])
-def test_fp32_uneven_outliers_are_classified_and_bounded(oracle, golden_dir, kind, qv_min, nonflip_max):
-    """2048 envs x 8 control periods on the heightfield, every env-step outside 1e-4 classified on the device's own sub-step trace
-    (tests/gpu_accuracy_report.py).  The heightfield has more discrete choices than the flat floor (facet, second facet, grid edge under a
-    bar); the facet-plane and bar-on-grid-edge distances are formed in fp64 for that reason, which leaves tensegrity_env at >= 99.9 % like the
-    flat floor.  tr_env's quasi-static robots (velocities of mm/s against the 1e-2 floor of the relative error, so 1e-6 rad/s of spin about a
-    bar's own axis counts) needed the Newton iteration on e = d - d_ref (tgr_row.h SHIFT); with it both env classes stay
-    >= 99.9 % inside 1e-4, and what is not a flip is bounded in number and in size."""
+@pytest.mark.parametrize("kind", ["tensegrity_env", "tr_env"])
+def test_fp32_uneven_outliers_are_classified_and_bounded(oracle, golden_dir, kind):
+    """4096 envs x 16 control periods on the heightfield (BASELINE config #4's model; by step 10 the tr_env robots have come to rest: the
+    hardest case there is -- velocities of mm/s against the 1e-2 floor of the relative error), every env-step outside 1e-4 classified on the
+    device's own sub-step trace next to the oracle's (tests/gpu_accuracy_report.py).  A FLIP here is a sub-step whose terrain contacts differ
+    from the oracle's -- in the mask of active slots, or (round 4: the identity words of the trace) in WHICH facet a cap or WHICH grid edge a
+    bar's cylinder touches under the same mask.
+      * >= 99.9 % of env-steps inside 1e-4 for qpos AND qvel (default stopping rule (7e-5, 3.5e-6): profiles/round4_uneven_tolerance_4096x16.log);
+      * what is outside and not a flip is bounded in number (0.1 %) and in size (5e-3): quasi-static robots at the stopping tolerance, or a
+        sub-step that left the solver by its stall exit -- the O(1) "neither" cases of round 3 were bars on another grid edge, now decided in K;
+      * a flip changes the velocity by what one sub-step of a contact's damping does: <= 2 (relative to max(|qvel|, 1e-2));
+      * flips that happen to stay inside the bound are counted too, and stay rare (< 0.2 % of env-steps)."""
     from gpu_accuracy_report import run_case, summary
-    u = summary(run_case(kind, True, 2048, 8, terrain(golden_dir)))
+    u = summary(run_case(kind, True, 4096, 16, terrain(golden_dir)))
     assert u["nonfinite"] == 0
-    assert u["qpos_in"] >= 0.997 and u["qvel_in"] >= qv_min, u
-    assert u["capped"] + u["neither"] <= nonflip_max * u["n"] and u["worst_nonflip"] < 5e-3, u
-    assert u["worst_flip"] < 10.0, u
-    assert u["unconverged_fraction"] < 2e-2, u
+    assert u["qpos_in"] >= 0.999 and u["qvel_in"] >= 0.999, u
+    assert u["capped"] + u["neither"] <= 0.001 * u["n"] and u["worst_nonflip"] < 5e-3, u
+    assert u["worst_flip"] <= 2.0, u
+    assert u["flips_inside_bound"] <= 0.002 * u["n"], u
+    assert u["unconverged_fraction"] < 4e-2, u   # (stall exits of the fp32 line search at hard onsets: counted, harmless for the bound above)
 
 
 def test_gym_wrapper_selects_the_model_from_xml_file(golden_dir):
