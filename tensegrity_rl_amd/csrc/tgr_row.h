@@ -731,17 +731,26 @@ template <int L, int N> TGR_RDEV void fm_cols_n(float* acc, const float* src, fl
 
 // ------------------------------------------------------------------ row-distributed dense algebra (lane i holds row i)
 // In-place Cholesky of an N x N SPD matrix whose row i lives in A[0..N) of lane i (full rows, both triangles).  Afterwards the
-// lower part of the rows holds L (A[j], j < i) and il[j] = 1 / L_jj is replicated.  Pivots are floored relative to the original
-// diagonal: a Schur complement that loses positivity to rounding must cost accuracy of one Newton direction, never produce inf.
-template <int N, typename F> TGR_RDEV void rchol(F* A, F* il) {
+// lower part of the rows holds L (A[j], j < i) and il[j] = 1 / L_jj is replicated.  Pivots are floored: a Schur complement that loses
+// positivity to rounding must cost accuracy of one Newton direction, never produce inf.  The floor of pivot j is a bound the CALLER knows
+// (floor_of(j), a uniform scalar): every matrix factored here is "something positive definite plus positive semi-definite terms" -- the mass
+// matrix plus contact terms, the identity plus the tendon dampers -- and a Cholesky pivot of A + B, B >= 0, is never below the same pivot of
+// A.  (Until round 4 the floor was 1e-6 of the original diagonal entry: six broadcasts, six multiplies and six maxima per factorisation for a
+// test that the known bound does in one maximum per pivot.)
+template <int N, typename F, typename FL> TGR_RDEV void rchol(F* A, F* il, FL floor_of) {
   typedef typename LaneTraits<F>::S S;
-  const S rel = sizeof(S) == 4 ? S(1e-6) : S(1e-13);
-  F ref[N];
-  static_for<N>([&](auto jc) { constexpr int j = decltype(jc)::value; ref[j] = bcast<j>(A[j]); });
   static_for<N>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    F d = bcast<j>(A[j]);
-    d = max_(d, max_(rel * abs_(ref[j]), F(S(1e-30))));
+    F d;
+#if TGR_DPP_ASM
+    if constexpr (std::is_same<F, float>::value) {
+      // broadcast and floor in ONE instruction (v_max_f32 with a DPP source; the floor has to sit in a VGPR).  From the compiler the pair comes
+      // as three: the broadcast travels through an integer bit cast, after which fmaxf() canonicalises its operand first (a v_max of it with itself)
+      const float fl = floor_of(j);
+      asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(A[j]), "v"(fl), "n"(j));
+    } else
+#endif
+    d = max_(bcast<j>(A[j]), F(S(floor_of(j))));
     const F ilj = rsqrt_(d);
     il[j] = ilj;
     const F t = A[j] * (ilj * ilj);  // L_ij / L_jj
@@ -889,7 +898,7 @@ template <typename F, typename S> TGR_RDEV void ls_slot(const RParams<S>& P, con
 
 // ------------------------------------------------------------------ Newton Hessian, dof role
 // per-lane dof constants: e = unit vector of my component, ang = am I an angular row
-template <typename F> struct DofC { V3<F> e; typename LaneTraits<F>::B ang, dof; };
+template <typename F> struct DofC { V3<F> e; typename LaneTraits<F>::B ang, dof, upper; };  // upper: lanes 8.. (the dof constants repeat there)
 // column r of J = [[I, -[arm]x], [0, I]] for my dof r:  (u_lin, u_ang)
 template <typename F> TGR_RDEV void dof_col(const DofC<F>& d, V3<F> arm, V3<F>& ul, V3<F>& ua) {
   typedef typename LaneTraits<F>::S S;
@@ -932,14 +941,24 @@ TGR_RDEV void hess_add_slot(RHess<F>& H, const DofC<F>& d, const RContact<F>& c,
   constexpr int A = slot_bar_a<MODEL>(PAGE, C), Bb = slot_bar_b<MODEL>(PAGE, C);
   static_assert(Bb >= 0, "slot without a body");
   V3<F> ul, ua, wl, wa;
-  dof_col(d, s.rB, ul, ua);
-  cone_mul(s, cone, ul, ua, wl, wa);
-  row_acc(H.D[Bb], wl, wa, s.rB, false);
-  if (A >= 0) {
-    row_acc(hess_off(H, A < 0 ? 0 : A, Bb), wl, wa, s.rA, true);  // rows: B dofs, columns: A dofs
-    dof_col(d, s.rA, ul, ua);
+  if constexpr (A < 0) {
+    dof_col(d, s.rB, ul, ua);
     cone_mul(s, cone, ul, ua, wl, wa);
-    row_acc(H.D[A < 0 ? 0 : A], wl, wa, s.rA, false);
+    row_acc(H.D[Bb], wl, wa, s.rB, false);
+  } else {
+    // A slot between two bars: the lower half of the row (lanes 0..5) works on body B's columns, the upper half (lanes 8..13, where the dof
+    // constants d repeat) on body A's -- the two differ only in the lever the Jacobian column is built on -- and one shift brings A's diagonal
+    // block down.  (One by one the two bodies cost a second column, a second cone product and a third accumulation: 122 operations, 84 so.
+    // The bar pairs' side-to-side slots are in use in 40 % of the wavefronts of the headline workload each: profiles/round4_slot_census.log.)
+    const V3<F> arm = sel3(d.upper, s.rA, s.rB);
+    dof_col(d, arm, ul, ua);
+    cone_mul(s, cone, ul, ua, wl, wa);
+    const V3<F> t = cross(arm, wl) + wa;
+    F* RB = H.D[Bb]; F* RA = H.D[A];
+    RB[0] = RB[0] + wl.x; RB[1] = RB[1] + wl.y; RB[2] = RB[2] + wl.z; RB[3] = RB[3] + t.x; RB[4] = RB[4] + t.y; RB[5] = RB[5] + t.z;  // (lower half: B's block)
+    RA[0] = RA[0] + upper8(wl.x); RA[1] = RA[1] + upper8(wl.y); RA[2] = RA[2] + upper8(wl.z);
+    RA[3] = RA[3] + upper8(t.x); RA[4] = RA[4] + upper8(t.y); RA[5] = RA[5] + upper8(t.z);
+    row_acc(hess_off(H, A, Bb), wl, wa, s.rA, true);  // rows: B dofs, columns: A dofs (lower half)
   }
 }
 
@@ -978,22 +997,25 @@ TGR_RDEV void hess_add_roving(RHess<F>& H, const DofC<F>& d, const RContact<F>& 
 // p = -H^-1 g.  g: per bar distributed (lane r: component r of the bar's 6-vector); returns p replicated, pr[b][0..6)
 // c01 / c02 / c12: does ANY environment of the wavefront couple bars (0,1) / (0,2) / (1,2)?  (uniform flags; an off-diagonal block
 // nobody fills is zero and its part of the factorisation is skipped.  O21 also fills in through O20 O10^T.)
-template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F pr[3][6], F& gHg, bool c01, bool c02, bool c12) {
+// fl_lin / fl_ang: floors of the pivots of a bar's linear / angular rows (half of what the mass matrix alone would give: m, Izz)
+template <typename F, typename S_> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F pr[3][6], F& gHg, bool c01, bool c02, bool c12, S_ fl_lin, S_ fl_ang) {
   typedef typename LaneTraits<F>::S S;
+  auto floor_of = [&](int j) { return j < 3 ? fl_lin : fl_ang; };
   const bool n21 = c12 || (c01 && c02);
   F il0[6], il1[6], il2[6];
-  rchol<6>(H.D[0], il0);
+  rchol<6>(H.D[0], il0, floor_of);
   if (c01) rtrsm<6>(H.D[0], il0, H.O10);
   if (c02) rtrsm<6>(H.D[0], il0, H.O20);
   if (c01) rsyrk<6>(H.D[1], H.O10, H.O10);
   if (c01 && c02) rsyrk<6>(H.O21, H.O20, H.O10);
-  rchol<6>(H.D[1], il1);
+  rchol<6>(H.D[1], il1, floor_of);
   if (n21) rtrsm<6>(H.D[1], il1, H.O21);
   if (c02) rsyrk<6>(H.D[2], H.O20, H.O20);
   if (n21) rsyrk<6>(H.D[2], H.O21, H.O21);
-  rchol<6>(H.D[2], il2);
-  // forward: L y = g  (the y of each block comes out replicated)
-  F y0 = gd[0], y1 = gd[1], y2 = gd[2], yr0[6], yr1[6], yr2[6];
+  rchol<6>(H.D[2], il2, floor_of);
+  // forward: L y = -g  (the y of each block comes out replicated; the sign goes in here, three negations, instead of onto the eighteen
+  // components of the solution)
+  F y0 = -gd[0], y1 = -gd[1], y2 = -gd[2], yr0[6], yr1[6], yr2[6];
   rfwd<6>(H.D[0], il0, y0, yr0);
   if (c01) rgemv_rep<6>(H.O10, yr0, y1);
   if (c02) rgemv_rep<6>(H.O20, yr0, y2);
@@ -1022,8 +1044,6 @@ template <typename F> TGR_RDEV void newton_direction(RHess<F>& H, const F* gd, F
     for (int i = 0; i < 6; i++) yr0[i] = yr0[i] - t[i];
   }
   rbwd_rep<6>(H.D[0], il0, yr0, pr[0]);
-  for (int b = 0; b < 3; b++)
-    for (int i = 0; i < 6; i++) pr[b][i] = -pr[b][i];
 }
 
 // constraint wrench on bar b from the neighbour sums of the slot lanes (P*: pairsum over lanes 2j, 2j+1; *B: as body B, *A: as body A of
@@ -1071,10 +1091,11 @@ TGR_RDEV void bar_sum(int b, V3<F> PfB, V3<F> PtB, V3<F> PtA, K PkB, K PkA, V3<F
 //   kd (K, replicated): pose x, q; unconstrained acceleration l0, a0; bar axes ez       fd (F, replicated): v, w, ctrl, act
 //   td (F, per lane):   tendon-role results u, ra x u, rb x u, damping                  rd (K, per lane, per block): tendon-role constants
 constexpr int KX = 0, KQ = 9, KL0 = 21, KA0 = 30, KEZ = 39, KTAX = 48, KACT = 51, K_SLAB = 57;
-constexpr int FV = 0, FW = 9, FCTRL = 18, FDL = 30, FDA = 39, FEZ = 48, FFCL = 57, FFCA = 66, FCAPD = 75, F_SLAB = 76;  // FDL / FDA: d = a - a0; FCAPD: cap radius minus the model's
+constexpr int FV = 0, FW = 9, FCTRL = 18, FDL = 30, FDA = 39, FEZ = 48, FFCL = 57, FFCA = 66, FCAPD = 75, FG = 76, F_SLAB = 94;  // FDL / FDA: d = a - a0; FCAPD: cap radius minus the model's
+// FG: the gradient, bar by bar (6 each) -- lane b forms bar b's, the dof lanes read it back transposed (lane r: component r of every bar)
 // MODEL 1 iterates on e = d - d_ref (see substep): d_ref (FRL / FRA) and I d_ref (FGA) sit behind the common part of the slab
-constexpr int FRL = 76, FRA = 85, FGA = 94;
-template <int MODEL> constexpr int f_slab() { return MODEL ? 103 : F_SLAB; }
+constexpr int FRL = 94, FRA = 103, FGA = 112;
+template <int MODEL> constexpr int f_slab() { return MODEL ? 121 : F_SLAB; }
 constexpr int TU = 0, TMA = 3, TMB = 6, TDAMP = 9, T_SLAB = 10;
 // cd (F, per lane): my contact slot.  (The iterate of my slot's two bars is NOT kept here: a lane reads it from the replicated iterate in fd
 // with its own bar numbers as index -- copies per slot cost twelve loads, fmas and stores per lane and iteration to keep up to date.)
@@ -1242,18 +1263,25 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
       const V3<FS> Sfu = mk<FS>(trisum(cvt<FS>(ften * u.x)), trisum(cvt<FS>(ften * u.y)), trisum(cvt<FS>(ften * u.z)));
       const V3<K> Sma = mk<K>(trisum(ften * ma.x), trisum(ften * ma.y), trisum(ften * ma.z));
       const V3<K> Smb = mk<K>(trisum(ften * mb.x), trisum(ften * mb.y), trisum(ften * mb.z));
-      static_for<3>([&](auto bc_) {
-        constexpr int b = decltype(bc_)::value;
-        V3<K> Fb, Tb;
-        if (b == 0) { Fb = cvt3<K>(-(bcast3v<0>(Sfu) + bcast3v<1>(Sfu))); Tb = -(bcast3v<0>(Sma) + bcast3v<1>(Sma)); }
-        else if (b == 1) { Fb = cvt3<K>(bcast3v<1>(Sfu) - bcast3v<2>(Sfu)); Tb = bcast3v<1>(Smb) - bcast3v<2>(Sma); }
-        else { Fb = cvt3<K>(bcast3v<0>(Sfu) + bcast3v<2>(Sfu)); Tb = bcast3v<0>(Smb) + bcast3v<2>(Smb); }
-        Fb.z = Fb.z - PK.mass * PK.grav;
-        const V3<K> wk = cvt3<K>(ld3(M.fd, FW + 3 * b)), kz = ld3(M.kd, KEZ + 3 * b);
-        const V3<K> Tq = Tb + (-(PK.Izz - PK.Ixx) * dot(kz, wk)) * cross(wk, kz);  // gyroscopic
-        st3(M.kd, KL0 + 3 * b, imk * Fb); st3(M.kd, KA0 + 3 * b, inv_inertia(PK, kz, Tq));
+      // the three bars' tendon wrenches from the class sums (replicated), then lane b finishes bar b -- gravity, the gyroscopic torque and the
+      // inverse inertia are fp64 work that three lanes do side by side instead of every lane three times -- and stores it
+      V3<K> Fb[3], Tb[3];
+      {
+        const V3<FS> s0 = bcast3v<0>(Sfu), s1 = bcast3v<1>(Sfu), s2 = bcast3v<2>(Sfu);
+        Fb[0] = cvt3<K>(-(s0 + s1)); Fb[1] = cvt3<K>(s1 - s2); Fb[2] = cvt3<K>(s0 + s2);
+        const V3<K> a0 = bcast3v<0>(Sma), a1 = bcast3v<1>(Sma), a2 = bcast3v<2>(Sma), b0 = bcast3v<0>(Smb), b1 = bcast3v<1>(Smb), b2 = bcast3v<2>(Smb);
+        Tb[0] = -(a0 + a1); Tb[1] = b1 - a2; Tb[2] = b0 + b2;
+      }
+      {
+        const I bi = sel(Ro.r == 1, I(1), sel(Ro.r == 2, I(2), I(0)));
+        V3<K> Fm = pick_bar(bi, Fb);
+        const V3<K> Tm = pick_bar(bi, Tb);
+        Fm.z = Fm.z - PK.mass * PK.grav;
+        const V3<K> wk = cvt3<K>(ld3(M.fd, FW + 3 * bi)), kz = ld3(M.kd, KEZ + 3 * bi);
+        const V3<K> Tq = Tm + (-(PK.Izz - PK.Ixx) * dot(kz, wk)) * cross(wk, kz);  // gyroscopic
+        st3_rep(M.kd, KL0 + 3 * bi, imk * Fm); st3_rep(M.kd, KA0 + 3 * bi, inv_inertia(PK, kz, Tq));
         TGR_SCHED();
-      });
+      }
     }
     TGR_RSTAMP(1);
     TGR_PHASE(2); TGR_REARG();
@@ -1491,9 +1519,13 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     TGR_PHASE(3);
     const I p15 = to_int(M.xs.ld(XP15));  // (the roving slot's pair; -1: none)
     const Roles<F> Ro = lane_roles<F, MODEL>(p15);
-    DofC<F> dc;
-    dc.dof = Ro.is_dof; dc.ang = Ro.is_ang;
-    dc.e = mk<F>(sel(Ro.is_dof & (Ro.k == 0), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 1), F(S(1)), zero), sel(Ro.is_dof & (Ro.k == 2), F(S(1)), zero));
+    DofC<F> dc;  // (repeated in the upper half of the row, lanes 8..13: hess_add_slot works on a pair slot's two bodies side by side)
+    {
+      const I r8 = Ro.r & 7;
+      const I k8 = sel(r8 < 3, r8, r8 - 3);
+      dc.dof = r8 < 6; dc.ang = (r8 >= 3) & (r8 < 6); dc.upper = Ro.r >= 8;
+      dc.e = mk<F>(sel(dc.dof & (k8 == 0), F(S(1)), zero), sel(dc.dof & (k8 == 1), F(S(1)), zero), sel(dc.dof & (k8 == 2), F(S(1)), zero));
+    }
     // ---- my slot's residual jar at the current iterate, cone force
     RContact<F> cs;
     cs.n = ld3(M.cd, CN); cs.rA = ld3(M.cd, CRA); cs.rB = ld3(M.cd, CRB);
@@ -1545,33 +1577,50 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     const BMask am = ballot_of(cs.active);  // which slots are in use anywhere in the wavefront (once per iteration)
     const bool third = !MODEL && slots_in<0x7000u>(am);
     const bool rove = slot_in<15>(am);
-    K gn = kzero;  // g^T M^-1 g
-    F dn = zero;   // d^T M d: the scale of the forces the gradient is the difference of
+    K gn;   // g^T M^-1 g
+    F dn;   // d^T M d: the scale of the forces the gradient is the difference of
     F gd[3];
-    static_for<3>([&](auto bc) {
-      constexpr int b = decltype(bc)::value;
-      // (the slab reads of this bar go out before its sums, whose DPP chains cover their latency)
-      const V3<F> dl = ld3(M.fd, FDL + 3 * b), da = ld3(M.fd, FDA + 3 * b), ezb = ld3(M.fd, FEZ + 3 * b);
-      const V3<K> kez = ld3(M.kd, KEZ + 3 * b);
+    {
+      // Every lane forms the three bars' sums (the broadcasts they are made of are the same instruction for the whole row); from there
+      // on LANE b WORKS ON BAR b (lanes 3.. repeat bar 0): it stores the bar's wrench, forms the bar's gradient and its share of the two norms,
+      // and leaves the gradient in the slab, where the dof lanes pick it up transposed.  A third of the arithmetic of doing every bar on
+      // every lane, most of the slab traffic gone.
+      const I bi = sel(Ro.r == 1, I(1), sel(Ro.r == 2, I(2), I(0)));
+      // (the slab reads of my bar go out before the sums, whose DPP chains cover their latency)
+      const V3<F> dl = ld3(M.fd, FDL + 3 * bi), da = ld3(M.fd, FDA + 3 * bi), ezb = ld3(M.fd, FEZ + 3 * bi);
+      const V3<K> kez = ld3(M.kd, KEZ + 3 * bi);
       TGR_SCHED();
       V3<F> fcl, fca;
       K tax;
-      bar_sum<MODEL>(b, PfB, PtB, PtA, PkB, PkA, fB, tB, tA, tauB, tauA, third, rove, p15, fcl, fca, tax);
-      st3(M.fd, FFCL + 3 * b, fcl); st3(M.fd, FFCA + 3 * b, fca); M.kd.st(KTAX + b, tax);
+      bar_sum<MODEL>(0, PfB, PtB, PtA, PkB, PkA, fB, tB, tA, tauB, tauA, third, rove, p15, fcl, fca, tax);
+      static_for<2>([&](auto bc) {  // (a bar's sums are taken up at once: three sets of them alive together cost registers the kernel does not have)
+        constexpr int b = 1 + decltype(bc)::value;
+        V3<F> f_, t_;
+        K x_;
+        bar_sum<MODEL>(b, PfB, PtB, PtA, PkB, PkA, fB, tB, tA, tauB, tauA, third, rove, p15, f_, t_, x_);
+        const auto mine = bi == b;
+        fcl = sel3(mine, f_, fcl); fca = sel3(mine, t_, fca); tax = sel(mine, x_, tax);
+        TGR_SCHED();
+      });
+      st3_rep(M.fd, FFCL + 3 * bi, fcl); st3_rep(M.fd, FFCA + 3 * bi, fca); M.kd.st_rep(KTAX + bi, tax);
       // (SHIFT: dl, da are the iterate e; the full d = d_ref + e)
-      const V3<F> rl = SHIFT ? ld3(M.fd, FRL + 3 * b) : z3, ra = SHIFT ? ld3(M.fd, FRA + 3 * b) : z3;
+      const V3<F> rl = SHIFT ? ld3(M.fd, FRL + 3 * bi) : z3, ra = SHIFT ? ld3(M.fd, FRA + 3 * bi) : z3;
       const V3<F> fl_ = SHIFT ? rl + dl : dl, fa_ = SHIFT ? ra + da : da;
       const V3<F> gl = P.mass * fl_ - fcl;
-      const V3<F> Ida = SHIFT ? ld3(M.fd, FGA + 3 * b) + inertia_mul(P, ezb, da) : inertia_mul(P, ezb, da);
+      const V3<F> Ida = SHIFT ? ld3(M.fd, FGA + 3 * bi) + inertia_mul(P, ezb, da) : inertia_mul(P, ezb, da);
       V3<F> ga = Ida - fca;
-      dn = dn + P.mass * dot(fl_, fl_) + dot(Ida, fa_);
+      const F dnb = P.mass * dot(fl_, fl_) + dot(Ida, fa_);
       // M-norm of the residual: force and transverse torque in F, the axial torque from K
       const K gax = PK.Izz * dot(kez, SHIFT ? cvt3<K>(ra) + cvt3<K>(da) : cvt3<K>(da)) - tax;
       const F gz = dot(ezb, ga);
-      gn = gn + cvt<K>(im * dot(gl, gl) + (dot(ga, ga) - gz * gz) * P.iIxx) + gax * gax * PK.iIzz;
+      const K gnb = cvt<K>(im * dot(gl, gl) + (dot(ga, ga) - gz * gz) * P.iIxx) + gax * gax * PK.iIzz;
       ga = ga + (cvt<F>(gax) - gz) * ezb;  // the direction is solved for the same axial residual the test looks at
-      gd[b] = sel(Ro.is_dof, sel(Ro.is_ang, pick_comp(Ro.k, ga), pick_comp(Ro.k, gl)), zero);
-    });
+      st3_rep(M.fd, FG + 6 * bi, gl); st3_rep(M.fd, FG + 6 * bi + 3, ga);
+      gn = (bcast<0>(gnb) + bcast<1>(gnb)) + bcast<2>(gnb);
+      dn = (bcast<0>(dnb) + bcast<1>(dnb)) + bcast<2>(dnb);
+      const I ri = sel(Ro.is_dof, Ro.r, I(0));
+      for (int b = 0; b < 3; b++) gd[b] = sel(Ro.is_dof, M.fd.ld(FG + 6 * b + ri), zero);
+    }
     if (LAST) bar_force = rowsum(sel(Ro.is_pair | Ro.is_pair2 | Ro.is_rove, sqrt_(dot(o.fl, o.fl)), zero));
     // converged: the M^-1-norm of the gradient is below the tolerance -- or below what the arithmetic resolves of it: the gradient is the
     // difference of inertial and contact forces of size sqrt(d^T M d) (a hard contact onset: 1e3 sqrt(kg) m/s^2), each known to a few ulp
@@ -1586,13 +1635,16 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     TGR_PHASE(5);
     // ---- Hessian rows (dof role)
     RHess<F> H;
-    for (int b = 0; b < 3; b++) {
+    {
+      // my row of the mass matrix: m e for a linear dof, Ixx e + (Izz - Ixx) (e . z) z for an angular one -- the parts that do not depend on the
+      // bar are formed once
       const S dI = P.Izz - P.Ixx;
-      const V3<F> ezb = ld3(M.fd, FEZ + 3 * b);
-      const F ze = dot(dc.e, ezb);
-      const V3<F> lin = sel3(dc.ang, z3, P.mass * dc.e);
-      const V3<F> ang = sel3(dc.ang, P.Ixx * dc.e + (dI * ze) * ezb, z3);
-      H.D[b][0] = lin.x; H.D[b][1] = lin.y; H.D[b][2] = lin.z; H.D[b][3] = ang.x; H.D[b][4] = ang.y; H.D[b][5] = ang.z;
+      const V3<F> lin = sel3(dc.ang, z3, P.mass * dc.e), ixe = sel3(dc.ang, P.Ixx * dc.e, z3);
+      for (int b = 0; b < 3; b++) {
+        const V3<F> ezb = ld3(M.fd, FEZ + 3 * b);
+        const F t = sel(dc.ang, dI * dot(dc.e, ezb), zero);
+        H.D[b][0] = lin.x; H.D[b][1] = lin.y; H.D[b][2] = lin.z; H.D[b][3] = ixe.x + t * ezb.x; H.D[b][4] = ixe.y + t * ezb.y; H.D[b][5] = ixe.z + t * ezb.z;
+      }
     }
     for (int i = 0; i < 6; i++) { H.O10[i] = zero; H.O20[i] = zero; H.O21[i] = zero; }
     const BMask cm = ballot_of(o.cg != S(0));
@@ -1609,22 +1661,30 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     TGR_PHASE(6);
     // ---- direction p = -H^-1 g
     F pr[3][6], gHg;
-    newton_direction(H, gd, pr, gHg, cp0, cp1, cp2);
+    newton_direction(H, gd, pr, gHg, cp0, cp1, cp2, S(0.5) * P.mass, S(0.5) * P.Izz);
     const F d0 = sel(conv, zero, -gHg);  // p . g = -g^T H^-1 g
     TGR_RSTAMP(7);  // direction
     TGR_PHASE(7);
     // ---- line search: Gauss part (replicated), cone part (slot role)
+    // The Gauss part's two coefficients, bar by bar: lane b takes bar b (lanes 3.. repeat bar 0), three broadcasts bring the shares together.
+    // (Rows that have converged carry a zero step in the update below; what the line search computes for them in between is never used --
+    // alpha stays zero, ls_done is set from the start -- so only the step of my own bar is masked.)
     V3<F> pl[3], pa[3];
-    F g1 = zero, g2 = zero;
-    for (int b = 0; b < 3; b++) {
-      pl[b] = sel3(conv, z3, mk<F>(pr[b][0], pr[b][1], pr[b][2]));
-      pa[b] = sel3(conv, z3, mk<F>(pr[b][3], pr[b][4], pr[b][5]));
-      const V3<F> Ipa = inertia_mul(P, ld3(M.fd, FEZ + 3 * b), pa[b]);
-      if (SHIFT) g1 = g1 + P.mass * dot(pl[b], ld3(M.fd, FRL + 3 * b) + ld3(M.fd, FDL + 3 * b)) + (dot(pa[b], ld3(M.fd, FGA + 3 * b)) + dot(Ipa, ld3(M.fd, FDA + 3 * b)));
-      else g1 = g1 + P.mass * dot(pl[b], ld3(M.fd, FDL + 3 * b)) + dot(Ipa, ld3(M.fd, FDA + 3 * b));
-      g2 = g2 + P.mass * dot(pl[b], pl[b]) + dot(Ipa, pa[b]);
+    for (int b = 0; b < 3; b++) { pl[b] = mk<F>(pr[b][0], pr[b][1], pr[b][2]); pa[b] = mk<F>(pr[b][3], pr[b][4], pr[b][5]); }
+    const I bi_ = sel(Ro.r == 1, I(1), sel(Ro.r == 2, I(2), I(0)));
+    const V3<F> plb = sel3(conv, z3, pick_bar(bi_, pl)), pab = sel3(conv, z3, pick_bar(bi_, pa));
+    F g1, g2;
+    {
+      const V3<F> Ipa = inertia_mul(P, ld3(M.fd, FEZ + 3 * bi_), pab);
+      F g1b;
+      if (SHIFT) g1b = P.mass * dot(plb, ld3(M.fd, FRL + 3 * bi_) + ld3(M.fd, FDL + 3 * bi_)) + (dot(pab, ld3(M.fd, FGA + 3 * bi_)) + dot(Ipa, ld3(M.fd, FDA + 3 * bi_)));
+      else g1b = P.mass * dot(plb, ld3(M.fd, FDL + 3 * bi_)) + dot(Ipa, ld3(M.fd, FDA + 3 * bi_));
+      const F g2b = P.mass * dot(plb, plb) + dot(Ipa, pab);
+      g1 = (bcast<0>(g1b) + bcast<1>(g1b)) + bcast<2>(g1b);
+      g2 = (bcast<0>(g2b) + bcast<1>(g2b)) + bcast<2>(g2b);
     }
-    const V3<F> plA = pick_bar0(Ro.sA, pl), paA = pick_bar0(Ro.sA, pa), plB = pick_bar0(Ro.sB, pl), paB = pick_bar0(Ro.sB, pa);
+    // (a slot's body B always exists where the slot can be active; idle lanes -- sB < 0 -- take bar 2 and are masked by their inactive slot)
+    const V3<F> plA = pick_bar0(Ro.sA, pl), paA = pick_bar0(Ro.sA, pa), plB = pick_bar(Ro.sB, pl), paB = pick_bar(Ro.sB, pa);
     const V3<F> ql = (plB + cross(paB, cs.rB)) - (plA + cross(paA, cs.rA));
     const V3<F> qa = paB - paA;
     const RLSlot<F> ls = ls_make(cs, jl, ja, ql, qa);
@@ -1678,7 +1738,6 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     {
       // the iterate moves: lane b updates bar b (lanes 3.. repeat bar 0) and stores it -- every reader takes it from the slab
       const I bi = sel(Ro.r == 1, I(1), sel(Ro.r == 2, I(2), I(0)));
-      const V3<F> plb = pick_bar(bi, pl), pab = pick_bar(bi, pa);
       const V3<F> nl = ld3(M.fd, FDL + 3 * bi) + alpha * plb, na_ = ld3(M.fd, FDA + 3 * bi) + alpha * pab;
       st3_rep(M.fd, FDL + 3 * bi, nl); st3_rep(M.fd, FDA + 3 * bi, na_);
     }
@@ -1780,7 +1839,7 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     });
     TGR_SCHED();
     TGR_CENSUS(14);
-    rchol<9>(Sr, il9);
+    rchol<9>(Sr, il9, [](int) { return SW(0.5); });  // (the identity plus the dampers' positive semi-definite part)
     TGR_SCHED();
     W zr[9];
     rfwd<9>(Sr, il9, zt, zr);

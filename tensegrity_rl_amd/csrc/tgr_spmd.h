@@ -102,6 +102,8 @@ template <int CTRL> TGR_RDEV double dpp_(double x) {
 }
 // value of lane K of the row, in every lane of the row (row_newbcast:K)
 template <int K, typename T> TGR_RDEV T bcast(T x) { return dpp_<0x150 + K>(x); }
+// lane i < 8: x of lane i + 8 (row_shl:8; the upper lanes read zero) -- what the upper half of a row worked out, brought down to the lower
+template <typename T> TGR_RDEV T upper8(T x) { return dpp_<0x108>(x); }
 // sum over the 16 lanes of the row, in every lane (row_ror butterfly)
 template <typename T> TGR_RDEV T rowsum(T x) {
   x = x + dpp_<0x128>(x); x = x + dpp_<0x124>(x); x = x + dpp_<0x122>(x); x = x + dpp_<0x121>(x);
@@ -225,6 +227,7 @@ TGR_EMUL_FN(rcp_, T(1) / x) TGR_EMUL_FN(sqrt_, std::sqrt(x)) TGR_EMUL_FN(rsqrt_,
 template <typename T> inline Ln<int> to_int(const Ln<T>& a) { Ln<int> r; for (int i = 0; i < ROW; i++) r.v[i] = (int)a.v[i]; return r; }
 template <typename T> inline Ln<T> from_int(const Ln<int>& a, Ln<T>) { Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = (T)a.v[i]; return r; }
 template <int K, typename T> inline Ln<T> bcast(const Ln<T>& x) { op_tick<T>(); return Ln<T>(x.v[K]); }
+template <typename T> inline Ln<T> upper8(const Ln<T>& x) { op_tick<T>(); Ln<T> r; for (int i = 0; i < ROW; i++) r.v[i] = i + 8 < ROW ? x.v[i + 8] : T(0); return r; }
 template <typename T> inline Ln<T> rowsum(const Ln<T>& x) {  // same butterfly as the device's row_ror:8,4,2,1
   Ln<T> a = x, b;
   for (int s = 8; s >= 1; s >>= 1) { op_tick<T>(); for (int i = 0; i < ROW; i++) b.v[i] = a.v[i] + a.v[(i + s) & 15]; a = b; }
