@@ -1336,7 +1336,7 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
         any1 = hit1;
         if (M.dbg && sidx < TRACE_SUB) {
           // trace, second word of the sub-step: WHICH facets / grid edges the terrain contacts touch (the mask of active slots does not
-          // say) -- low 16 bits: the caps (a cap's two facets enter symmetrically), high 16 bits: the bars' cylinders; the oracle hashes its
+          // say) -- low 16 bits: the caps (a cap's two facets enter symmetrically), high 16 bits: the bars' cylinders; the CPU checker hashes its
           // own contacts the same way (tgo_feature_hash)
           auto mix = [&](I id) { return xshr(wmul(id + 1, I((int)2654435761u)), 15); };
           const I zi = I(0);
@@ -1515,9 +1515,11 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
   TGR_FENCE();
   TGR_RSTAMP(3);  // Newton set-up (warm start, slot into the slab)
   TGR_REARG();
+  // (the roving slot's pair; -1: none -- one register held across the loop: re-read from the slab at the head of every iteration it was a
+  // round trip through LDS that the lane roles, and with them every address of the iteration, waited for)
+  const I p15 = to_int(M.xs.ld(XP15));
   for (int it = 0;; it++) {
     TGR_PHASE(3);
-    const I p15 = to_int(M.xs.ld(XP15));  // (the roving slot's pair; -1: none)
     const Roles<F> Ro = lane_roles<F, MODEL>(p15);
     DofC<F> dc;  // (repeated in the upper half of the row, lanes 8..13: hess_add_slot works on a pair slot's two bodies side by side)
     {
@@ -1527,17 +1529,19 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
       dc.e = mk<F>(sel(dc.dof & (k8 == 0), F(S(1)), zero), sel(dc.dof & (k8 == 1), F(S(1)), zero), sel(dc.dof & (k8 == 2), F(S(1)), zero));
     }
     // ---- my slot's residual jar at the current iterate, cone force
-    RContact<F> cs;
-    cs.n = ld3(M.cd, CN); cs.rA = ld3(M.cd, CRA); cs.rB = ld3(M.cd, CRB);
-    cs.c0 = M.cd.ld(CC0); cs.Dn = M.cd.ld(CDN); cs.active = M.cd.ld(CACT) != S(0);
+    // (my slot: in registers since the contact stage -- it is read in every stage of the iteration, so holding it across the back edge costs
+    // nothing at the loop's peak, and re-reading it from the slab at the head of every iteration was twelve loads the cone evaluation waited for)
+    const RContact<F>& cs = c;
     // (the iterate at my slot's two bars, straight from the replicated iterate: a lane-dependent LDS address; a slot without a bar A -- floor
     // contacts -- takes zero there, an idle lane reads bar 0 and is masked by its inactive slot)
     const I jbi = sel(Ro.sB >= 0, Ro.sB, I(0)), jai = sel(Ro.sA >= 0, Ro.sA, I(0));
     const auto hasAi = Ro.sA >= 0;
     const V3<F> dLB = ld3(M.fd, FDL + 3 * jbi), dAB = ld3(M.fd, FDA + 3 * jbi);
     const V3<F> dLA = sel3(hasAi, ld3(M.fd, FDL + 3 * jai), z3), dAA = sel3(hasAi, ld3(M.fd, FDA + 3 * jai), z3);
-    const V3<F> jl = ld3(M.cd, CJL0) + ((dLB + cross(dAB, cs.rB)) - (dLA + cross(dAA, cs.rA)));
-    const V3<F> ja = ld3(M.cd, CJA0) + (dAB - dAA);
+    // (the residual at the start of the iteration: likewise in registers -- jl0, ja0 -- where the stage that forms it leaves it there; MODEL 1
+    // forms it in K at the reference iterate and parks it in the slab)
+    const V3<F> jl = (SHIFT ? ld3(M.cd, CJL0) : jl0) + ((dLB + cross(dAB, cs.rB)) - (dLA + cross(dAA, cs.rA)));
+    const V3<F> ja = (SHIFT ? ld3(M.cd, CJA0) : ja0) + (dAB - dAA);
     const RCone<F> o = cone_eval(P, cs, jl, ja);
     // MODEL 1, page 1: a cap's second terrain contact (same bar, no body A)
     RContact<F> cs1;
@@ -1580,6 +1584,7 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     K gn;   // g^T M^-1 g
     F dn;   // d^T M d: the scale of the forces the gradient is the difference of
     F gd[3];
+    V3<F> ez3[3];
     {
       // Every lane forms the three bars' sums (the broadcasts they are made of are the same instruction for the whole row); from there
       // on LANE b WORKS ON BAR b (lanes 3.. repeat bar 0): it stores the bar's wrench, forms the bar's gradient and its share of the two norms,
@@ -1589,6 +1594,9 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
       // (the slab reads of my bar go out before the sums, whose DPP chains cover their latency)
       const V3<F> dl = ld3(M.fd, FDL + 3 * bi), da = ld3(M.fd, FDA + 3 * bi), ezb = ld3(M.fd, FEZ + 3 * bi);
       const V3<K> kez = ld3(M.kd, KEZ + 3 * bi);
+      // (... and so do the three bar axes the Hessian's mass-matrix rows are made of: asked for at the head of the Hessian stage they were a
+      // round trip through LDS with nothing to cover it)
+      for (int b = 0; b < 3; b++) ez3[b] = ld3(M.fd, FEZ + 3 * b);
       TGR_SCHED();
       V3<F> fcl, fca;
       K tax;
@@ -1618,8 +1626,10 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
       st3_rep(M.fd, FG + 6 * bi, gl); st3_rep(M.fd, FG + 6 * bi + 3, ga);
       gn = (bcast<0>(gnb) + bcast<1>(gnb)) + bcast<2>(gnb);
       dn = (bcast<0>(dnb) + bcast<1>(dnb)) + bcast<2>(dnb);
+      // (lanes past the sixth read component 0 and are never looked at: the solves below take their right-hand sides from lanes 0..5 by
+      // broadcast.  No select on the loaded value -- its first use is in the forward solve, after the factorisation.)
       const I ri = sel(Ro.is_dof, Ro.r, I(0));
-      for (int b = 0; b < 3; b++) gd[b] = sel(Ro.is_dof, M.fd.ld(FG + 6 * b + ri), zero);
+      for (int b = 0; b < 3; b++) gd[b] = M.fd.ld(FG + 6 * b + ri);
     }
     if (LAST) bar_force = rowsum(sel(Ro.is_pair | Ro.is_pair2 | Ro.is_rove, sqrt_(dot(o.fl, o.fl)), zero));
     // converged: the M^-1-norm of the gradient is below the tolerance -- or below what the arithmetic resolves of it: the gradient is the
@@ -1641,14 +1651,23 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
       const S dI = P.Izz - P.Ixx;
       const V3<F> lin = sel3(dc.ang, z3, P.mass * dc.e), ixe = sel3(dc.ang, P.Ixx * dc.e, z3);
       for (int b = 0; b < 3; b++) {
-        const V3<F> ezb = ld3(M.fd, FEZ + 3 * b);
+        const V3<F> ezb = ez3[b];
         const F t = sel(dc.ang, dI * dot(dc.e, ezb), zero);
         H.D[b][0] = lin.x; H.D[b][1] = lin.y; H.D[b][2] = lin.z; H.D[b][3] = ixe.x + t * ezb.x; H.D[b][4] = ixe.y + t * ezb.y; H.D[b][5] = ixe.z + t * ezb.z;
       }
     }
     for (int i = 0; i < 6; i++) { H.O10[i] = zero; H.O20[i] = zero; H.O21[i] = zero; }
     const BMask cm = ballot_of(o.cg != S(0));
-    static_for<n_slots<MODEL>(0)>([&](auto cc) { hess_add_slot<MODEL, 0, decltype(cc)::value>(H, dc, cs, o, am, cm); });
+    // (the caps and the bar pairs' side-to-side slots one by one; the slots that are rarely in use -- a pair's other contacts: lanes 7, 9, 11 and,
+    // MODEL 0, 12..14: 0.3 % / 0.1 % of wavefronts each, profiles/round4_slot_census.log -- behind ONE test of the ballot: a skipped slot is a
+    // scalar test and a taken branch, and there are sixteen of them per iteration)
+    static_for<6>([&](auto cc) { hess_add_slot<MODEL, 0, decltype(cc)::value>(H, dc, cs, o, am, cm); });
+    static_for<3>([&](auto cc) { hess_add_slot<MODEL, 0, 6 + 2 * decltype(cc)::value>(H, dc, cs, o, am, cm); });
+    if (slots_in<MODEL ? 0x0a80u : 0x7a80u>(am)) {
+      static_for<3>([&](auto cc) { hess_add_slot<MODEL, 0, 7 + 2 * decltype(cc)::value>(H, dc, cs, o, am, cm); });
+      if (!MODEL) static_for<3>([&](auto cc) { hess_add_slot<MODEL, 0, 12 + decltype(cc)::value>(H, dc, cs, o, am, cm); });
+    }
+    if (MODEL) static_for<3>([&](auto cc) { hess_add_slot<MODEL, 0, 12 + decltype(cc)::value>(H, dc, cs, o, am, cm); });
     if (page1) {
       const BMask am1 = ballot_of(cs1.active), cm1 = ballot_of(o1.cg != S(0));
       static_for<6>([&](auto cc) { hess_add_slot<MODEL, 1, decltype(cc)::value>(H, dc, cs1, o1, am1, cm1); });
@@ -1661,6 +1680,9 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     TGR_PHASE(6);
     // ---- direction p = -H^-1 g
     F pr[3][6], gHg;
+    // (what the line search and the update read of my bar -- lane b: bar b -- is asked for here, before the factorisation that covers the trip)
+    const I bi_ = sel(Ro.r == 1, I(1), sel(Ro.r == 2, I(2), I(0)));
+    const V3<F> ezm = ld3(M.fd, FEZ + 3 * bi_), dlm = ld3(M.fd, FDL + 3 * bi_), dam = ld3(M.fd, FDA + 3 * bi_);
     newton_direction(H, gd, pr, gHg, cp0, cp1, cp2, S(0.5) * P.mass, S(0.5) * P.Izz);
     const F d0 = sel(conv, zero, -gHg);  // p . g = -g^T H^-1 g
     TGR_RSTAMP(7);  // direction
@@ -1671,14 +1693,13 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     // alpha stays zero, ls_done is set from the start -- so only the step of my own bar is masked.)
     V3<F> pl[3], pa[3];
     for (int b = 0; b < 3; b++) { pl[b] = mk<F>(pr[b][0], pr[b][1], pr[b][2]); pa[b] = mk<F>(pr[b][3], pr[b][4], pr[b][5]); }
-    const I bi_ = sel(Ro.r == 1, I(1), sel(Ro.r == 2, I(2), I(0)));
     const V3<F> plb = sel3(conv, z3, pick_bar(bi_, pl)), pab = sel3(conv, z3, pick_bar(bi_, pa));
     F g1, g2;
     {
-      const V3<F> Ipa = inertia_mul(P, ld3(M.fd, FEZ + 3 * bi_), pab);
+      const V3<F> Ipa = inertia_mul(P, ezm, pab);
       F g1b;
-      if (SHIFT) g1b = P.mass * dot(plb, ld3(M.fd, FRL + 3 * bi_) + ld3(M.fd, FDL + 3 * bi_)) + (dot(pab, ld3(M.fd, FGA + 3 * bi_)) + dot(Ipa, ld3(M.fd, FDA + 3 * bi_)));
-      else g1b = P.mass * dot(plb, ld3(M.fd, FDL + 3 * bi_)) + dot(Ipa, ld3(M.fd, FDA + 3 * bi_));
+      if (SHIFT) g1b = P.mass * dot(plb, ld3(M.fd, FRL + 3 * bi_) + dlm) + (dot(pab, ld3(M.fd, FGA + 3 * bi_)) + dot(Ipa, dam));
+      else g1b = P.mass * dot(plb, dlm) + dot(Ipa, dam);
       const F g2b = P.mass * dot(plb, plb) + dot(Ipa, pab);
       g1 = (bcast<0>(g1b) + bcast<1>(g1b)) + bcast<2>(g1b);
       g2 = (bcast<0>(g2b) + bcast<1>(g2b)) + bcast<2>(g2b);
@@ -1737,9 +1758,8 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
 #endif
     {
       // the iterate moves: lane b updates bar b (lanes 3.. repeat bar 0) and stores it -- every reader takes it from the slab
-      const I bi = sel(Ro.r == 1, I(1), sel(Ro.r == 2, I(2), I(0)));
-      const V3<F> nl = ld3(M.fd, FDL + 3 * bi) + alpha * plb, na_ = ld3(M.fd, FDA + 3 * bi) + alpha * pab;
-      st3_rep(M.fd, FDL + 3 * bi, nl); st3_rep(M.fd, FDA + 3 * bi, na_);
+      const V3<F> nl = dlm + alpha * plb, na_ = dam + alpha * pab;
+      st3_rep(M.fd, FDL + 3 * bi_, nl); st3_rep(M.fd, FDA + 3 * bi_, na_);
     }
     TGR_FENCE();
     TGR_RSTAMP(10);  // iterate update
