@@ -18,6 +18,10 @@
 namespace tgr {
 namespace row {
 
+#if defined(TGR_OTHERS_HIST) && !defined(TGR_ROW_EMUL)
+__device__ unsigned long long g_others_hist[64];
+#endif
+
 template <typename S> struct RParams {
   S h, grav, mass, Ixx, Izz;
   S cap_r, bar_half, rcyl_r, bcyl_r, bcyl_lo, bcyl_hi, site_off, site_z;
@@ -1397,6 +1401,15 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
         const auto mine = p15 == ((Ro.r - 6) >> 1);
         const F slots = sel(mine, F(S(MODEL ? 2 : 3)), F(S(MODEL ? 1 : 2)));
         dropped = sel(Ro.is_pair & s0 & (others > slots), others - slots, zero);
+#if defined(TGR_OTHERS_HIST) && !defined(TGR_ROW_EMUL)
+        // development aid: how many "other" contacts (besides the r-cylinders side to side) a bar pair has, per (env, pair, sub-step) that has any;
+        // [32 + k]: how many of an environment's pairs want more than the fixed slots at once
+        if (Ro.is_pair & s0 & (others > S(0))) atomicAdd(&g_others_hist[(int)min_(others, F(S(31)))], 1ull);
+        {
+          const F wants = rowsum(sel(Ro.is_pair & s0 & (others > F(S(MODEL ? 1 : 2))), F(S(1)), zero));
+          if ((Ro.r == 0) & (wants > S(0))) atomicAdd(&g_others_hist[32 + (int)wants], 1ull);
+        }
+#endif
       }
       // my slot's bars, now that lane 15 knows whose contact it carries
       const auto rove = s3 & (p15 >= 0);

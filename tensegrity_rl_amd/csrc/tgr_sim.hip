@@ -1962,6 +1962,13 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
   return TGR_OK;
 }
 
+#ifdef TGR_OTHERS_HIST
+extern "C" int tgr_debug_others_hist(unsigned long long* out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(tgr::row::g_others_hist), sizeof(unsigned long long) * 64);
+  return 0;
+}
+#endif
 #ifdef TGR_WAVE_TIMES
 extern "C" int tgr_debug_wave_times(unsigned long long* out, int n_waves) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(tgr::g_wave_times), sizeof(unsigned long long) * 4 * n_waves);
