@@ -21,8 +21,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROFILE = os.path.join(ROOT, "profiles", "round3_bench_rocprofv3_summary.json")
-CENSUS = os.path.join(ROOT, "profiles", "round3_lane_census.json")
+PROFILE = os.path.join(ROOT, "profiles", "round4_bench_rocprofv3_summary.json")
+CENSUS = os.path.join(ROOT, "profiles", "round4_lane_census.json")
 
 
 def profiled():
@@ -57,7 +57,7 @@ HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); measured co
 
 def useful_lane_fraction():
     """Share of the lanes of a VALU instruction of the step kernel that own distinct work (the rest replicate a value or idle in their role):
-    from the operation census of the host emulation of the same kernel source (tests/emul_census.py -> profiles/round3_lane_census.json)."""
+    from the operation census of the host emulation of the same kernel source (tests/emul_census.py -> profiles/round4_lane_census.json)."""
     try:
         return float(json.load(open(CENSUS))["useful_lane_frac"])
     except Exception:

@@ -237,10 +237,9 @@ int tgr_set_seed(tgr_handle* h, uint64_t seed);
 int tgr_bind_real_observation(tgr_handle* h, void* real_obs_dev);
 /* diagnostic (accuracy classification, tests/gpu_accuracy_report.py): bind a DEVICE buffer uint32 [N][TGR_TRACE_WORDS] (caller-owned, valid
  * until unbound with NULL); every tgr_step of a row-kernel handle then records, per env and sub-step s < frame_skip, word s =
- * contact slots instantiated in the forward pass of that sub-step (bit c < 6: cap c on the floor; 6 + 2p / 7 + 2p: the r-cylinders of bar
- * pair p side to side / any other contact of the pair; 12 + p (flat floor): a second such other contact of pair p; 12 + b (heightfield):
- * bar b's cylinder on the terrain; 15: the roving slot -- the next other contact (flat floor: the third, heightfield: the second) of the
- * first bar pair that has one; 16 + c: cap c on a second facet)
+ * contact slots instantiated in the forward pass of that sub-step (bit c < 6: cap c on the floor; 6 + 2p: the r-cylinders of bar pair p
+ * side to side; every OTHER contact between two bars, whichever pair: the next bit of the pool 7, 9, 11, 12, 13, 14, 15 (heightfield:
+ * 7, 9, 11, 15); 12 + b (heightfield): bar b's cylinder on the terrain; 16 + c: cap c on a second facet)
  * | (Newton iterations the env itself needed so far this step, mod 256) << 22 | (the solver left this sub-step at its iteration cap) << 30
  * | (its line search stalled at working precision) << 31;
  * and (heightfield model) word 24 + s = WHICH facets and grid edges those terrain contacts touch, hashed: low 16 bits the caps' facets

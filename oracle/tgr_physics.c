@@ -984,14 +984,16 @@ uint32_t tgo_contact_mask(const tgo_model* m, const tgo_data* d) {
       const int p = A == 0 ? (B == 1 ? 0 : 1) : 2;
       const int g1 = c->geom1 - 1 - 5 * c->body1, g2 = c->geom2 - 1 - 5 * c->body2;
       if (g1 == 0 && g2 == 0) mask |= 1u << (6 + 2 * p);
-      else if (others[p]++ == 0) mask |= 1u << (7 + 2 * p);
-      else if (!m->hf_data && others[p] == 2) mask |= 1u << (12 + p); /* flat-floor model: the row kernels keep a second one of these on lane 12 + p */
+      else others[p]++;
     }
   }
-  /* bit 15: the row kernels' roving slot (lane 15) -- the next "other" contact (flat floor: the third, heightfield: the second) of the
-   * FIRST bar pair that has one */
-  for (int p = 0; p < 3; p++)
-    if (others[p] >= (m->hf_data ? 2 : 3)) { mask |= 1u << 15; break; }
+  /* every OTHER contact between two bars takes the next lane of the row kernels' POOL, whichever pair it belongs to (tgr_row.h: flat floor
+   * lanes 7, 9, 11, 12..15; heightfield, whose lanes 12..14 carry the bars' terrain contacts: 7, 9, 11, 15) */
+  {
+    static const int pool0[7] = {7, 9, 11, 12, 13, 14, 15}, pool1[4] = {7, 9, 11, 15};
+    const int np = m->hf_data ? 4 : 7, total = others[0] + others[1] + others[2];
+    for (int i = 0; i < total && i < np; i++) mask |= 1u << (m->hf_data ? pool1[i] : pool0[i]);
+  }
   return mask;
 }
 

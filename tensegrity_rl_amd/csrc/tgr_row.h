@@ -61,20 +61,20 @@ constexpr int ten_ba(int t) { return RTab::TEN0[t][0]; }  // the bars of a tendo
 constexpr int ten_bb(int t) { return RTab::TEN0[t][2]; }
 constexpr int pair_a(int p) { return p == 2 ? 1 : 0; }    // bar pairs (A,B): (0,1), (0,2), (1,2)
 constexpr int pair_b(int p) { return p == 0 ? 1 : 2; }
-// contact slot c of page 0: 0..5 cap c on the floor, 6..11 sub-slot (c-6)&1 of pair (c-6)>>1 (sub-slot 0: the r-cylinders side to side, 1: the
-// deepest of every other contact of the two bars), 12..14 -- MODEL 0: the second deepest of those other contacts of pair c-12 (a bar
-// crossing deeper than 3.1 mm touches the b-cylinder inside the r-cylinder as well: mujoco keeps every geom pair), MODEL 1: rod of bar c-12
-// on the terrain; 15: the ROVING slot -- the next deepest "other" contact (MODEL 0: the third, MODEL 1: the second) of the first bar pair
-// that has one; which pair that is (p15) is a run-time value of the environment, kept in the xs slab, and the bars of lane 15 follow it
+// contact slot c of page 0: 0..5 cap c on the floor; 6, 8, 10: the r-cylinders of bar pair (c-6)>>1 side to side; MODEL 1: 12..14 rod of bar
+// c-12 on the terrain; the POOL -- MODEL 0: lanes 7, 9, 11, 12..15, MODEL 1: 7, 9, 11, 15 -- every OTHER contact between two bars (a crossing
+// deeper than 3.1 mm touches the b-cylinders inside the r-cylinders as well, bar ends meet cap to cap or cap to cylinder: mujoco keeps
+// every geom pair), whichever pair it belongs to: the pair a pool lane serves (pl) is a run-time value of the lane, and its bars follow it
 // (lane_roles); page 1 (MODEL 1 only): 0..5 second terrain contact of cap c
+template <int MODEL> constexpr unsigned pool_mask() { return MODEL ? 0x8a80u : 0xfa80u; }
+template <int MODEL> constexpr int pool_size() { return MODEL ? 4 : 7; }
 template <int MODEL> constexpr int slot_bar_a(int page, int c) {
-  return page != 0 ? -1 : ((c >= 6 && c < 12) ? pair_a((c - 6) >> 1) : ((!MODEL && c >= 12 && c < 15) ? pair_a(c - 12) : -1));
+  return page != 0 ? -1 : ((c == 6 || c == 8 || c == 10) ? pair_a((c - 6) >> 1) : -1);
 }
 template <int MODEL> constexpr int slot_bar_b(int page, int c) {
-  return c < 6 ? (c >> 1) : (page != 0 ? -1 : (c < 12 ? pair_b((c - 6) >> 1) : (c < 15 ? (MODEL ? c - 12 : pair_b(c - 12)) : -1)));
+  return c < 6 ? (c >> 1) : (page != 0 ? -1 : ((c == 6 || c == 8 || c == 10) ? pair_b((c - 6) >> 1) : ((MODEL && c >= 12 && c < 15) ? c - 12 : -1)));
 }
 template <int MODEL> constexpr int n_pages() { return MODEL ? 2 : 1; }
-template <int MODEL> constexpr int n_slots(int page) { return page == 0 ? 15 : (MODEL ? 6 : 0); }  // (fixed-bar slots; lane 15: hess_add_roving)
 
 // ------------------------------------------------------------------ replicated state of one environment
 // K: the lane type of pose, kinematics, tendon geometry and smooth forces (double in the mixed-precision production kernels: a tendon
@@ -143,7 +143,7 @@ template <typename F> struct Roles {
   // tendon role (its K constants -- site coordinates, stiffness, damping, spring length -- live in the role slab)
   B is_ten; I ba, bb; B actuated;
   // slot role (page 0)
-  B is_cap, is_pair, is_pair2, is_rod, is_rove; I sub; I sA, sB; F cap_sign;
+  B is_cap, is_side, is_pool, is_rod, pooled; I sA, sB; F cap_sign;  // pooled: a pool lane that carries a contact
   // dof role
   B is_dof, is_ang; I k;
 };
@@ -171,8 +171,8 @@ template <typename K, typename F, typename SK, int MODEL> TGR_RDEV void store_ro
 }
 // what lane r does: pure arithmetic on the lane number, recomputed where it is needed (a role kept in a register for the whole kernel
 // costs more than the few instructions that rebuild it)
-// p15: the bar pair lane 15's roving slot serves in this sub-step (replicated; < 0: none)
-template <typename F, int MODEL> TGR_RDEV Roles<F> lane_roles(typename LaneTraits<F>::I p15 = typename LaneTraits<F>::I(-1)) {
+// pl: the bar pair a POOL lane's contact belongs to in this sub-step (a lane value; < 0: none)
+template <typename F, int MODEL> TGR_RDEV Roles<F> lane_roles(typename LaneTraits<F>::I pl = typename LaneTraits<F>::I(-1)) {
   typedef typename LaneTraits<F>::I I;
   typedef typename LaneTraits<F>::S S;
   Roles<F> R;
@@ -185,13 +185,12 @@ template <typename F, int MODEL> TGR_RDEV Roles<F> lane_roles(typename LaneTrait
   R.bb = sel((r == 1) | (r == 4) | (r == 7), I(1), I(2));
   R.actuated = r < 6;
   R.is_cap = r < 6;
-  R.is_pair = (r >= 6) & (r < 12);
+  R.is_side = (r == 6) | (r == 8) | (r == 10);
   R.is_rod = MODEL ? ((r >= 12) & (r < 15)) : (r < 0);
-  R.is_pair2 = MODEL ? (r < 0) : ((r >= 12) & (r < 15));  // third slot of a bar pair (flat-floor model)
-  R.is_rove = (r == 15) & (p15 >= 0);
-  const I pr = sel(R.is_rove, p15, sel(R.is_pair2, r - 12, (r - 6) >> 1));
-  const auto anypair = R.is_pair | R.is_pair2 | R.is_rove;
-  R.sub = (r - 6) & 1;
+  R.is_pool = (r == 7) | (r == 9) | (r == 11) | (MODEL ? (r == 15) : (r >= 12));
+  R.pooled = R.is_pool & (pl >= 0);
+  const I pr = sel(R.pooled, pl, (r - 6) >> 1);
+  const auto anypair = R.is_side | R.pooled;
   R.sA = sel(anypair, sel(pr == 2, I(1), I(0)), I(-1));
   R.sB = sel(R.is_cap, r >> 1, sel(anypair, sel(pr == 0, I(1), I(2)), sel(R.is_rod, r - 12, I(-1))));
   R.cap_sign = sel((r & 1) == 0, F(S(1)), F(S(-1)));
@@ -275,36 +274,23 @@ template <typename F, typename S> TGR_RDEV RCone<F> cone_eval(const RParams<S>& 
   return o;
 }
 
-// ---- contact geometry between two bars (slot role, pair lanes); same rules as tgr_device.h bar_pair_contacts
-template <typename F> struct RCand { F dist; V3<F> n, p; typename LaneTraits<F>::B ok; };
-// the deepest, the second and the third deepest of the candidates seen so far
-template <typename F> struct RCands { RCand<F> best, second, third; F count; };
-template <typename F, typename B> TGR_RDEV void keep_deeper(RCands<F>& k, F dist, V3<F> n, V3<F> p, B valid) {
-  typedef typename LaneTraits<F>::S S;
-  RCand<F>& best = k.best; RCand<F>& second = k.second; RCand<F>& third = k.third;
-  auto hit = valid & (dist < S(0));
-  k.count = k.count + sel(hit, F(S(1)), F(S(0)));
-  auto first = hit & (!best.ok | (dist < best.dist));
-  auto sec = hit & !first & (!second.ok | (dist < second.dist));
-  auto thr = hit & !first & !sec & (!third.ok | (dist < third.dist));
-  {
-    const auto push = first | sec;  // the old second moves down
-    third.dist = sel(push, second.dist, sel(thr, dist, third.dist));
-    third.n = sel3(push, second.n, sel3(thr, n, third.n));
-    third.p = sel3(push, second.p, sel3(thr, p, third.p));
-    third.ok = (push & second.ok) | ((!push) & (third.ok | thr));
-  }
-  second.dist = sel(first, best.dist, sel(sec, dist, second.dist));
-  second.n = sel3(first, best.n, sel3(sec, n, second.n));
-  second.p = sel3(first, best.p, sel3(sec, p, second.p));
-  second.ok = (first & best.ok) | ((!first) & (second.ok | sec));
-  best.dist = sel(first, dist, best.dist);
-  best.n = sel3(first, n, best.n);
-  best.p = sel3(first, p, best.p);
-  best.ok = best.ok | hit;
-}
-template <typename F, typename S, typename B>
-TGR_RDEV void sphere_vs_bar(const RParams<S>& P, F capr, V3<F> c, V3<F> xo, V3<F> zo, bool flip, B enable, RCands<F>& cands) {
+// ---- contact geometry between two bars (slot role); same rules as tgr_device.h bar_pair_contacts.
+// A pair of bars has ONE side-to-side contact of its r-cylinders (a fixed slot: lanes 6, 8, 10) and any number of OTHER contacts -- cap
+// against cap, cap against a cylinder, b-cylinders inside the r-cylinders of a deep crossing: 24 candidate geometries -- which mujoco keeps
+// all of.  The others go to a POOL of lanes that carry the contact of a run-time pair (MODEL 0: lanes 7, 9, 11, 12..15; MODEL 1: 7, 9, 11,
+// 15), handed out in the order (rank by depth, pair).  The candidates are enumerated once per rank -- pick the next one in the order
+// (distance, candidate number) after the previous pick -- instead of keeping the k deepest in registers: k is whatever the pool holds, the
+// enumeration is only entered by the wavefronts that have such a contact at all (one sub-step in a hundred), and a pick is routed to its pool
+// lane the moment it is made.  (Until round 4: three fixed ranks per pair + one roving lane; a bar crossing deeper than 6 mm near the caps
+// has four to six others -- profiles/round4_other_contacts_histogram.log -- and the rest was dropped and counted.)
+template <typename F> struct RPairGeom {
+  typedef typename LaneTraits<F>::B B;
+  V3<F> xA, zA, xB, zB, pa, n;
+  F s, t, dd, capr;
+  B near_, okdir, more;  // more: the pair may have other contacts than the side-to-side one (a deep crossing, or bar ends within reach)
+};
+template <typename F, typename S, typename B, typename V>
+TGR_RDEV void sphere_vs_bar(const RParams<S>& P, F capr, V3<F> c, V3<F> xo, V3<F> zo, bool flip, B enable, V&& visit) {
   V3<F> wv = c - xo;
   F t = dot(wv, zo);
   V3<F> rad = wv - t * zo;
@@ -327,21 +313,22 @@ TGR_RDEV void sphere_vs_bar(const RParams<S>& P, F capr, V3<F> c, V3<F> xo, V3<F
     V3<F> pos = c + (capr + S(0.5) * dist) * n;
     auto valid = enable & sel(inside, rho > S(1e-12), dd > S(1e-12));
     V3<F> nn = flip ? -n : n;
-    keep_deeper(cands, dist, nn, pos, valid);
+    visit(dist, nn, pos, valid);
   }
 }
-// c0: r-cylinder against r-cylinder (side-side; kept as a candidate up to near0 above touching); c1, c2, c3: the deepest, the second and the
-// third deepest of everything else; count: how many of those others there are in all (the caller knows how many slots it has for them)
+// the geometry the two bars share, and c0: r-cylinder against r-cylinder side to side (kept as a candidate up to near0 above touching: the
+// caller decides on a distance formed in K).  lanes: the lanes whose outcome is used (they alone steer the wavefront-uniform early exits)
 template <typename F, typename S>
-TGR_RDEV void bar_pair_contacts(const RParams<S>& P, F capr, V3<F> xA, V3<F> zA, V3<F> xB, V3<F> zB, typename LaneTraits<F>::B lanes,
-                                RContact<F>& c0, RContact<F>& c1, RContact<F>& c2, RContact<F>& c3, F& count, S near0 = S(0)) {
+TGR_RDEV RPairGeom<F> pair_side_contact(const RParams<S>& P, F capr, V3<F> xA, V3<F> zA, V3<F> xB, V3<F> zB, typename LaneTraits<F>::B lanes,
+                                        RContact<F>& c0, S near0 = S(0)) {
   typedef typename LaneTraits<F>::B B;
   const F zero = F(S(0));
-  c0.active = B(false); c1.active = B(false); c2.active = B(false); c3.active = B(false);
-  c0.n = mk<F>(zero, zero, F(S(1))); c1.n = c0.n; c2.n = c0.n; c3.n = c0.n;
-  c0.rA = mk<F>(zero, zero, zero); c0.rB = c0.rA; c1.rA = c0.rA; c1.rB = c0.rA; c2.rA = c0.rA; c2.rB = c0.rA; c3.rA = c0.rA; c3.rB = c0.rA;
-  c0.c0 = zero; c1.c0 = zero; c2.c0 = zero; c3.c0 = zero; c0.Dn = zero; c1.Dn = zero; c2.Dn = zero; c3.Dn = zero;
-  count = zero;
+  RPairGeom<F> G;
+  G.xA = xA; G.zA = zA; G.xB = xB; G.zB = zB; G.capr = capr;
+  c0.active = B(false);
+  c0.n = mk<F>(zero, zero, F(S(1)));
+  c0.rA = mk<F>(zero, zero, zero); c0.rB = c0.rA;
+  c0.c0 = zero; c0.Dn = zero;
   V3<F> wv = xA - xB;
   F b = dot(zA, zB), dA = dot(zA, wv), dB = dot(zB, wv);
   F den = S(1) - b * b;
@@ -354,20 +341,20 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, F capr, V3<F> xA, V3<F> zA,
   F idd = rcp_(max_(dd, F(S(1e-30))));
   V3<F> n = idd * dif;
   auto okdir = skew & (dd > S(1e-9));
-  B near_;
+  G.s = s; G.t = t; G.dd = dd; G.pa = pa; G.n = n; G.okdir = okdir; G.more = B(false);
   {
     F sc = clamp_(sel(skew, s, zero), F(-P.bar_half), F(P.bar_half));
     F tc = clamp_(dB + b * sc, F(-P.bar_half), F(P.bar_half));
     sc = clamp_(b * tc - dA, F(-P.bar_half), F(P.bar_half));
     V3<F> dv = (xB + tc * zB) - (xA + sc * zA);
     const F reach = S(2) * capr + S(1e-6);
-    near_ = lanes & (dot(dv, dv) <= reach * reach);
+    G.near_ = lanes & (dot(dv, dv) <= reach * reach);
   }
-  if (!any_lane(near_)) return;
+  if (!any_lane(G.near_)) return G;
   {
-    auto interior = near_ & okdir & (abs_(s) < P.bar_half) & (abs_(t) < P.bar_half);
+    auto interior = G.near_ & okdir & (abs_(s) < P.bar_half) & (abs_(t) < P.bar_half);
     F dist = dd - S(2) * P.rcyl_r;
-    auto hit = interior & (dist < near0);  // (near0 > 0: a candidate; the caller decides on a distance formed in K)
+    auto hit = interior & (dist < near0);
     c0.active = hit;
     c0.n = sel3(hit, n, c0.n);
     V3<F> pos = pa + (P.rcyl_r + S(0.5) * dist) * n;
@@ -376,7 +363,7 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, F capr, V3<F> xA, V3<F> zA,
     contact_params(P, sel(hit, dist, zero), S(2), cc, dn);
     c0.c0 = sel(hit, cc, zero); c0.Dn = sel(hit, dn, zero);
   }
-  auto deep = near_ & okdir & (dd - S(2) * P.rcyl_r < -(P.rcyl_r - P.bcyl_r));
+  auto deep = G.near_ & okdir & (dd - S(2) * P.rcyl_r < -(P.rcyl_r - P.bcyl_r));
   B ends = B(false);
   {
     const F reach2 = (S(2) * capr + S(1e-6)) * (S(2) * capr + S(1e-6));
@@ -390,54 +377,62 @@ TGR_RDEV void bar_pair_contacts(const RParams<S>& P, F capr, V3<F> xA, V3<F> zA,
       V3<F> db = eb - tb * zA;
       ends = ends | (dot(da, da) <= reach2) | (dot(db, db) <= reach2);
     }
-    ends = ends & near_;
+    ends = ends & G.near_;
   }
-  if (!any_lane(deep | ends)) return;
-  RCands<F> cands;
-  cands.best.ok = B(false); cands.best.dist = zero; cands.best.n = c0.n; cands.best.p = xA;
-  cands.second = cands.best; cands.third = cands.best;
-  cands.count = zero;
+  G.more = deep | ends;
+  return G;
+}
+// every OTHER candidate contact of the pair, in a fixed order: visit(distance, normal A -> B, position, valid)
+template <typename F, typename S, typename V> TGR_RDEV void pair_other_candidates(const RParams<S>& P, const RPairGeom<F>& G, V&& visit) {
+  const V3<F> xA = G.xA, zA = G.zA, xB = G.xB, zB = G.zB;
   const S bc = S(0.5) * (P.bcyl_hi + P.bcyl_lo), bh = S(0.5) * (P.bcyl_hi - P.bcyl_lo);
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
       if (i == 0 && j == 0) continue;
       const S ci = i == 0 ? S(0) : (i == 1 ? bc : -bc), hi_ = i == 0 ? P.bar_half : bh, ri = i == 0 ? P.rcyl_r : P.bcyl_r;
       const S cj = j == 0 ? S(0) : (j == 1 ? bc : -bc), hj_ = j == 0 ? P.bar_half : bh, rj = j == 0 ? P.rcyl_r : P.bcyl_r;
-      auto interior = near_ & okdir & (abs_(s - ci) < hi_) & (abs_(t - cj) < hj_);
-      F dist = dd - (ri + rj);
-      V3<F> pos = pa + (ri + S(0.5) * dist) * n;
-      keep_deeper(cands, dist, n, pos, interior);
+      auto interior = G.near_ & G.okdir & (abs_(G.s - ci) < hi_) & (abs_(G.t - cj) < hj_);
+      F dist = G.dd - (ri + rj);
+      V3<F> pos = G.pa + (ri + S(0.5) * dist) * G.n;
+      visit(dist, G.n, pos, interior);
     }
   for (int ea = 0; ea < 2; ea++) {
     V3<F> ca = xA + (ea == 0 ? P.bar_half : -P.bar_half) * zA;
-    sphere_vs_bar(P, capr, ca, xB, zB, false, near_, cands);
+    sphere_vs_bar(P, G.capr, ca, xB, zB, false, G.near_, visit);
     for (int eb = 0; eb < 2; eb++) {
       V3<F> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
       V3<F> dv = cb - ca;
       F cd = sqrt_(dot(dv, dv));
-      F dist = cd - S(2) * capr;
+      F dist = cd - S(2) * G.capr;
       V3<F> nn = rcp_(max_(cd, F(S(1e-30)))) * dv;
-      V3<F> pos = ca + (capr + S(0.5) * dist) * nn;
-      keep_deeper(cands, dist, nn, pos, near_ & (cd > S(1e-12)));
+      V3<F> pos = ca + (G.capr + S(0.5) * dist) * nn;
+      visit(dist, nn, pos, G.near_ & (cd > S(1e-12)));
     }
   }
   for (int eb = 0; eb < 2; eb++) {
     V3<F> cb = xB + (eb == 0 ? P.bar_half : -P.bar_half) * zB;
-    sphere_vs_bar(P, capr, cb, xA, zA, true, near_, cands);
+    sphere_vs_bar(P, G.capr, cb, xA, zA, true, G.near_, visit);
   }
-  auto take = [&](const RCand<F>& k, RContact<F>& c) {
-    auto hit = k.ok;
-    c.active = hit;
-    c.n = sel3(hit, k.n, c.n);
-    c.rA = sel3(hit, k.p - xA, c.rA); c.rB = sel3(hit, k.p - xB, c.rB);
-    F cc, dn;
-    contact_params(P, sel(hit, k.dist, zero), S(2), cc, dn);
-    c.c0 = sel(hit, cc, zero); c.Dn = sel(hit, dn, zero);
-  };
-  take(cands.best, c1);
-  take(cands.second, c2);
-  take(cands.third, c3);
-  count = cands.count;
+}
+// the next candidate in the order (distance, candidate number) after (prev_d, prev_i); count (first call only: prev_i < 0): how many there are
+template <typename F> struct RPick { F dist; V3<F> n, p; typename LaneTraits<F>::I idx; typename LaneTraits<F>::B ok; F count; };
+template <typename F, typename S>
+TGR_RDEV RPick<F> pair_next_other(const RParams<S>& P, const RPairGeom<F>& G, F prev_d, typename LaneTraits<F>::I prev_i) {
+  typedef typename LaneTraits<F>::I I;
+  typedef typename LaneTraits<F>::B B;
+  RPick<F> k;
+  k.ok = B(false); k.dist = F(S(0)); k.n = G.n; k.p = G.xA; k.idx = I(-1); k.count = F(S(0));
+  int idx = 0;
+  pair_other_candidates(P, G, [&](F dist, V3<F> n, V3<F> pos, B valid) {
+    const auto hit = valid & (dist < S(0));
+    k.count = k.count + sel(hit, F(S(1)), F(S(0)));
+    const auto after = (dist > prev_d) | ((dist == prev_d) & (prev_i < idx));
+    const auto better = hit & after & (!k.ok | (dist < k.dist));  // (of equally deep ones the first in the enumeration)
+    k.dist = sel(better, dist, k.dist); k.n = sel3(better, n, k.n); k.p = sel3(better, pos, k.p); k.idx = sel(better, I(idx), k.idx);
+    k.ok = k.ok | better;
+    idx++;
+  });
+  return k;
 }
 
 // ------------------------------------------------------------------ heightfield floor (MODEL 1), slot role, select form
@@ -966,16 +961,17 @@ TGR_RDEV void hess_add_slot(RHess<F>& H, const DofC<F>& d, const RContact<F>& c,
   }
 }
 
-// the roving slot of lane 15: its bar pair is a run-time value of the environment (p15), so each of the three pairs is handled under a mask
-// (environments whose slot serves another pair add zero), and a pair nobody in the wavefront routes to lane 15 is skipped
+// a POOL lane's slot: its bar pair is a run-time value of the environment (plC: lane C's pl, broadcast), so each of the three pairs is handled
+// under a mask (environments whose slot serves another pair add zero), and a pair nobody in the wavefront routes to this lane is skipped
 template <typename F> TGR_RDEV void row_acc_masked(F* R, V3<F> wl, V3<F> wa, V3<F> arm, F m) {  // m: +1, -1 or 0
   V3<F> t = cross(arm, wl) + wa;
   R[0] = R[0] + m * wl.x; R[1] = R[1] + m * wl.y; R[2] = R[2] + m * wl.z; R[3] = R[3] + m * t.x; R[4] = R[4] + m * t.y; R[5] = R[5] + m * t.z;
 }
-template <typename F, typename I>
-TGR_RDEV void hess_add_roving(RHess<F>& H, const DofC<F>& d, const RContact<F>& c, const RCone<F>& o, I p15, BMask cm) {
+template <int C, typename F, typename I>
+TGR_RDEV void hess_add_pool(RHess<F>& H, const DofC<F>& d, const RContact<F>& c, const RCone<F>& o, I pl, BMask am, BMask cm) {
   typedef typename LaneTraits<F>::S S;
-  constexpr int C = 15;
+  if (!slot_in<C>(am)) return;
+  const I plC = bcast<C>(pl);
   SlotB<F> s;
   s.n = bcast3<C>(c.n); s.rA = bcast3<C>(c.rA); s.rB = bcast3<C>(c.rB);
   s.a1 = bcast<C>(o.a1); s.a2 = bcast<C>(o.a2); s.b1 = bcast<C>(o.b1); s.b2 = bcast<C>(o.b2);
@@ -989,7 +985,7 @@ TGR_RDEV void hess_add_roving(RHess<F>& H, const DofC<F>& d, const RContact<F>& 
   static_for<3>([&](auto pc) {
     constexpr int p = decltype(pc)::value;
     constexpr int A = pair_a(p), Bb = pair_b(p);
-    const auto mine = p15 == p;
+    const auto mine = plC == p;
     if (!any_lane(mine)) return;
     const F m = sel(mine, F(S(1)), F(S(0)));
     row_acc_masked(H.D[Bb], wlB, waB, s.rB, m);
@@ -1050,43 +1046,46 @@ template <typename F, typename S_> TGR_RDEV void newton_direction(RHess<F>& H, c
   rbwd_rep<6>(H.D[0], il0, yr0, pr[0]);
 }
 
-// constraint wrench on bar b from the neighbour sums of the slot lanes (P*: pairsum over lanes 2j, 2j+1; *B: as body B, *A: as body A of
-// a pair slot).  Pairs (A, B): lanes 6,7 = (0,1); 8,9 = (0,2); 10,11 = (1,2).  MODEL 1: bar b's cylinder slot on lane 12 + b (no neighbour).
+// constraint wrench on bar b.  The caps of bar b sit on lanes 2b, 2b+1: PfB / PtB / PkB are their neighbour sums (pairsum); the side-to-side
+// slot of pair (A, B) = (0,1), (0,2), (1,2) on lane 6, 8, 10 pushes bar B with +f and bar A with -f; MODEL 1: bar b's cylinder slot on lane
+// 12 + b; a pool lane in use (am: the wavefront's ballot of active slots) serves the pair its pl names.  (An idle slot carries zero force.)
 template <int L, typename F> TGR_RDEV V3<F> bcast3v(V3<F> a) { return mk<F>(bcast<L>(a.x), bcast<L>(a.y), bcast<L>(a.z)); }
-// MODEL 0: the third slot of pair (0,1) / (0,2) / (1,2) sits alone on lane 12 / 13 / 14; `third`: does any environment of the wavefront use one?
-// rove / p15: does any environment of the wavefront use the roving slot (lane 15), and which pair does it serve in THIS environment
 template <int MODEL, typename K, typename F, typename I>
-TGR_RDEV void bar_sum(int b, V3<F> PfB, V3<F> PtB, V3<F> PtA, K PkB, K PkA, V3<F> fB, V3<F> tB, V3<F> tA, K tauB, K tauA, bool third, bool rove, I p15,
-                      V3<F>& f, V3<F>& t, K& tax) {
+TGR_RDEV void bar_sum(int b, V3<F> PfB, V3<F> PtB, K PkB, V3<F> fB, V3<F> tB, V3<F> tA, K tauB, K tauA, BMask am, I pl, V3<F>& f, V3<F>& t, K& tax) {
   if (b == 0) {
-    f = (bcast3v<0>(PfB) - bcast3v<6>(PfB)) - bcast3v<8>(PfB);
-    t = (bcast3v<0>(PtB) - bcast3v<6>(PtA)) - bcast3v<8>(PtA);
-    tax = (bcast<0>(PkB) - bcast<6>(PkA)) - bcast<8>(PkA);
+    f = (bcast3v<0>(PfB) - bcast3v<6>(fB)) - bcast3v<8>(fB);
+    t = (bcast3v<0>(PtB) - bcast3v<6>(tA)) - bcast3v<8>(tA);
+    tax = (bcast<0>(PkB) - bcast<6>(tauA)) - bcast<8>(tauA);
     if (MODEL) { f = f + bcast3v<12>(fB); t = t + bcast3v<12>(tB); tax = tax + bcast<12>(tauB); }
-    else if (third) { f = (f - bcast3v<12>(fB)) - bcast3v<13>(fB); t = (t - bcast3v<12>(tA)) - bcast3v<13>(tA); tax = (tax - bcast<12>(tauA)) - bcast<13>(tauA); }
   } else if (b == 1) {
-    f = (bcast3v<2>(PfB) + bcast3v<6>(PfB)) - bcast3v<10>(PfB);
-    t = (bcast3v<2>(PtB) + bcast3v<6>(PtB)) - bcast3v<10>(PtA);
-    tax = (bcast<2>(PkB) + bcast<6>(PkB)) - bcast<10>(PkA);
+    f = (bcast3v<2>(PfB) + bcast3v<6>(fB)) - bcast3v<10>(fB);
+    t = (bcast3v<2>(PtB) + bcast3v<6>(tB)) - bcast3v<10>(tA);
+    tax = (bcast<2>(PkB) + bcast<6>(tauB)) - bcast<10>(tauA);
     if (MODEL) { f = f + bcast3v<13>(fB); t = t + bcast3v<13>(tB); tax = tax + bcast<13>(tauB); }
-    else if (third) { f = (f + bcast3v<12>(fB)) - bcast3v<14>(fB); t = (t + bcast3v<12>(tB)) - bcast3v<14>(tA); tax = (tax + bcast<12>(tauB)) - bcast<14>(tauA); }
   } else {
-    f = (bcast3v<4>(PfB) + bcast3v<8>(PfB)) + bcast3v<10>(PfB);
-    t = (bcast3v<4>(PtB) + bcast3v<8>(PtB)) + bcast3v<10>(PtB);
-    tax = (bcast<4>(PkB) + bcast<8>(PkB)) + bcast<10>(PkB);
+    f = (bcast3v<4>(PfB) + bcast3v<8>(fB)) + bcast3v<10>(fB);
+    t = (bcast3v<4>(PtB) + bcast3v<8>(tB)) + bcast3v<10>(tB);
+    tax = (bcast<4>(PkB) + bcast<8>(tauB)) + bcast<10>(tauB);
     if (MODEL) { f = f + bcast3v<14>(fB); t = t + bcast3v<14>(tB); tax = tax + bcast<14>(tauB); }
-    else if (third) { f = (f + bcast3v<13>(fB)) + bcast3v<14>(fB); t = (t + bcast3v<13>(tB)) + bcast3v<14>(tB); tax = (tax + bcast<13>(tauB)) + bcast<14>(tauB); }
   }
-  if (rove) {
-    // pair p15 = (A, B): bar A gets -f (torque about A's centre: tA), bar B gets +f.  (0,1), (0,2), (1,2).  (An idle slot carries zero force.)
+  if (slots_in<pool_mask<MODEL>()>(am)) {
     typedef typename LaneTraits<F>::S S;
     typedef typename LaneTraits<K>::S SK;
     const V3<F> z3 = mk<F>(F(S(0)), F(S(0)), F(S(0)));
-    const auto asA = b == 0 ? ((p15 == 0) | (p15 == 1)) : (b == 1 ? (p15 == 2) : (p15 == 99));
-    const auto asB = b == 0 ? (p15 == 99) : (b == 1 ? (p15 == 0) : ((p15 == 1) | (p15 == 2)));
-    f = (f + sel3(asB, bcast3v<15>(fB), z3)) - sel3(asA, bcast3v<15>(fB), z3);
-    t = (t + sel3(asB, bcast3v<15>(tB), z3)) - sel3(asA, bcast3v<15>(tA), z3);
-    tax = (tax + sel(asB, bcast<15>(tauB), K(SK(0)))) - sel(asA, bcast<15>(tauA), K(SK(0)));
+    auto add = [&](auto lc) {
+      constexpr int L = decltype(lc)::value;
+      if (!slot_in<L>(am)) return;
+      // pair plL = (A, B): bar A gets -f (torque about A's centre: tA), bar B gets +f.  (0,1), (0,2), (1,2)
+      const I plL = bcast<L>(pl);
+      const auto asA = b == 0 ? ((plL == 0) | (plL == 1)) : (b == 1 ? (plL == 2) : (plL == 99));
+      const auto asB = b == 0 ? (plL == 99) : (b == 1 ? (plL == 0) : ((plL == 1) | (plL == 2)));
+      f = (f + sel3(asB, bcast3v<L>(fB), z3)) - sel3(asA, bcast3v<L>(fB), z3);
+      t = (t + sel3(asB, bcast3v<L>(tB), z3)) - sel3(asA, bcast3v<L>(tA), z3);
+      tax = (tax + sel(asB, bcast<L>(tauB), K(SK(0)))) - sel(asA, bcast<L>(tauA), K(SK(0)));
+    };
+    add(std::integral_constant<int, 7>{}); add(std::integral_constant<int, 9>{}); add(std::integral_constant<int, 11>{});
+    if (!MODEL) { add(std::integral_constant<int, 12>{}); add(std::integral_constant<int, 13>{}); add(std::integral_constant<int, 14>{}); }
+    add(std::integral_constant<int, 15>{});
   }
 }
 
@@ -1117,9 +1116,9 @@ constexpr int LPX = 0, LPQ = 9, LPT = 21, LP_SLAB = 30;
 // the x / y velocity the health test and the reward read -- stays in K.  A robot 30 m from the origin resolves its fp32 coordinates to
 // 2e-6 m, i.e. 1e-4 m/s of velocity: the size of the is_healthy threshold (tensegrity_env.py:279).  On the GPU: columns 14, 15 of the tendon slab.
 constexpr int LCX = 0, LC_SLAB = 3;
-// xs (F, replicated): small per-environment scalars -- XP15: the bar pair the roving slot of lane 15 serves in this sub-step (-1: none).  On
+// xs (F, replicated): small per-environment scalars (none at present: the pool lanes' pairs live in a register).  On
 // the GPU: rows 3.. of column 14 of the tendon slab.
-constexpr int XP15 = 0, XS_SLAB = 1;
+constexpr int XS_SLAB = 1;
 #ifdef TGR_ROW_EMUL
 constexpr int hidx(int i) { return i; }
 constexpr int lidx(int i) { return i; }
@@ -1167,6 +1166,7 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
   RContact<F> c;
   V3<F> jl0, ja0;  // my slot's residual at the unconstrained acceleration: J (a0 + B v) + c0 n
   F dropped;
+  I pl;            // the bar pair my POOL lane's contact belongs to (-1: none); held in a register through the Newton loop
   // MODEL 1, mixed precision: my tendon's Jacobian pieces stay in K registers for the implicitfast stage (see there); otherwise td holds them
   constexpr bool TEN_K = (MODEL != 0) && TGR_IMPLICIT_K && !std::is_same<K, F>::value;
   // MODEL 1: Newton iterates on e = d - d_ref, d_ref = the warm start.  The uneven-ground model's tendons (1e4 N/m, uneven xml:38) and cap
@@ -1357,72 +1357,73 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
       }
       contact_params(P, dist, S(1), cc, dn);
       const auto is_floor = MODEL ? (Ro.is_cap | Ro.is_rod) : Ro.is_cap;
-      // bar pairs (every lane runs the routine; only pair lanes keep the outcome)
+      // bar pairs: every lane runs the routine on the bars of its role; the side lanes (6, 8, 10: pairs (0,1), (0,2), (1,2)) own the outcome
       // (positions relative to bar A's centre, the difference formed in K: a robot that has walked 30 m resolves a 0.5 mm bar-bar
       // penetration as well as one at the origin -- in absolute F coordinates it would carry 2e-6 m of rounding)
       const V3<F> pxA = z3, pzA = ld3(M.fd, FEZ + 3 * ja_), pxB = cvt3<F>(kxc - ld3(M.kd, KX + 3 * ja_)), pzB = cvt3<F>(kzc);
-      RContact<F> p0, p1, p2, p3;
-      F others;  // how many contacts of my pair besides the r-cylinders side to side
+      RContact<F> p0;
       TGR_SCHED();
-      bar_pair_contacts(P, capr, pxA, pzA, pxB, pzB, Ro.is_pair | Ro.is_pair2, p0, p1, p2, p3, others, S(2e-5));
+      const RPairGeom<F> G = pair_side_contact(P, capr, pxA, pzA, pxB, pzB, Ro.is_side, p0, S(2e-5));
       TGR_SCHED();
-      const auto s0 = Ro.sub == 0;
-      const auto s2 = Ro.is_pair2;
-      // The roving slot (lane 15): the next deepest "other" contact -- MODEL 0: the third, MODEL 1 (lanes 12..14 carry the rods): the second --
-      // of the first bar pair that has one.  Lane 6 + 2p holds pair p's candidates.  Rare (a crossing deeper than 6 mm near the b-cylinders:
-      // 1e-4 per env-step under random actions), so everything about it sits behind wavefront-uniform tests.
-      const RContact<F>& pn = MODEL ? p2 : p3;
-      const auto want = Ro.is_pair & s0 & pn.active;
-      I p15 = I(-1);
-      RContact<F> rv;
-      rv.n = mk<F>(zero, zero, F(S(1))); rv.rA = z3; rv.rB = z3; rv.c0 = zero; rv.Dn = zero; rv.active = B(false);
-      if (any_slots<0x0540u>(want)) {
-        const F w_ = sel(want, F(S(1)), zero);
-        const auto w0 = bcast<6>(w_) != S(0), w1 = bcast<8>(w_) != S(0), w2 = bcast<10>(w_) != S(0);
-        p15 = sel(w0, I(0), sel(w1, I(1), sel(w2, I(2), I(-1))));
-        auto pick = [&](F x) { return sel(p15 == 0, bcast<6>(x), sel(p15 == 1, bcast<8>(x), bcast<10>(x))); };
-        rv.n = mk<F>(pick(pn.n.x), pick(pn.n.y), pick(pn.n.z));
-        rv.rA = mk<F>(pick(pn.rA.x), pick(pn.rA.y), pick(pn.rA.z));
-        rv.rB = mk<F>(pick(pn.rB.x), pick(pn.rB.y), pick(pn.rB.z));
-        rv.c0 = pick(pn.c0); rv.Dn = pick(pn.Dn);
-        rv.active = p15 >= 0;
-      }
-      M.xs.st(XP15, from_int(p15, F()));
-      const auto s3 = Ro.r == 15;
-      c.n = sel3(is_floor, fn, sel3(s3, rv.n, sel3(s2, p2.n, sel3(s0, p0.n, p1.n))));
-      c.rA = sel3(is_floor, z3, sel3(s3, rv.rA, sel3(s2, p2.rA, sel3(s0, p0.rA, p1.rA))));
-      c.rB = sel3(is_floor, frB, sel3(s3, rv.rB, sel3(s2, p2.rB, sel3(s0, p0.rB, p1.rB))));
-      c.c0 = sel(is_floor, cc, sel(s3, rv.c0, sel(s2, p2.c0, sel(s0, p0.c0, p1.c0))));
-      c.Dn = sel(is_floor, dn, sel(s3, rv.Dn, sel(s2, p2.Dn, sel(s0, p0.Dn, p1.Dn))));
-      c.active = sel(is_floor, fhit, sel(s3, rv.active, sel(s2, p2.active, sel(Ro.is_pair, sel(s0, p0.active, p1.active), false))));
-      {
-        // what found no slot (counted on the pair's first lane): the pair's others beyond its fixed slots (MODEL 0: two, MODEL 1: one) and
-        // the roving slot, if that serves this pair
-        const auto mine = p15 == ((Ro.r - 6) >> 1);
-        const F slots = sel(mine, F(S(MODEL ? 2 : 3)), F(S(MODEL ? 1 : 2)));
-        dropped = sel(Ro.is_pair & s0 & (others > slots), others - slots, zero);
-#if defined(TGR_OTHERS_HIST) && !defined(TGR_ROW_EMUL)
-        // development aid: how many "other" contacts (besides the r-cylinders side to side) a bar pair has, per (env, pair, sub-step) that has any;
-        // [32 + k]: how many of an environment's pairs want more than the fixed slots at once
-        if (Ro.is_pair & s0 & (others > S(0))) atomicAdd(&g_others_hist[(int)min_(others, F(S(31)))], 1ull);
-        {
-          const F wants = rowsum(sel(Ro.is_pair & s0 & (others > F(S(MODEL ? 1 : 2))), F(S(1)), zero));
-          if ((Ro.r == 0) & (wants > S(0))) atomicAdd(&g_others_hist[32 + (int)wants], 1ull);
+      c.n = sel3(is_floor, fn, p0.n);
+      c.rA = sel3(is_floor, z3, p0.rA);
+      c.rB = sel3(is_floor, frB, p0.rB);
+      c.c0 = sel(is_floor, cc, p0.c0);
+      c.Dn = sel(is_floor, dn, p0.Dn);
+      c.active = (is_floor & fhit) | (!is_floor & Ro.is_side & p0.active);
+      pl = I(-1);
+      dropped = zero;
+      if (any_lane(G.more)) {
+        // The OTHER contacts of the pairs, rank by rank (depth), each routed to the next free pool lane the moment it is picked.  Rare -- a bar
+        // end near another bar, or a crossing deeper than 3.1 mm: one (env, sub-step) in three hundred -- so everything sits behind
+        // wavefront-uniform tests.  What the pool cannot hold is counted (never seen with seven lanes; MODEL 1 has four).
+        F prev_d = F(S(-1e30)), npool = zero, total = zero;
+        I prev_i = I(-1);
+        for (int rank = 0; rank < 24; rank++) {
+          const RPick<F> pk = pair_next_other(P, G, prev_d, prev_i);
+          const auto got = Ro.is_side & G.more & pk.ok;
+          if (rank == 0) {
+            const F cnt = sel(Ro.is_side & G.more, pk.count, zero);
+            total = (bcast<6>(cnt) + bcast<8>(cnt)) + bcast<10>(cnt);
+          }
+          if (!any_lane(got)) break;
+          prev_d = sel(pk.ok, pk.dist, prev_d); prev_i = sel(pk.ok, pk.idx, prev_i);
+          RContact<F> q;
+          q.n = pk.n; q.rA = pk.p - G.xA; q.rB = pk.p - G.xB;
+          contact_params(P, sel(got, pk.dist, zero), S(2), q.c0, q.Dn);
+          const F gotf = sel(got, F(S(1)), zero);
+          static_for<3>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            const auto okp = bcast<6 + 2 * p>(gotf) != S(0);  // (replicated: does pair p of THIS environment have a contact of this rank)
+            if (!any_lane(okp)) return;
+            // position npool of the pool: lanes 7, 9, 11, then 12.. (MODEL 1: then 15)
+            const I pos = to_int(npool);
+            const I L = sel(pos < 3, 7 + 2 * pos, MODEL ? I(15) : 9 + pos);
+            const auto here = okp & (npool < S(pool_size<MODEL>())) & (Ro.r == L);
+            c.n = sel3(here, bcast3<6 + 2 * p>(q.n), c.n); c.rA = sel3(here, bcast3<6 + 2 * p>(q.rA), c.rA); c.rB = sel3(here, bcast3<6 + 2 * p>(q.rB), c.rB);
+            c.c0 = sel(here, bcast<6 + 2 * p>(q.c0), c.c0); c.Dn = sel(here, bcast<6 + 2 * p>(q.Dn), c.Dn);
+            c.active = c.active | here;
+            pl = sel(here, I(p), pl);
+            npool = npool + sel(okp, F(S(1)), zero);
+          });
         }
+        dropped = sel((Ro.r == 0) & (total > S(pool_size<MODEL>())), total - S(pool_size<MODEL>()), zero);
+#if defined(TGR_OTHERS_HIST) && !defined(TGR_ROW_EMUL)
+        // development aid: how many "other" contacts the bar pairs of an environment have in all, per (env, sub-step) that has any
+        if ((Ro.r == 0) & (total > S(0))) atomicAdd(&g_others_hist[(int)min_(total, F(S(31)))], 1ull);
 #endif
       }
-      // my slot's bars, now that lane 15 knows whose contact it carries
-      const auto rove = s3 & (p15 >= 0);
-      jb = sel(rove, sel(p15 == 0, I(1), I(2)), jb); ja_ = sel(rove, sel(p15 == 2, I(1), I(0)), ja_);
-      hasA = hasA | rove;
+      // my slot's bars, now that a pool lane knows whose contact it carries
+      const auto pooled = pl >= 0;
+      jb = sel(pooled, sel(pl == 0, I(1), I(2)), jb); ja_ = sel(pooled, sel(pl == 2, I(1), I(0)), ja_);
+      hasA = hasA | pooled;
       V3<K> kzcL = kzc;
-      if (any_lane(rove)) kzcL = ld3(M.kd, KEZ + 3 * jb);
+      if (any_lane(pooled)) kzcL = ld3(M.kd, KEZ + 3 * jb);
       {
         // Two bars side to side: whether they touch, and how deep, is decided on the distance of the two axes formed again in K (the F
         // routine above names the candidate): over relative coordinates of 0.3 m an F distance carries 1e-7 m, ten times what the pose
-        // itself is uncertain by -- a third of the flat floor's contact flips started at such a contact.  (Here, after the slot has been
-        // picked: the three candidates of the pair are dead and the K temporaries fit the register budget.)
-        const auto side = Ro.is_pair & s0 & c.active;
+        // itself is uncertain by -- a third of the flat floor's contact flips started at such a contact.
+        const auto side = Ro.is_side & c.active;
         if (any_lane(side)) {
           const V3<K> zAk = ld3(M.kd, KEZ + 3 * ja_), wv = ld3(M.kd, KX + 3 * ja_) - kxc;
           const K b = dot(zAk, kzc), dA = dot(zAk, wv), dB = dot(kzc, wv);
@@ -1470,7 +1471,7 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
   // Start: last sub-step's constraint acceleration (P.warm_start) -- a contact's reference acceleration moves by ~B h a every sub-step,
   // so last sub-step's ACCELERATION is a poor guess, but the part of it the contacts produced is a good one -- or zero.
   {
-    const Roles<F> Ro = lane_roles<F, MODEL>(to_int(M.xs.ld(XP15)));
+    const Roles<F> Ro = lane_roles<F, MODEL>(pl);
     V3<F> dl[3], da[3];
     const F pc = M.hd.ld(hidx(HPC)), ppc = M.hd.ld(hidx(HPPC));
     #ifndef TGR_WX
@@ -1528,12 +1529,9 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
   TGR_FENCE();
   TGR_RSTAMP(3);  // Newton set-up (warm start, slot into the slab)
   TGR_REARG();
-  // (the roving slot's pair; -1: none -- one register held across the loop: re-read from the slab at the head of every iteration it was a
-  // round trip through LDS that the lane roles, and with them every address of the iteration, waited for)
-  const I p15 = to_int(M.xs.ld(XP15));
   for (int it = 0;; it++) {
     TGR_PHASE(3);
-    const Roles<F> Ro = lane_roles<F, MODEL>(p15);
+    const Roles<F> Ro = lane_roles<F, MODEL>(pl);
     DofC<F> dc;  // (repeated in the upper half of the row, lanes 8..13: hess_add_slot works on a pair slot's two bodies side by side)
     {
       const I r8 = Ro.r & 7;
@@ -1588,12 +1586,10 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     // The slots of a bar sit on fixed lanes (caps 2b, 2b+1; pair (a, b) on two neighbouring lanes), so its wrench is not a masked
     // sum over the row: neighbour sums first (one DPP add), then three broadcasts per bar (bar_sum below).  Lanes that own no slot are
     // never read.
-    const V3<F> PfB = mk<F>(pairsum(fB.x), pairsum(fB.y), pairsum(fB.z)), PtB = mk<F>(pairsum(tB.x), pairsum(tB.y), pairsum(tB.z)),
-                PtA = mk<F>(pairsum(tA.x), pairsum(tA.y), pairsum(tA.z));
-    const K PkB = pairsum(tauB), PkA = pairsum(tauA);
+    const V3<F> PfB = mk<F>(pairsum(fB.x), pairsum(fB.y), pairsum(fB.z)), PtB = mk<F>(pairsum(tB.x), pairsum(tB.y), pairsum(tB.z));
+    const K PkB = pairsum(tauB);
     const BMask am = ballot_of(cs.active);  // which slots are in use anywhere in the wavefront (once per iteration)
-    const bool third = !MODEL && slots_in<0x7000u>(am);
-    const bool rove = slot_in<15>(am);
+    const bool pool = slots_in<pool_mask<MODEL>()>(am);
     K gn;   // g^T M^-1 g
     F dn;   // d^T M d: the scale of the forces the gradient is the difference of
     F gd[3];
@@ -1613,16 +1609,17 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
       TGR_SCHED();
       V3<F> fcl, fca;
       K tax;
-      bar_sum<MODEL>(0, PfB, PtB, PtA, PkB, PkA, fB, tB, tA, tauB, tauA, third, rove, p15, fcl, fca, tax);
+      bar_sum<MODEL>(0, PfB, PtB, PkB, fB, tB, tA, tauB, tauA, am, pl, fcl, fca, tax);
       static_for<2>([&](auto bc) {  // (a bar's sums are taken up at once: three sets of them alive together cost registers the kernel does not have)
         constexpr int b = 1 + decltype(bc)::value;
         V3<F> f_, t_;
         K x_;
-        bar_sum<MODEL>(b, PfB, PtB, PtA, PkB, PkA, fB, tB, tA, tauB, tauA, third, rove, p15, f_, t_, x_);
+        bar_sum<MODEL>(b, PfB, PtB, PkB, fB, tB, tA, tauB, tauA, am, pl, f_, t_, x_);
         const auto mine = bi == b;
         fcl = sel3(mine, f_, fcl); fca = sel3(mine, t_, fca); tax = sel(mine, x_, tax);
         TGR_SCHED();
       });
+      TGR_CENSUS(16);
       st3_rep(M.fd, FFCL + 3 * bi, fcl); st3_rep(M.fd, FFCA + 3 * bi, fca); M.kd.st_rep(KTAX + bi, tax);
       // (SHIFT: dl, da are the iterate e; the full d = d_ref + e)
       const V3<F> rl = SHIFT ? ld3(M.fd, FRL + 3 * bi) : z3, ra = SHIFT ? ld3(M.fd, FRA + 3 * bi) : z3;
@@ -1644,7 +1641,7 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
       const I ri = sel(Ro.is_dof, Ro.r, I(0));
       for (int b = 0; b < 3; b++) gd[b] = M.fd.ld(FG + 6 * b + ri);
     }
-    if (LAST) bar_force = rowsum(sel(Ro.is_pair | Ro.is_pair2 | Ro.is_rove, sqrt_(dot(o.fl, o.fl)), zero));
+    if (LAST) bar_force = rowsum(sel(Ro.is_side | Ro.pooled, sqrt_(dot(o.fl, o.fl)), zero));
     // converged: the M^-1-norm of the gradient is below the tolerance -- or below what the arithmetic resolves of it: the gradient is the
     // difference of inertial and contact forces of size sqrt(d^T M d) (a hard contact onset: 1e3 sqrt(kg) m/s^2), each known to a few ulp
     conv = conv | !(gn >= PK.tol * PK.tol + (PK.rtol * PK.rtol) * cvt<K>(dn));
@@ -1671,24 +1668,23 @@ TGR_RDEV void substep(const ArgRef<RParams<SK>> argPK, const ArgRef<RParams<S>> 
     }
     for (int i = 0; i < 6; i++) { H.O10[i] = zero; H.O20[i] = zero; H.O21[i] = zero; }
     const BMask cm = ballot_of(o.cg != S(0));
-    // (the caps and the bar pairs' side-to-side slots one by one; the slots that are rarely in use -- a pair's other contacts: lanes 7, 9, 11 and,
-    // MODEL 0, 12..14: 0.3 % / 0.1 % of wavefronts each, profiles/round4_slot_census.log -- behind ONE test of the ballot: a skipped slot is a
-    // scalar test and a taken branch, and there are sixteen of them per iteration)
+    // (the caps and the bar pairs' side-to-side slots one by one; the pool -- a pair's other contacts: 0.3 % of wavefronts per lane,
+    // profiles/round4_slot_census.log -- behind ONE test of the ballot: a skipped slot is a scalar test and a taken branch)
     static_for<6>([&](auto cc) { hess_add_slot<MODEL, 0, decltype(cc)::value>(H, dc, cs, o, am, cm); });
     static_for<3>([&](auto cc) { hess_add_slot<MODEL, 0, 6 + 2 * decltype(cc)::value>(H, dc, cs, o, am, cm); });
-    if (slots_in<MODEL ? 0x0a80u : 0x7a80u>(am)) {
-      static_for<3>([&](auto cc) { hess_add_slot<MODEL, 0, 7 + 2 * decltype(cc)::value>(H, dc, cs, o, am, cm); });
-      if (!MODEL) static_for<3>([&](auto cc) { hess_add_slot<MODEL, 0, 12 + decltype(cc)::value>(H, dc, cs, o, am, cm); });
+    if constexpr (MODEL != 0) static_for<3>([&](auto cc) { hess_add_slot<MODEL, 0, 12 + decltype(cc)::value>(H, dc, cs, o, am, cm); });
+    if (pool) {
+      static_for<3>([&](auto cc) { hess_add_pool<7 + 2 * decltype(cc)::value>(H, dc, cs, o, pl, am, cm); });
+      if constexpr (MODEL == 0) static_for<3>([&](auto cc) { hess_add_pool<12 + decltype(cc)::value>(H, dc, cs, o, pl, am, cm); });
+      hess_add_pool<15>(H, dc, cs, o, pl, am, cm);
     }
-    if (MODEL) static_for<3>([&](auto cc) { hess_add_slot<MODEL, 0, 12 + decltype(cc)::value>(H, dc, cs, o, am, cm); });
     if (page1) {
       const BMask am1 = ballot_of(cs1.active), cm1 = ballot_of(o1.cg != S(0));
       static_for<6>([&](auto cc) { hess_add_slot<MODEL, 1, decltype(cc)::value>(H, dc, cs1, o1, am1, cm1); });
     }
-    if (rove) hess_add_roving(H, dc, cs, o, p15, cm);
     // which bar pairs does any environment of the wavefront couple?  (uniform: lets the factorisation skip zero blocks)
-    bool cp0 = slots_in<MODEL ? 0x00c0u : 0x10c0u>(am), cp1 = slots_in<MODEL ? 0x0300u : 0x2300u>(am), cp2 = slots_in<MODEL ? 0x0c00u : 0x4c00u>(am);
-    if (rove) { cp0 = cp0 || any_lane(Ro.is_rove & cs.active & (p15 == 0)); cp1 = cp1 || any_lane(Ro.is_rove & cs.active & (p15 == 1)); cp2 = cp2 || any_lane(Ro.is_rove & cs.active & (p15 == 2)); }
+    bool cp0 = slot_in<6>(am), cp1 = slot_in<8>(am), cp2 = slot_in<10>(am);
+    if (pool) { cp0 = cp0 || any_lane(Ro.pooled & cs.active & (pl == 0)); cp1 = cp1 || any_lane(Ro.pooled & cs.active & (pl == 1)); cp2 = cp2 || any_lane(Ro.pooled & cs.active & (pl == 2)); }
     TGR_RSTAMP(6);  // Hessian rows
     TGR_PHASE(6);
     // ---- direction p = -H^-1 g

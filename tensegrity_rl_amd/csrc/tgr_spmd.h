@@ -165,7 +165,7 @@ template <typename T> struct Ln {
 };
 // optional operation census of the emulation (TGR_ROW_OPCOUNT): lane-value operations per phase, fp64 ones counted separately
 #ifdef TGR_ROW_OPCOUNT
-struct OpCount { long long n[2][16]; int phase; };
+struct OpCount { long long n[2][24]; int phase; };
 inline OpCount& opcount() { static thread_local OpCount c = {}; return c; }
 template <typename T> inline void op_tick() { OpCount& c = opcount(); c.n[sizeof(T) == 8 ? 1 : 0][c.phase]++; }
 #define TGR_PHASE(i) (::tgr::row::opcount().phase = (i))

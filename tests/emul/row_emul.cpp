@@ -111,9 +111,9 @@ static int run(const double* params, const float* hf, int nrow, int ncol, int n,
 }
 
 #ifdef TGR_ROW_OPCOUNT
-extern "C" void tgr_row_opcount(long long* out /* [2][16] */, int reset) {
+extern "C" void tgr_row_opcount(long long* out /* [2][24] */, int reset) {
   OpCount& c = opcount();
-  for (int p = 0; p < 2; p++) for (int i = 0; i < 16; i++) { out[p * 16 + i] = c.n[p][i]; if (reset) c.n[p][i] = 0; }
+  for (int p = 0; p < 2; p++) for (int i = 0; i < 24; i++) { out[p * 24 + i] = c.n[p][i]; if (reset) c.n[p][i] = 0; }
 }
 #endif
 // precision: 0 = fp32 throughout, 1 = fp64 throughout, 2 = mixed (pose / kinematics / tendons fp64, the rest fp32)

@@ -6,7 +6,7 @@ instruction on the GPU, executed by all 16 lanes of the row whatever the role of
 
 with the per-phase lane counts below (a replicated phase -- all 16 lanes compute the same value -- counts 1 lane).  bench.py multiplies
 its measured VALU rate by this number to report an honest useful lane-op rate.  TEST INFRASTRUCTURE (CPU only).
-usage: python tests/emul_census.py [env-kind] [n] -> JSON on stdout (committed as profiles/round3_lane_census.json)"""
+usage: python tests/emul_census.py [env-kind] [n] -> JSON on stdout (committed as profiles/round4_lane_census.json)"""
 import ctypes as C
 import json
 import os
@@ -19,11 +19,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE); sys.path.insert(0, os.path.join(HERE, "emul"))
 
 # lanes of a 16-lane row that own distinct work in each census phase (tgr_row.h TGR_PHASE / TGR_CENSUS marks)
-PHASES = {0: ("kinematics (replicated)", 1), 1: ("tendons (tendon role)", 9), 2: ("contact detection (slot role; every lane runs the bar-pair routine, 9 keep it)", 12),
-          3: ("residual + cone (slot role)", 12), 4: ("wrench per slot (slot role)", 12), 12: ("bar sums + gradient (replicated)", 1), 5: ("Hessian rows (dof role)", 6),
-          6: ("direction: block Cholesky + solves (dof role)", 6), 7: ("line search set-up (replicated + slot role)", 6), 10: ("line search evaluations (slot role)", 12),
-          11: ("iterate update (replicated)", 1), 8: ("last sub-step readouts (replicated)", 1), 13: ("implicitfast set-up (tendon role)", 9),
-          14: ("implicitfast matrix (tendon role)", 9), 15: ("implicitfast solve + correction (tendon role / replicated)", 5), 9: ("advance (replicated)", 1)}
+PHASES = {0: ("kinematics (lane b: bar b)", 3), 1: ("tendons (tendon role; a bar's wrench finished on lane b)", 9),
+          2: ("contact detection (slot role: 6 caps, 3 side-to-side slots; the pool's enumeration where a pair has other contacts)", 9),
+          3: ("residual + cone (slot role)", 12), 4: ("wrench per slot (slot role)", 12), 12: ("bar sums (replicated)", 1), 16: ("gradient (lane b: bar b)", 3),
+          5: ("Hessian rows (dof role; a side-to-side slot's two bodies in the two halves of the row)", 8),
+          6: ("direction: block Cholesky + solves (dof role)", 6), 7: ("line search set-up (lane b: bar b; slot role)", 8), 10: ("line search evaluations (slot role)", 12),
+          11: ("iterate update (lane b: bar b)", 3), 8: ("last sub-step readouts (replicated)", 1), 13: ("implicitfast set-up (tendon role)", 9),
+          14: ("implicitfast matrix (tendon role)", 9), 15: ("implicitfast solve + correction (tendon role / replicated)", 5), 9: ("advance (lane b: bar b)", 3)}
 
 
 def main():
@@ -38,7 +40,7 @@ def main():
     ob = O.OracleBatch(O.make_cfg(kind, "straight"), n, seed=1234); ob.reset()
     P = RE.params_from_oracle_model(ob.env(0).model, 5e-4, 16, 6, rtol=2e-5)
     rng = np.random.default_rng(0)
-    cnt = (C.c_longlong * 32)()
+    cnt = (C.c_longlong * 48)()
     RE.lib().tgr_row_opcount(cnt, 1)
     iters = 0
     steps = 4
@@ -50,7 +52,7 @@ def main():
         iters += out[:, 23].sum()
         ob.step(a, auto_reset=False)
     RE.lib().tgr_row_opcount(cnt, 0)
-    ops = np.array(list(cnt), dtype=np.float64).reshape(2, 16)   # [fp32 | fp64][phase]
+    ops = np.array(list(cnt), dtype=np.float64).reshape(2, 24)   # [fp32 | fp64][phase]
     per_sub = ops / (n * steps * 20)
     tot = per_sub.sum()
     useful = sum(per_sub[:, p].sum() * lanes / 16.0 for p, (_, lanes) in PHASES.items())

@@ -25,8 +25,8 @@ def oracle_trace(ob):
     return out
 
 
-FLIP_CLASSES = {"cap on the floor": 0x00003f, "bar pair": 0x000fc0, "lanes 12-14 (pair's third slot / bar on the terrain)": 0x007000,
-                "cap on a second facet": 0x3f0000, "roving slot (lane 15)": 0x008000}
+FLIP_CLASSES = {"cap on the floor": 0x00003f, "bar pair side to side": 0x000540, "pool lanes 7, 9, 11 (a pair's other contacts)": 0x000a80,
+                "lanes 12-14 (pool / bar on the terrain)": 0x007000, "cap on a second facet": 0x3f0000, "pool lane 15": 0x008000}
 
 
 def classify(trg, tro):

@@ -32,7 +32,7 @@ m = np.stack(masks)              # [steps, n, 20]
 it = np.stack(iters)
 bits = ((m[..., None] >> np.arange(16)) & 1).astype(bool)   # [steps, n, 20, 16]
 wave = bits.reshape(steps, n // 4, 4, 20, 16).any(axis=2)   # union over the 4 envs of a wavefront
-names = [f"cap{c}" for c in range(6)] + [f"pair{p}.{s}" for p in range(3) for s in range(2)] + [f"third{p}" for p in range(3)] + ["rove"]
+names = [f"cap{c}" for c in range(6)] + [x for p in range(3) for x in (f"side{p}", f"pool{p}")] + [f"pool{3 + p}" for p in range(4)]
 print("slot      env-level  wavefront-level (fraction of sub-steps the slot is active)")
 for k in range(16):
     print(f"  {names[k]:8s}  {bits[..., k].mean():.4f}     {wave[..., k].mean():.4f}")
@@ -43,8 +43,8 @@ for b in range(3):
     both_w = (wave[..., 2 * b] & wave[..., 2 * b + 1]).mean()
     both_e = (bits[..., 2 * b] & bits[..., 2 * b + 1]).mean()
     print(f"  bar {b}: both caps active -- env {both_e:.4f}, wavefront {both_w:.4f}")
-print("wavefronts with any pair slot: %.4f; any coupling (c01 %.4f c02 %.4f c12 %.4f)" % (
-    wave[..., 6:].any(-1).mean(), wave[..., [6, 7, 12]].any(-1).mean(), wave[..., [8, 9, 13]].any(-1).mean(), wave[..., [10, 11, 14]].any(-1).mean()))
+print("wavefronts with any pair slot: %.4f; side-to-side slots (c01 %.4f c02 %.4f c12 %.4f)" % (
+    wave[..., 6:].any(-1).mean(), wave[..., 6].mean(), wave[..., 8].mean(), wave[..., 10].mean()))
 hist = np.bincount(wave.sum(-1).ravel(), minlength=17)
 print("wavefront union size histogram:", (hist / hist.sum()).round(4).tolist())
 own = it

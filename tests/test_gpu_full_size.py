@@ -41,7 +41,7 @@ def test_full_size_tr_env_flat_auto_reset_rollout():
     assert bad == 0 and dones >= 4 * n
     lane = s1["lane_substeps"] - s0["lane_substeps"]
     assert s1["unconverged_lane_substeps"] - s0["unconverged_lane_substeps"] < 0.002 * lane, s1
-    assert s1["dropped_contacts"] - s0["dropped_contacts"] < 3e-4 * n * steps, s1
+    assert s1["dropped_contacts"] - s0["dropped_contacts"] == 0, s1   # (every contact between two bars finds a lane since round 4: the pool)
     # (four synchronised TimeLimit waves of 4096 against 8192 donor lanes: all but a handful are served by a donor -- with the donor stream;
     # the fused launch of TGR_DONOR_STREAM=0 paces half its donor rows, which then miss the third wave)
     assert s1["donor_resets"] - s0["donor_resets"] >= 3 * n - (n if os.environ.get("TGR_DONOR_STREAM") == "0" else 0), s1

@@ -204,7 +204,7 @@ def test_a_deep_bar_crossing_carries_the_three_contacts_mujoco_would_keep():
     trace = env.bind_substep_trace()
     env.step_tensors(np.zeros((n, 6), dtype=np.float32))
     st = env.get_state()
-    assert ((trace.cpu().numpy()[:, 0] & 0xffff) == ((1 << 6) | (1 << 7) | (1 << 12))).all()      # pair (0, 1): both sub-slots and the third slot
+    assert ((trace.cpu().numpy()[:, 0] & 0xffff) == ((1 << 6) | (1 << 7) | (1 << 9))).all()      # pair (0, 1): side to side on its lane, the two others on the first two pool lanes
     v = st["qvel"].reshape(n, 3, 6)
     # qvel: world-frame linear velocity, BODY-frame angular velocity
     from scipy.spatial.transform import Rotation as Rot

@@ -276,7 +276,7 @@ def test_full_size_rollout_counters_stay_inside_their_bounds():
         bad += int((~torch.isfinite(o).all(dim=1)).sum().item()) if t % 8 == 0 else 0
     s1 = env.stats()
     assert bad == 0
-    assert s1["dropped_contacts"] - s0["dropped_contacts"] < 3e-4 * n * steps, s1   # (three slots per bar pair since round 3)
+    assert s1["dropped_contacts"] - s0["dropped_contacts"] == 0, s1   # (every contact between two bars finds a lane since round 4: the pool)
     assert s1["unconverged_lane_substeps"] - s0["unconverged_lane_substeps"] < 0.002 * (s1["lane_substeps"] - s0["lane_substeps"]), s1
     assert s1["settle_kernel_resets"] == s0["settle_kernel_resets"] and s1["donor_resets"] > 0, s1
     env.close()

@@ -166,12 +166,16 @@ def _crossed_bars(pairs, pen, s0=0.4):
     return q.reshape(21)
 
 
-@pytest.mark.parametrize("pairs,dropped", [([(0, 1)], 0), ([(0, 2)], 0), ([(1, 2)], 0), ([(0, 1), (1, 2)], 1)])
-def test_the_roving_slot_carries_a_pairs_fourth_contact(oracle, pairs, dropped):
+_PAIR_INDEX = {(0, 1): 0, (0, 2): 1, (1, 2): 2}
+POOL0, POOL1 = 0xfa80, 0x8a80   # the pool lanes of the flat-floor / heightfield row kernels (tgr_row.h pool_mask)
+
+
+@pytest.mark.parametrize("pairs", [[(0, 1)], [(0, 2)], [(1, 2)], [(0, 1), (1, 2)]])
+def test_the_pool_carries_every_other_contact_of_the_bar_pairs(oracle, pairs):
     """A bar crossing deeper than 6.2 mm where both bars carry a b-cylinder touches four times (r-r, r-b, b-r, b-b); mujoco keeps every
-    geom pair.  The pair's three fixed slots (lanes 6 + 2p, 7 + 2p, 12 + p) take three, lane 15 -- the roving slot, whose bar pair is a
-    run-time value -- the fourth: fp64 row sub-steps equal the oracle's for every pair; with two pairs that deep at once the second pair's
-    fourth contact finds the slot taken and is counted."""
+    geom pair.  The r-cylinders' side-to-side contact has its fixed lane (6 + 2p); every other contact takes the next lane of the pool
+    (7, 9, 11, 12..15), whose bar pair is a run-time value of the lane: fp64 row sub-steps equal the oracle's for every pair, also with two
+    pairs that deep at once (six others: until round 4 the second pair's fourth contact found no slot), and nothing is dropped."""
     import row_emul as RE
     O = oracle
     m = O.default_model()
@@ -190,18 +194,17 @@ def test_the_roving_slot_carries_a_pairs_fourth_contact(oracle, pairs, dropped):
         O.lib().tgo_step(O.C.byref(m), O.C.byref(d), 3)
         qo, vo = O.arr(d.qpos).copy()[None], O.arr(d.qvel).copy()[None]
         otr = np.ctypeslib.as_array(d.trace)[:3]
-        if dropped == 0 or i == 0:
-            assert rel_env(qfix(q2[i:i + 1], qo) - qo, qo, 1e-3).max() < 1e-8 and rel_env(v2[i:i + 1] - vo, vo, 1e-2).max() < 1e-6, (pairs, i)
+        assert rel_env(qfix(q2[i:i + 1], qo) - qo, qo, 1e-3).max() < 1e-8 and rel_env(v2[i:i + 1] - vo, vo, 1e-2).max() < 1e-6, (pairs, i)
         assert ((trace[i, :3] ^ otr) & 0xffff).max() == 0, (pairs, i, [hex(x) for x in trace[i, :3]], [hex(x) for x in otr])
-        assert bool(trace[i, 0] & 0x8000) == (i > 0)                        # lane 15 is in use exactly where the crossing is deep enough
-    # contacts that found no slot in the last sub-step (the 7 mm crossing has been pushed back above 6.2 mm by then)
-    assert (out[0, 21] == 0) and (out[1, 21] <= dropped) and (out[2:, 21] == dropped).all(), out[:, 21]
+        assert bin(int(trace[i, 0]) & POOL0).count("1") == (2 if i == 0 else 3) * len(pairs)   # r-b, b-r (+ b-b where the crossing is deep enough) per pair
+        assert all(int(trace[i, 0]) & (1 << (6 + 2 * _PAIR_INDEX[p_])) for p_ in pairs)       # the side-to-side contacts on their fixed lanes
+    assert (out[:, 21] == 0).all(), out[:, 21]   # contacts that found no slot in the last sub-step
 
 
 @pytest.mark.parametrize("pairs", [[(0, 1)], [(1, 2)]])
-def test_the_roving_slot_on_the_heightfield_model(oracle, golden_dir, pairs):
-    """MODEL = 1: lanes 12..14 carry the bars' terrain contacts, so a pair has ONE fixed slot besides the r-cylinders side to side; the roving
-    slot takes the pair's second other contact (a 4 mm crossing: r-r, r-b, b-r), a third (b-b, beyond 6.2 mm) is counted"""
+def test_the_pool_on_the_heightfield_model(oracle, golden_dir, pairs):
+    """MODEL = 1: lanes 12..14 carry the bars' terrain contacts, so the pool is lanes 7, 9, 11, 15: a 4 mm crossing (r-r, r-b, b-r) uses two of
+    them, a 9 mm one (+ b-b) three; nothing is dropped"""
     import row_emul as RE
     from tensegrity_rl_amd.vec_env import heights_from_image
     O = oracle
@@ -224,7 +227,7 @@ def test_the_roving_slot_on_the_heightfield_model(oracle, golden_dir, pairs):
         qo, vo = O.arr(d.qpos).copy()[None], O.arr(d.qvel).copy()[None]
         otr = np.ctypeslib.as_array(d.trace)[:1]
         assert ((trace[i, :1] ^ otr) & 0x3fffff).max() == 0, (pairs, i, [hex(x) for x in trace[i, :1]], [hex(x) for x in otr])
-        if i < 2:
+        if True:
             assert rel_env(qfix(q2[i:i + 1], qo) - qo, qo, 1e-3).max() < 1e-8 and rel_env(v2[i:i + 1] - vo, vo, 1e-2).max() < 1e-6, (pairs, i)
-    assert [bool(t & 0x8000) for t in trace[:, 0]] == [False, True, True]
-    assert list(out[:, 21]) == [0, 0, 1]
+    assert [bin(int(t) & POOL1).count("1") for t in trace[:, 0]] == [0, 2, 3]
+    assert list(out[:, 21]) == [0, 0, 0]
