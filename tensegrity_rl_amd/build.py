@@ -17,7 +17,10 @@ STAMP = LIB + ".srchash"
 # -fno-slp-vectorize: the SLP vectoriser pairs the row kernels' fp32 arithmetic into v_pk_* instructions, which take as long as two scalar
 # ones on this hardware would if the pairs did not have to be assembled first -- 690 of the 4400 instructions of the Newton loop were
 # register moves doing that, and 135 VGPRs spilled (37 without it); measured +7 % env-steps/s
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize"]
+# -amdgpu-sched-strategy=max-ilp: a wavefront of the row kernels is alone with one other on its SIMD and issues VALU 61 % of its cycles -- what is
+# left are dependent chains and LDS round trips, and the ILP-first scheduling strategy interleaves them better than the default
+# (occupancy-first) one: live-row launch -2.3 %, no spills (profiles/round4_ab_scheduling.log)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def lib_path():

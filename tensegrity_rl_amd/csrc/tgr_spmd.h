@@ -33,11 +33,18 @@ namespace row {
 constexpr int ROW = 16;
 
 #ifndef TGR_ROW_EMUL
-// nothing is scheduled across a phase mark: the machine scheduler otherwise hoists the next phase's loads over this phase's arithmetic
-// and the register allocator pays for it
+// Scheduling fences between (TGR_PHASE) and inside (TGR_SCHED) the stages of the sub-step.  They date from the builds that spilled: the machine
+// scheduler hoisted the next stage's loads over this stage's arithmetic and the register allocator paid for it.  Since round 4 the row kernels
+// are built with the max-ILP scheduling strategy (build.py) and fit their budget without the fences; with them the live-row launch is 0.9 %
+// slower (profiles/round4_ab_scheduling.log).  TGR_KEEP_SCHED_FENCES restores them.
+#ifdef TGR_KEEP_SCHED_FENCES
 #define TGR_PHASE(i) __builtin_amdgcn_sched_barrier(0)
-#define TGR_CENSUS(i) ((void)0)
 #define TGR_SCHED() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TGR_PHASE(i) ((void)0)
+#define TGR_SCHED() ((void)0)
+#endif
+#define TGR_CENSUS(i) ((void)0)
 // the compiler must not connect this value with an earlier copy of it (so it is recomputed here instead of kept alive since there)
 #define TGR_LAUNDER(x) asm volatile("" : "+v"(x))
 // values parked in a slab must really be re-read after this point (no forwarding through registers), and nothing is scheduled across it
