@@ -262,17 +262,24 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     stats0 = env.stats()
-    # kernel-only timing of the dominant kernel with HIP events on the launch stream (roofline.achieved)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # Kernel-only timing of the dominant kernel -- the step kernel over the live rows -- with HIP events the library records around exactly that
+    # launch, on the stream it is launched on, INSIDE the timed region (roofline.achieved) -- on one step in four: an event pair is two packets on
+    # the stream, and timed on every step the run is 2 % slower for its own measurement.  The same steps carry the torch events of step_chain_ms.
+    every = 4
+    n_timed = (args.steps + every - 1) // every
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_timed)]
+    env.time_kernels(n_timed, every)
     multi = world > 1 or force_dist
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        evs[i][0].record()
+        if i % every == 0:
+            evs[i // every][0].record()
         one_step(args.warmup + i)
-        evs[i][1].record()
+        if i % every == 0:
+            evs[i // every][1].record()
     if gather is not None:
         gather.flush()  # the last chunk's all-gather belongs to the timed region
     if multi:
@@ -286,12 +293,7 @@ def main():
     stats1 = env.stats()
     step_ms = sorted(a.elapsed_time(b) for a, b in evs)
     chain_ms = sum(step_ms) / len(step_ms)   # one step's work on the caller's stream: step kernel over the live rows + match + settle + gaps
-    # the dominant kernel alone -- the step kernel over the live rows -- with HIP events the library records around exactly that launch, on the
-    # stream it is launched on; measured AFTER the timed region (the events would add two packets per step to it), same workload, same state
-    env.time_kernels(128)
-    for i in range(128):
-        one_step(args.warmup + args.steps + i)
-    kt = sorted(env.kernel_times_ms(128))
+    kt = sorted(env.kernel_times_ms(n_timed))
     env.time_kernels(0)
     kern_ms = sum(kt) / len(kt) if kt else chain_ms
 
@@ -326,7 +328,7 @@ def main():
                        "dropped_contacts_per_env_step": (stats1["dropped_contacts"] - stats0["dropped_contacts"]) / (n_local * args.steps),
                        "starved_resets_rank0": stats1["settle_kernel_resets"] - stats0["settle_kernel_resets"],
                        # a donor lane needs 51 launches to settle its first episode: a timed window that starts before ~100 steps sees the
-                       # pool's start-up transient (more Newton iterations per sub-step, ~5 % below the steady state of the 8(d) protocol)
+                       # pool's start-up transient (every donor wavefront busy with one row, more Newton iterations per sub-step)
                        "donor_pool_warm": bool(args.warmup >= 100),
                        # what "1e-4 relative" means wherever this repo quotes it (tests/gpu_common.py rel_env): per env-step and per env,
                        # max_i |err_i| / max(max_i |ref_i|, floor) over the 21 qpos (floor 1e-3) or the 18 qvel (floor 1e-2) components
@@ -335,7 +337,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": prof["traffic"], "traffic_source": prof["source"],
                          "note": "step kernel: 674 algorithmic B per env-step x envs per launch / mean duration of the launch that steps the live "
-                                 "rows (HIP events the library records around exactly that launch, on the caller's stream: tgr_time_kernels; "
+                                 "rows (HIP events the library records around exactly that launch, on the caller's stream, inside the timed region, one step in "
+                                 "four: tgr_time_kernels_every; "
                                  "step_chain_ms = that launch + match + settle launches + gaps, from events around tgr_step; the donor rows run "
                                  "concurrently in their own launch on the handle's low-priority stream); the path is VALU-issue bound (~1e6 flop "
                                  "per env-step), not HBM bound: see DESIGN.md",

@@ -253,6 +253,9 @@ int tgr_bind_substep_trace(tgr_handle* h, uint32_t* trace_dev);
  * n_slots = 0 switches it off.  tgr_kernel_times_ms synchronises and returns the durations [ms] of the last min(n, recorded) such launches,
  * oldest first (its return value is their number, or a negative error code).  No reference counterpart */
 int tgr_time_kernels(tgr_handle* h, int n_slots);
+/* the same, timing only every `every`-th step from now on (an event pair is two packets on the stream: sampled sparsely the timed run is not
+ * slowed by its own measurement -- bench.py times one step in four INSIDE its timed region) */
+int tgr_time_kernels_every(tgr_handle* h, int n_slots, int every);
 int tgr_kernel_times_ms(tgr_handle* h, float* out_ms, int n);
 int tgr_synchronize(tgr_handle* h);
 const char* tgr_last_error(const tgr_handle* h);

@@ -45,7 +45,7 @@ class Config(C.Structure):
 SYMBOLS = ["tgr_default_config", "tgr_create", "tgr_destroy", "tgr_num_envs", "tgr_obs_dim", "tgr_precision", "tgr_reset",
            "tgr_step", "tgr_step_f64", "tgr_get_state", "tgr_set_state", "tgr_stats", "tgr_set_seed", "tgr_synchronize",
            "tgr_last_error", "tgr_version", "tgr_sizeof_config", "tgr_lane_key", "tgr_uneven_config", "tgr_set_hfield", "tgr_bind_real_observation",
-           "tgr_bind_substep_trace", "tgr_time_kernels", "tgr_kernel_times_ms"]
+           "tgr_bind_substep_trace", "tgr_time_kernels", "tgr_time_kernels_every", "tgr_kernel_times_ms"]
 
 _lib = None
 
@@ -92,6 +92,7 @@ def load():
     L.tgr_bind_real_observation.argtypes = [vp, vp]
     L.tgr_bind_substep_trace.argtypes = [vp, vp]
     L.tgr_time_kernels.argtypes = [vp, C.c_int]
+    L.tgr_time_kernels_every.argtypes = [vp, C.c_int, C.c_int]
     L.tgr_kernel_times_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     if L.tgr_sizeof_config() != C.sizeof(Config):
         raise RuntimeError(f"tgr_config layout mismatch: C {L.tgr_sizeof_config()} vs ctypes {C.sizeof(Config)}")

@@ -57,6 +57,12 @@ template <typename T> struct EnvCfg {
   int cap_noise; double cap_lo, cap_hi, cap_nominal;
 };
 
+// counters[STAMP_SLOT + 2 * (launch & 1) + {0, 1}]: when the live-row launch of that step started / when its last wavefront ended
+// (launch index << 40 | 100 MHz clock) -- what the donor launches stagger themselves by (KArgs::stagger_pct)
+constexpr int STAMP_SLOT = 150;
+#ifndef TGR_DONOR_STAGGER_PCT
+#define TGR_DONOR_STAGGER_PCT 42
+#endif
 template <typename T> struct KArgs {
   Params<T> P;
   EnvCfg<T> E;
@@ -83,6 +89,15 @@ template <typename T> struct KArgs {
   // step j - 1 and only carries out commands with tag <= j - 1.  What either side sees is thus a function of launch indices alone -- results
   // do not depend on how the two streams happen to overlap.
   int async, launch_idx, lane_base, lane_limit;
+  // STAGGER of the two streams.  A step is the live-row launch + 45 us of serial work on the caller's stream (match kernel, launch gaps) next
+  // to the donor-row launch on the donor stream.  Started TOGETHER -- which is what happens whenever the donor launch is the shorter of the two:
+  // it starts the moment the previous step's match kernel ends -- both launches' tails coincide and nothing covers the serial section (0.94 ms
+  // per step); staggered, either stream's tail is covered by the other's bulk (0.87 ms).  So: the live launch stamps its start and
+  // every live wavefront its end (counters[STAMP_SLOT..]); a donor wavefront that finds itself starting within stagger_pct / 4 percent of the
+  // previous live launch's duration after this step's live launch sleeps (s_sleep: it holds a wave slot, not the ALU) until stagger_pct percent
+  // of that duration have passed, for at most 0.6 ms; one that starts later already is staggered and goes ahead.  Timing only: nothing a
+  // kernel computes depends on it.  0: off.  (fp32 flat-floor handles: the instantiation with two wavefronts per SIMD.)
+  int stagger_pct;
   unsigned long long* dcmd; int* dapplied; int* dready; int* consumed;
   uint8_t* doneflag;
   T* dobs;  // reset observations of the donors [m-n][D]
@@ -1026,6 +1041,37 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
   // they end before the longest first-round wavefront does.  Wavefront-uniform: slow_e and the rows of a wavefront are multiples of 4.
   const bool slow = k.lane_base + lb * ROW_ENVS >= k.slow_e;
   const int nsub = slow ? E.frame_skip / 2 : E.frame_skip;
+  const unsigned long long mask40 = (1ull << 40) - 1ull;
+  if (k.stagger_pct > 0) {  // (donor stream only: KArgs::stagger_pct)
+    unsigned long long* const mine = k.counters + STAMP_SLOT + 2 * (k.launch_idx & 1);
+    if (k.lane_base == 0) {
+      if (bx == 0 && threadIdx.x == 0)
+        __hip_atomic_store(mine, ((unsigned long long)(unsigned)k.launch_idx << 40) | (wall_clock64() & mask40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (__any(active)) {
+      auto rd = [](unsigned long long* p) {
+        const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffull));
+      };
+      // how long the previous live launch took (its stamps carry its index; anything else: no stagger this time)
+      unsigned long long* const prev = k.counters + STAMP_SLOT + 2 * ((k.launch_idx - 1) & 1);
+      const unsigned long long ps = rd(prev), pe = rd(prev + 1);
+      const bool have = (unsigned)(ps >> 40) == (unsigned)(k.launch_idx - 1) && (unsigned)(pe >> 40) == (unsigned)(k.launch_idx - 1);
+      unsigned long long dur = have ? ((pe - ps) & mask40) : 0ull;
+      dur = dur > 400000ull ? 400000ull : dur;  // (4 ms)
+      const unsigned long long need = dur * (unsigned long long)k.stagger_pct / 100ull, early = need / 4ull;
+      const unsigned long long t0 = wall_clock64();
+      bool first = true;
+      for (; need > 0ull;) {  // (every wavefront on its own, every path out bounded by the clock)
+        const unsigned long long w = rd(mine), now = wall_clock64();
+        const unsigned idx = (unsigned)(w >> 40);
+        const unsigned long long age = (now - w) & mask40;
+        const bool late = idx > (unsigned)k.launch_idx || (idx == (unsigned)k.launch_idx && age >= (first ? early : need));
+        if (late || now - t0 >= 60000ull) break;
+        first = false;
+        __builtin_amdgcn_s_sleep(64);
+      }
+    }
+  }
   row::RLag<TK, T> rl;
   row_lag_init<T, TK>(rl);
   if (__any(active)) {  // (a wavefront of idle donor rows has nothing to do)
@@ -1141,6 +1187,8 @@ template <typename T, typename TK, int MODEL> __global__ __launch_bounds__((16 *
     __builtin_amdgcn_wave_barrier();
     if (live)
       for (int c = r; c < D; c += 16) k.obs[(size_t)e * D + c] = orow[c];
+    if (k.stagger_pct > 0 && k.lane_base == 0 && (tx2 & 63u) == 0)  // (the live launch's end: the latest of its wavefronts' -- KArgs::stagger_pct)
+      atomicMax(k.counters + STAMP_SLOT + 2 * (k.launch_idx & 1) + 1, ((unsigned long long)(unsigned)k.launch_idx << 40) | (wall_clock64() & ((1ull << 40) - 1ull)));
   }
 }
 
@@ -1561,6 +1609,7 @@ struct tgr_handle {
   tgr_config cfg;
   int n = 0, m = 0, device = 0, obs_dim = 0;
   int n_cu = 256;  // compute units of the device (how many rows one round of the row kernels holds)
+  int stagger_pct = TGR_DONOR_STAGGER_PCT;  // TGR_DONOR_STAGGER_PCT=<percent of a live-row launch>: stagger of the donor launch behind the live one (0: off)
   int pace_from = -1;  // TGR_PACE_FROM=<lane>: test hook -- pace the donor rows from this lane on, whatever the device's size
   void* st = nullptr;   // T[NF][m]
   int* ist = nullptr;   // int[NI][m]
@@ -1583,7 +1632,7 @@ struct tgr_handle {
   unsigned long long* dcmd = nullptr; int* dapplied = nullptr; int* dready = nullptr; int* consumed = nullptr;
   // tgr_time_kernels: HIP events around the launch that steps the live rows (the dominant kernel), a ring of tm_n pairs
   std::vector<hipEvent_t> tm_start, tm_stop;
-  int tm_n = 0; long long tm_count = 0;
+  int tm_n = 0, tm_every = 1; long long tm_count = 0, tm_step = 0;  // (tm_every: only every tm_every-th step is timed)
   uint8_t* doneflag = nullptr;
   unsigned long long* counters = nullptr;
   float* hf = nullptr;  // heightfield elevations (model_kind 1)
@@ -1799,7 +1848,7 @@ template <typename T> static void fill_args(const tgr_handle* h, KArgs<T>& k) {
   k.st = (T*)h->st; k.ist = h->ist; k.ring = (T*)h->ring; k.dobs = (T*)h->dobs; k.hp = h->hp;
   k.list_count = h->list_count; k.list = h->list; k.rlist = h->rlist; k.doneflag = h->doneflag; k.counters = h->counters;
   k.list_ep = h->list_ep; k.cls = h->cls; k.holder = h->holder; k.stream_table = h->stream_table;
-  k.async = h->async ? 1 : 0; k.launch_idx = h->launch; k.lane_base = 0; k.lane_limit = h->m;
+  k.async = h->async ? 1 : 0; k.launch_idx = h->launch; k.lane_base = 0; k.lane_limit = h->m; k.stagger_pct = (h->async && c.precision != TGR_PRECISION_F64 && c.model_kind == 0) ? h->stagger_pct : 0;
   k.dcmd = h->dcmd; k.dapplied = h->dapplied; k.dready = h->dready; k.consumed = h->consumed;
   k.auto_reset = c.auto_reset;
   k.actions = nullptr; k.obs = nullptr; k.reward = nullptr; k.terminated = nullptr; k.truncated = nullptr;
@@ -1922,6 +1971,7 @@ extern "C" int tgr_create(const tgr_config* cfg, int n_envs, int device, tgr_han
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
   }
   if (const char* v = getenv("TGR_PACE_FROM")) h->pace_from = atoi(v);
+  if (const char* v = getenv("TGR_DONOR_STAGGER_PCT")) h->stagger_pct = atoi(v);
   int donors = cfg->n_donors < 0 ? 2 * n_envs : cfg->n_donors;
   if (!cfg->auto_reset) donors = 0;
   // donor stream: 0 = auto (on whenever the handle has donor lanes, is stepped by the row kernels and n_envs is a multiple of the four rows
@@ -2035,14 +2085,16 @@ extern "C" int tgr_bind_substep_trace(tgr_handle* h, uint32_t* trace_dev) {
   h->trace = trace_dev;
   return TGR_OK;
 }
-extern "C" int tgr_time_kernels(tgr_handle* h, int n_slots) {
-  if (!h || n_slots < 0) return TGR_ERR_INVALID;
+extern "C" int tgr_time_kernels_every(tgr_handle* h, int n_slots, int every);
+extern "C" int tgr_time_kernels(tgr_handle* h, int n_slots) { return tgr_time_kernels_every(h, n_slots, 1); }
+extern "C" int tgr_time_kernels_every(tgr_handle* h, int n_slots, int every) {
+  if (!h || n_slots < 0 || every < 1) return TGR_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipDeviceSynchronize());
   for (hipEvent_t e : h->tm_start) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->tm_stop) (void)hipEventDestroy(e);
   h->tm_start.assign(n_slots, nullptr); h->tm_stop.assign(n_slots, nullptr);
-  h->tm_n = 0; h->tm_count = 0;
+  h->tm_n = 0; h->tm_count = 0; h->tm_step = 0; h->tm_every = every;
   for (int i = 0; i < n_slots; i++) { HIP_TRY(h, hipEventCreate(&h->tm_start[i])); HIP_TRY(h, hipEventCreate(&h->tm_stop[i])); }
   h->tm_n = n_slots;
   return TGR_OK;
@@ -2206,7 +2258,7 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
       // live rows on the caller's stream; the donor rows advance one control period on their own low-priority stream, concurrently --
       // after the match kernel of the previous step (whose commands this launch carries out)
       k.lane_base = 0; k.lane_limit = h->n;
-      const int ti = h->tm_n ? (int)(h->tm_count++ % h->tm_n) : -1;
+      const int ti = (h->tm_n && (h->tm_step++ % h->tm_every) == 0) ? (int)(h->tm_count++ % h->tm_n) : -1;
       if (ti >= 0) HIP_TRY(h, hipEventRecord(h->tm_start[ti], s));
       launch_rows(k, h->n, s);
       if (ti >= 0) HIP_TRY(h, hipEventRecord(h->tm_stop[ti], s));
@@ -2221,7 +2273,7 @@ static int step_impl(tgr_handle* h, const float* actions, T* obs, T* reward, uin
       HIP_TRY(h, hipStreamWaitEvent(s, h->ev_donor[(h->launch - 1) & 1], 0));
       k.lane_base = 0; k.lane_limit = h->m;
     } else {
-      const int ti = h->tm_n ? (int)(h->tm_count++ % h->tm_n) : -1;
+      const int ti = (h->tm_n && (h->tm_step++ % h->tm_every) == 0) ? (int)(h->tm_count++ % h->tm_n) : -1;
       if (ti >= 0) HIP_TRY(h, hipEventRecord(h->tm_start[ti], s));
       launch_rows(k, h->m, s);
       if (ti >= 0) HIP_TRY(h, hipEventRecord(h->tm_stop[ti], s));

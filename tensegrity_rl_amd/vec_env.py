@@ -451,9 +451,9 @@ class TensegrityVecEnv:
         N.check(self.handle, self.lib.tgr_bind_substep_trace(self.handle, self.trace.data_ptr() if on else None), "tgr_bind_substep_trace")
         return self.trace
 
-    def time_kernels(self, n_slots):
-        """HIP events around every launch of the dominant kernel from now on (a ring of n_slots; 0 = off): tgr_time_kernels"""
-        N.check(self.handle, self.lib.tgr_time_kernels(self.handle, int(n_slots)), "tgr_time_kernels")
+    def time_kernels(self, n_slots, every=1):
+        """HIP events around every `every`-th launch of the dominant kernel from now on (a ring of n_slots; 0 = off): tgr_time_kernels_every"""
+        N.check(self.handle, self.lib.tgr_time_kernels_every(self.handle, int(n_slots), int(every)), "tgr_time_kernels_every")
 
     def kernel_times_ms(self, n):
         out = (C.c_float * int(n))()
