@@ -1,16 +1,22 @@
 // tgr_row.h -- one physics sub-step of the 3-bar tensegrity robot in the "one environment = one DPP row" layout
-// (tgr_spmd.h): 16 lanes per environment, 4 environments per wavefront, no LDS and no barriers inside the sub-step.
+// (tgr_spmd.h): 16 lanes per environment, 4 environments per wavefront, no barriers and no cross-wave traffic inside the sub-step.
 //
 // What it computes is what the reference gets from mujoco==2.3.7 mj_step for 3prism_jonathan_steady_side.xml (call sites
 // tensegrity_env.py:297, tr_env.py:346,812): tendon/actuator forces, soft contacts with elliptic cones solved by Newton's
 // method, implicitfast integration -- the same convex problem and the same formulation (world-frame twists, frame-free contact
 // rows, "isotropic + rank-1" cone Hessian) as the block kernels of tgr_device.h, which remain the cross-check.  What differs is
 // the mapping onto the machine:
-//   replicated in the row : rigid-body state, Newton iterate a (18), unconstrained acceleration a0, gradient, step p, all scalars
+//   replicated in the row : rigid-body state, Newton iterate d (18), unconstrained acceleration a0, step p, all scalars -- kept in LDS slabs
+//                            between uses, not in registers
+//   bar role     (lane b < 3)  : what concerns ONE bar at a time -- kinematics, its tendon and constraint wrench, gradient, its share of the
+//                                 norms and of the line search's Gauss part, iterate update, advance: lane b works on bar b and stores the
+//                                 result in the slab (lanes 3.. repeat bar 0)
 //   tendon role  (lane t < 9)  : geometry, force and Jacobian of tendon t; row t of the 9x9 implicitfast (Woodbury) system
-//   slot role    (lane c < 12) : contact slot c -- cap c on the floor (c < 6) or sub-slot (c-6)&1 of bar pair (c-6)>>1:
-//                                 detection, cone evaluation, line-search coefficients
-//   dof role     (lane i < 6)  : row i of every 6x6 block of the 18x18 Newton Hessian; block Cholesky with row_newbcast
+//   slot role    (lane c < 16) : contact slot c -- cap c on the floor (c < 6), the r-cylinders of bar pair (c-6)>>1 side to side (c = 6, 8, 10),
+//                                 MODEL 1: bar c-12 on the terrain (c = 12..14), and the POOL (every other contact between two bars, the pair a
+//                                 run-time value of the lane): detection, cone evaluation, line-search coefficients
+//   dof role     (lane i < 6)  : row i of every 6x6 block of the 18x18 Newton Hessian (repeated on lanes 8..13: a pair slot's two bodies are
+//                                 worked on side by side); block Cholesky with row_newbcast
 // A wavefront iterates until its four environments have converged (the block kernels wait for 64).
 #pragma once
 #include "tgr_spmd.h"
