@@ -148,7 +148,7 @@ def test_one_substep_of_a_central_bar_bar_contact_in_closed_form(prec, case):
 def test_a_deep_bar_crossing_carries_the_three_contacts_mujoco_would_keep():
     """r-cylinders crossing 4 mm deep at 0.4 m from both centres, where both bars also carry a b-cylinder (r = 0.035 inside r = 0.0381,
     flat xml:77): mujoco instantiates r-r (4 mm), r-b and b-r (0.9 mm each) -- b-b would need 6.2 mm.  All three share the normal and the
-    point; the row kernels keep them in the pair's three slots (lanes 6/7 and 12).  Contacts are unilateral: the deep one alone pushes the
+    point; the row kernels keep them on the pair's side-to-side lane (6) and the first two pool lanes (7, 9).  Contacts are unilateral: the deep one alone pushes the
     bars apart harder (relative normal acceleration 20 m/s^2) than the two shallow ones ask for (aref = K imp 0.9 mm = 4.7 m/s^2), so those
     stay force-free, and with the deep contact's rows in the quadratic zone of its cone the sub-step is the linear problem
     (M + J^T D J) a = J^T D aref, solved here with numpy from the geometry alone (six rows: normal, two tangents, torsion, two rolling;

@@ -260,7 +260,7 @@ def test_fp64_clamped_actuator_derivative_option_matches_oracle(oracle):
 def test_full_size_rollout_counters_stay_inside_their_bounds():
     """BASELINE size, production settings (4096 envs, fp32, auto-reset through donor lanes, random actions): what the solver and the
     contact slots leave unresolved is counted on the device and bounded here --
-      * bar-bar contacts beyond the three slots per bar pair (the deepest are kept): < 3 per 10000 env-steps,
+      * bar-bar contacts that found no lane: none (every other contact of the bar pairs goes to the pool since round 4),
       * lane-sub-steps that left the Newton solver unconverged (iteration cap, or stalled at working precision): < 0.2 %,
       * no env ever waited for a synchronous settle (donor lanes always had an episode ready), every observation finite."""
     import torch
