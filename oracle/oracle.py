@@ -103,6 +103,7 @@ def lib():
     L.tgo_reset_data.argtypes = [P(Model), P(Data)]
     L.tgo_forward.argtypes = [P(Model), P(Data)]
     L.tgo_step.argtypes = [P(Model), P(Data), C.c_int]
+    L.tgo_hfield_census.argtypes = [P(Model), P(Data), P(C.c_int)]
     L.tgo_env_default_cfg.argtypes = [P(EnvCfg), C.c_int, C.c_int]
     L.tgo_env_init.argtypes = [P(Env), P(EnvCfg)]
     L.tgo_env_obs_dim.argtypes = [P(EnvCfg)]

@@ -510,6 +510,77 @@ static void hfield_bars(const tgo_model* m, tgo_data* d) {
   }
 }
 
+/* Census for DESIGN.md's heightfield assumptions (development aid; not on the path of tgo_step): with the kinematics d holds, how many
+ * grid triangles does each cap touch (MuJoCo: one contact per prism touched; hfield_caps keeps the two deepest) and how many grid edges
+ * does each bar's cylinder touch (hfield_bars keeps the deepest).  out[0..5] = triangles per cap, out[6..8] = edges per bar. */
+void tgo_hfield_census(const tgo_model* m, const tgo_data* d, int* out) {
+  for (int i = 0; i < 9; i++) out[i] = 0;
+  if (!m->hf_data) return;
+  const int nr = m->hf_nrow, nc = m->hf_ncol;
+  const double rx = m->hf_size[0], ry = m->hf_size[1], ez = m->hf_size[2];
+  const double dx = 2 * rx / (nc - 1), dy = 2 * ry / (nr - 1);
+  for (int k = 0; k < 6; k++) {
+    const double rad = m->cap_radius;
+    const double* cw = d->cap_xpos[k];
+    double p[3] = {cw[0] - m->hf_pos[0], cw[1] - m->hf_pos[1], cw[2] - m->hf_pos[2]};
+    if (p[0] < -rx - rad || p[0] > rx + rad || p[1] < -ry - rad || p[1] > ry + rad || p[2] > ez + rad) continue;
+    int c0 = (int)floor((p[0] - rad + rx) / dx), c1 = (int)floor((p[0] + rad + rx) / dx);
+    int r0 = (int)floor((p[1] - rad + ry) / dy), r1 = (int)floor((p[1] + rad + ry) / dy);
+    if (c0 < 0) c0 = 0;
+    if (r0 < 0) r0 = 0;
+    if (c1 > nc - 2) c1 = nc - 2;
+    if (r1 > nr - 2) r1 = nr - 2;
+    for (int r = r0; r <= r1; r++)
+      for (int c = c0; c <= c1; c++) {
+        double v[4][3];
+        for (int j = 0; j < 4; j++) {
+          int cc = c + (j >> 1), rr = r + (j & 1);
+          v[j][0] = cc * dx - rx; v[j][1] = rr * dy - ry; v[j][2] = (double)m->hf_data[rr * nc + cc] * ez;
+        }
+        for (int tri = 0; tri < 2; tri++) {
+          double q[3];
+          closest_on_triangle(p, v[tri], v[tri + 1], v[tri + 2], q);
+          double dif[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+          if (norm3(dif) - rad < 0) out[k]++;
+        }
+      }
+  }
+  for (int b = 0; b < TGO_NBAR; b++) {
+    const double rad = m->rcyl_radius, H = m->bar_half;
+    const double* R = d->xmat[b];
+    double a[3] = {R[2], R[5], R[8]};
+    double c[3] = {d->xpos[b][0] - m->hf_pos[0], d->xpos[b][1] - m->hf_pos[1], d->xpos[b][2] - m->hf_pos[2]};
+    double ex = fabs(a[0]) * H + rad, ey = fabs(a[1]) * H + rad;
+    if (c[0] + ex < -rx || c[0] - ex > rx || c[1] + ey < -ry || c[1] - ey > ry) continue;
+    if (c[2] - fabs(a[2]) * H - rad > ez) continue;
+    int c0 = (int)floor((c[0] - ex + rx) / dx), c1 = (int)floor((c[0] + ex + rx) / dx) + 1;
+    int r0 = (int)floor((c[1] - ey + ry) / dy), r1 = (int)floor((c[1] + ey + ry) / dy) + 1;
+    if (c0 < 0) c0 = 0;
+    if (r0 < 0) r0 = 0;
+    if (c1 > nc - 1) c1 = nc - 1;
+    if (r1 > nr - 1) r1 = nr - 1;
+    for (int r = r0; r <= r1; r++)
+      for (int cc = c0; cc <= c1; cc++) {
+        static const int E[3][4] = {{0, 0, 1, 0}, {0, 0, 0, 1}, {0, 1, 1, 0}};
+        for (int k = 0; k < 3; k++) {
+          int ca = cc + E[k][0], ra = r + E[k][1], cb = cc + E[k][2], rb = r + E[k][3];
+          if (ca > nc - 1 || cb > nc - 1 || ra > nr - 1 || rb > nr - 1) continue;
+          double va[3] = {ca * dx - rx, ra * dy - ry, (double)m->hf_data[ra * nc + ca] * ez};
+          double vb[3] = {cb * dx - rx, rb * dy - ry, (double)m->hf_data[rb * nc + cb] * ez};
+          double mid[3], ed[3];
+          for (int i = 0; i < 3; i++) { mid[i] = 0.5 * (va[i] + vb[i]); ed[i] = vb[i] - va[i]; }
+          double el = norm3(ed);
+          if (el < MINVAL) continue;
+          for (int i = 0; i < 3; i++) ed[i] /= el;
+          double s_, t_, df[3];
+          seg_seg(c, a, H, mid, ed, 0.5 * el, &s_, &t_);
+          for (int i = 0; i < 3; i++) df[i] = c[i] + s_ * a[i] - (mid[i] + t_ * ed[i]);
+          if (norm3(df) - rad < 0) out[6 + b]++;
+        }
+      }
+  }
+}
+
 static void collision(const tgo_model* m, tgo_data* d) {
   d->ncon = 0;
   if (m->hf_data) { hfield_caps(m, d); hfield_bars(m, d); }

@@ -214,3 +214,38 @@ def test_a_deep_bar_crossing_carries_the_three_contacts_mujoco_would_keep():
     assert np.abs(got - want).max() < 1e-8, (got, want)
     assert abs(want[8] - 6.435e-3) < 1e-5 and abs(want[4]) > 5e-3 and env.stats()["dropped_contacts"] == 0   # translation and rotation
     env.close()
+
+
+# ------------------------------------------------------------------ heightfield floor, closed form (no oracle involved): tests/hfield_known.py
+@pytest.mark.parametrize("prec,layout", [("f64", "row"), ("f32", "row"), ("f64", "block")])
+@pytest.mark.parametrize("case", ["groove", "ridge"])
+def test_free_bars_on_a_zigzag_heightfield_rest_at_the_closed_form_height(prec, layout, case):
+    """Uneven-ground model (MODEL = 1 kernels) on a synthetic zigzag terrain.  groove: a free bar along a V-groove rests with each cap on both
+    walls -- two facets per cap (page 1 of the contact slots), each carrying m g / (4 cos theta): axis (r_cap - p) / cos theta above the groove
+    line; the contact set is also what MuJoCo's one-contact-per-prism rule gives.  ridge: a free bar balanced across a ridge rests on the grid
+    edge with one contact carrying m g (the documented rule for a bar's cylinder: deepest grid edge; MuJoCo would report two tilted contacts).
+    Pins cell size (2 radius / (ncol - 1)), elevation scale, geom offset, facet normals and force sharing with no oracle in the loop."""
+    import hfield_known as HK
+    from tensegrity_rl_amd import TensegrityVecEnv
+    n = 16
+    free = dict(gain=0.0, ten_stiffness=[0.0] * 9, ten_damping=[0.0] * 9)
+    env = TensegrityVecEnv(n, "tensegrity_env-v0", precision=prec, auto_reset=False, kernel_layout=layout, use_contact_forces=1,
+                           contact_force_range=(-1e4, 1e4), terminate_when_unhealthy=0, config_overrides=free,
+                           xml_file="3prism_jonathan_steady_side_uneven_ground.xml", terrain=HK.zigzag_heights())
+    assert env.cfg.model_kind == 1 and env.cfg.cap_radius == HK.R_CAP and tuple(env.cfg.hf_size) == (50.0, 50.0, 1.0, 0.1)
+    qpos, zr = (HK.groove_case if case == "groove" else HK.ridge_case)(n)
+    env.set_state(qpos, np.zeros((n, 18)))
+    zero = np.zeros((n, 6), dtype=np.float32)
+    for _ in range(70):
+        obs, rew, term, trunc, tobs, info = env.step_tensors(zero)
+    st = env.get_state()
+    q = st["qpos"].reshape(n, 3, 7)
+    tol = 2e-7 if prec == "f64" else 3e-6
+    assert np.abs(q[:, :, 2] - zr).max() < tol, (np.abs(q[:, :, 2] - zr).max(), zr[0])
+    assert np.abs(q[:, :, :2] - qpos.reshape(n, 3, 7)[:, :, :2]).max() < (1e-6 if prec == "f64" else 1e-4)     # nothing pushes sideways
+    assert np.abs(st["qvel"]).max() < (1e-6 if prec == "f64" else 2e-3)
+    cc = -info.cpu().numpy()[:, 1]
+    want = 5e-4 * 3 * (HK.M_BAR * HK.G) ** 2                      # cfrc_ext of a resting bar: (no torque, m g up), as on the flat floor
+    assert np.abs(cc - want).max() < (1e-6 if prec == "f64" else 2e-3) * want, (cc.min(), cc.max(), want)
+    assert env.stats()["dropped_contacts"] == 0
+    env.close()
