@@ -249,3 +249,55 @@ def test_free_bars_on_a_zigzag_heightfield_rest_at_the_closed_form_height(prec, 
     assert np.abs(cc - want).max() < (1e-6 if prec == "f64" else 2e-3) * want, (cc.min(), cc.max(), want)
     assert env.stats()["dropped_contacts"] == 0
     env.close()
+
+
+# ------------------------------------------------------------------ smooth dynamics against an independent numpy restatement: tests/smooth_numpy.py
+@pytest.mark.parametrize("model,prec,layout", [("flat", "f64", "row"), ("flat", "f32", "row"), ("flat", "f64", "block"),
+                                               ("uneven", "f64", "row"), ("uneven", "f32", "row"), ("uneven", "f64", "block")])
+def test_an_airborne_control_period_matches_the_numpy_restatement(oracle, model, prec, layout):
+    """One control period (20 sub-steps) of robots in the air -- no contacts, so the sub-step is tendon geometry, spring / damper / actuator
+    forces (affine bias + force clamp on the flat model, filter activations on the uneven one), gyroscopic bias, implicitfast and the
+    quaternion update -- against tests/smooth_numpy.py, which shares no code with oracle/ or the kernels (only the model constants, which
+    tests/test_model_constants.py pins against the reference XMLs).  Actions beyond ctrlrange on purpose (the clip is part of the path)."""
+    import smooth_numpy as SN
+    from tensegrity_rl_amd import TensegrityVecEnv
+    O = oracle
+    m = O.default_model() if model == "flat" else O.uneven_model(None)
+    c = SN.Consts(m)
+    n = 16
+    kw = dict(xml_file="3prism_jonathan_steady_side_uneven_ground.xml", terrain=np.zeros((100, 100), dtype=np.float32)) if model == "uneven" else {}
+    env = TensegrityVecEnv(n, "tensegrity_env-v0", precision=prec, auto_reset=False, kernel_layout=layout, terminate_when_unhealthy=0, **kw)
+    rng = np.random.default_rng(11)
+    roll = O.rolling_qpos()
+    qpos = np.zeros((n, 21)); qvel = np.zeros((n, 18)); act = np.zeros((n, 6))
+    for e in range(n):
+        q = (np.array(m.qpos0[:]) if e % 2 == 0 else roll[e % 6].copy()).reshape(3, 7)
+        q[:, 2] += 5.0
+        q[:, 3:7] += rng.normal(0, 0.02, (3, 4)); q[:, 3:7] /= np.linalg.norm(q[:, 3:7], axis=1, keepdims=True)
+        qpos[e] = q.reshape(21)
+        qvel[e] = np.concatenate([np.concatenate([rng.uniform(-0.5, 0.5, 3), rng.uniform(-2, 2, 3)]) for _ in range(3)])
+        if c.filter:
+            act[e] = rng.uniform(-0.3, 0.1, 6)
+    env.set_state(qpos, qvel)
+    if c.filter:
+        aux = env.get_state()["aux"]; aux[:, 17:23] = act
+        env.set_state(qpos, qvel, aux=aux)
+    a = rng.uniform(-0.6, 0.3, (n, 6)).astype(np.float32)
+    env.step_tensors(a)
+    st = env.get_state()
+    worst_q = worst_v = 0.0
+    for e in range(n):
+        q, v, ac = qpos[e].copy(), qvel[e].copy(), act[e].copy()
+        for s in range(20):
+            q, v, ac, _ = SN.substep(c, q, v, a[e].astype(np.float64), ac)
+        g = st["qpos"][e].copy()
+        for b in range(3):
+            if np.dot(g[7 * b + 3:7 * b + 7], q[7 * b + 3:7 * b + 7]) < 0:
+                g[7 * b + 3:7 * b + 7] *= -1
+        worst_q = max(worst_q, np.abs(g - q).max())
+        worst_v = max(worst_v, np.abs(st["qvel"][e] - v).max() / max(1.0, np.abs(v).max()))
+        if c.filter:
+            assert np.abs(st["aux"][e, 17:23] - ac).max() < (1e-12 if prec == "f64" else 1e-6)
+    assert worst_q < (1e-10 if prec == "f64" else 2e-6), worst_q
+    assert worst_v < (1e-8 if prec == "f64" else 1e-4), worst_v
+    env.close()
