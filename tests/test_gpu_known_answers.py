@@ -301,3 +301,64 @@ def test_an_airborne_control_period_matches_the_numpy_restatement(oracle, model,
     assert worst_q < (1e-10 if prec == "f64" else 2e-6), worst_q
     assert worst_v < (1e-8 if prec == "f64" else 1e-4), worst_v
     env.close()
+
+
+# ------------------------------------------------------------------ kinematics and observation layout against MuJoCo-written observations
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_hip_observations_reproduce_the_mujoco_recorded_ones(oracle, golden_dir, prec):
+    """tests/golden/mujoco_last_obs.json: observations real MuJoCo wrote (SB3 checkpoints of the reference, full precision).  The pose behind
+    each record is recovered on the oracle's kinematics (tests/test_oracle_anchors.py: machine-precision fits), handed to an fp64 handle with
+    everything that moves a bar switched off (no gravity, tendons, actuators; one sub-step per step), and the observation the HIP path then
+    returns must be the recorded one in every entry that is kinematics: tensegrity_env's three geom quaternions (scipy's sign rule, the geom
+    frame's half turn) and nine tendon lengths; tr_env's six cap positions about their centroid and nine tendon lengths.  Uneven-XML table
+    for the records that belong to it, the flat XML's layout with the sites at 0.05 m for the six `models_aiming` checkpoints of that
+    intermediate model version."""
+    import json
+    import os
+    import test_oracle_anchors as A
+    from tensegrity_rl_amd import TensegrityVecEnv
+    O = oracle
+    recs = json.load(open(os.path.join(golden_dir, "mujoco_last_obs.json")))["records"]
+    mu = O.uneven_model(None)
+    flat05 = A._with_site_offset(O.default_model(), 0.05)
+    free = dict(gain=0.0, bias=[0.0, 0.0, 0.0], ten_stiffness=[0.0] * 9, ten_damping=[0.0] * 9, gravity=0.0, frame_skip=1)
+    jobs = {}   # (env id, table) -> list of (qpos, record observation)
+    for r in recs:
+        o = np.array(r["_last_obs"]); dim = r["obs_dim"]
+        if dim == 39:
+            quats = [A._body_quat_from_obs(o[4 * b:4 * b + 4]) for b in range(3)]
+            f = A._fit_relative_positions(O, mu, quats, o[30:39], starts=6)
+            assert np.sqrt(np.mean(f.fun ** 2)) < 1e-12
+            q = np.zeros(21)
+            for b in range(3):
+                q[7 * b + 3:7 * b + 7] = quats[b]
+            q[0:3] = (0, 0, 5.0); q[7:10] = f.x[:3] + (0, 0, 5.0); q[14:17] = f.x[3:] + (0, 0, 5.0)
+            jobs.setdefault(("tensegrity_env-v0", "uneven", 39), []).append((q, o))
+            continue
+        caps = o[:18].reshape(6, 3); tend = o[18:27] if dim == 27 else o[36:45]
+        if max(abs(np.linalg.norm(caps[2 * b] - caps[2 * b + 1]) - 1.376) for b in range(3)) > 1e-9:
+            continue                                           # the noisy record
+        a, q = A._fit_spins(O, mu, caps, tend, want_qpos=True)
+        table = "uneven"
+        if a > 1e-12:
+            a, q = A._fit_spins(O, flat05, caps, tend, want_qpos=True); table = "flat05"
+        assert a < 1e-12
+        jobs.setdefault(("tr_env-v0", table, 27), []).append((q, np.concatenate([o[:18], tend])))
+    assert sorted((k[1], len(v)) for k, v in jobs.items()) == [("flat05", 6), ("uneven", 11), ("uneven", 17)]
+    for (env_id, table, dim), items in jobs.items():
+        n = len(items)
+        kw = dict(xml_file="3prism_jonathan_steady_side_uneven_ground.xml", terrain=np.zeros((100, 100), dtype=np.float32), config_overrides=free) \
+            if table == "uneven" else dict(config_overrides=dict(free, site_offset=0.05))
+        if env_id == "tr_env-v0":
+            kw.update(use_cap_velocity=0)                       # the 27-dim observation: caps + tendon lengths
+        env = TensegrityVecEnv(n, env_id, precision=prec, auto_reset=False, terminate_when_unhealthy=0, **kw)
+        assert env.obs_dim == dim
+        tol = 1e-12 if prec == "f64" else 2e-6                  # (fp32 handle: fp64 pose and kinematics, the observation itself is fp32)
+        env.set_state(np.array([q for q, _ in items]), np.zeros((n, 18)))
+        obs = env.step_tensors(np.zeros((n, 6), dtype=np.float32))[0].cpu().numpy()
+        want = np.array([o for _, o in items])
+        if dim == 39:
+            assert np.abs(obs[:, :12] - want[:, :12]).max() < tol and np.abs(obs[:, 30:] - want[:, 30:]).max() < tol
+        else:
+            assert np.abs(obs - want).max() < tol, np.abs(obs - want).max()
+        env.close()

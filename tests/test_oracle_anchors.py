@@ -1,6 +1,7 @@
 """Physics restatement (oracle/tgr_physics.c) against the only MuJoCo-generated material the reference ships
  plus self-consistency properties.  Physics vs MuJoCo itself stays "parity unpinned"."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -293,6 +294,115 @@ def test_mujoco_recorded_pose_rejects_wrong_tables_and_conventions(oracle):
     for model, quats in ((O.default_model(), good), (O.uneven_model(None), no_half_turn), (O.uneven_model(None), scalar_first)):
         r = _fit_relative_positions(O, model, quats, MJ_TENDONS, starts=8)
         assert np.sqrt(np.mean(r.fun ** 2)) > 3e-3, r.fun
+
+
+# ------------------------------------------------------------------ all 35 checkpoints, full precision (tests/golden/mujoco_last_obs.json)
+def _quat_z_to(axis):
+    a = np.asarray(axis, float) / np.linalg.norm(axis)
+    c = np.cross([0, 0, 1.0], a); w = 1.0 + a[2]
+    q = np.concatenate([[w], c]) if w > 1e-9 else np.array([0.0, 1.0, 0.0, 0.0])
+    return q / np.linalg.norm(q)
+
+
+def _qmul(a, b):
+    aw, ax, ay, az = a; bw, bx, by, bz = b
+    return np.array([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw])
+
+
+def _fit_spins(O, m, caps, tendons, starts=8, want_qpos=False):
+    """tr_env record: the six cap positions fix every bar's centre and axis; what is left is each bar's spin about its own axis -- three
+    unknowns for nine tendon lengths"""
+    from scipy.optimize import least_squares
+    L = O.lib(); d = O.new_data(m)
+    xs = [(caps[2 * b] + caps[2 * b + 1]) / 2 for b in range(3)]
+    q0 = [_quat_z_to(caps[2 * b] - caps[2 * b + 1]) for b in range(3)]   # cap s_2b sits at +z of its bar (flat xml:75-76)
+
+    def res(phi):
+        q = np.zeros(21)
+        for b in range(3):
+            q[7 * b:7 * b + 3] = xs[b] + np.array([0, 0, 5.0])
+            q[7 * b + 3:7 * b + 7] = _qmul(q0[b], np.array([np.cos(phi[b] / 2), 0, 0, np.sin(phi[b] / 2)]))
+        O.arr(d.qpos)[:] = q
+        L.tgo_forward(C.byref(m), C.byref(d))
+        return O.arr(d.ten_length) - tendons
+    rng = np.random.default_rng(0)
+    best = np.inf
+    for _ in range(starts):
+        r = least_squares(res, rng.uniform(-np.pi, np.pi, 3), xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        best = min(best, float(np.sqrt(np.mean(r.fun ** 2))))
+        if best < 1e-12:
+            res(r.x)
+            break
+    return (best, O.arr(d.qpos).copy()) if want_qpos else best      # (qpos: of the last evaluation -- the solution when best < 1e-12)
+
+
+def _with_site_offset(m, off):
+    for i in range(6):
+        x, y = m.site_local[i][0], m.site_local[i][1]
+        r = np.hypot(x, y)
+        m.site_local[i][0] = x / r * off; m.site_local[i][1] = y / r * off
+    return m
+
+
+def test_every_mujoco_recorded_observation_fits_a_site_table_to_machine_precision(oracle, golden_dir):
+    """tests/golden/mujoco_last_obs.json (oracle/extract_last_obs.py): `_last_obs` and `_last_original_obs` of all 35 SB3 checkpoints the
+    reference ships, at full double precision -- 70 observations written by real MuJoCo (the reset observation and a mid-gait one per
+    checkpoint).  tensegrity_env (39): quaternions + tendon lengths, six unknowns for nine equations; tr_env (27 / 45 / 48): the cap positions
+    fix centres and axes, three spins for nine equations.  Solved on the oracle's own kinematics + tendon routine:
+      * every one of the 22 tensegrity_env observations and 34 of the tr_env ones fit the UNEVEN XML's table (sites 0.05 m off the axis, layout
+        of uneven xml:76-81,122-158) to 1e-15 m rms -- machine precision on 9 equations;
+      * the 12 observations of six `models_aiming` checkpoints (_tr, _t, _cw, _ccw) fit the FLAT XML's layout and connectivity (flat
+        xml:82-87,127-164) with the sites 0.05 m off the axis, again to 1e-15: an intermediate version of the model -- today's flat XML
+        moved the sites out to the 0.0675 m cap radius.  That pins the flat model's site layout and tendon connectivity against MuJoCo (the
+        offset itself is a constant tests/test_model_constants.py reads off the XML);
+      * models_forward/SAC_19800000 holds noisy observations (use_obs_noise: its cap pairs are 1.32 .. 1.38 m apart instead of 1.376) and is
+        recognised as such.
+    Besides: cap pairs are 2 x 0.688 m apart and the six relative positions sum to zero to 1e-12 (tr_env's observation layout, tr_env.py:536-552),
+    cap velocities of a bar differ by something perpendicular to it (:586-604), the tracking tail is (waypt - centre, atan2) (:626-636)."""
+    import json
+    O = oracle
+    recs = json.load(open(os.path.join(golden_dir, "mujoco_last_obs.json")))["records"]
+    assert len(recs) == 35
+    mu = O.uneven_model(None)
+    flat05 = _with_site_offset(O.default_model(), 0.05)
+    flat_now = O.default_model()
+    n_uneven = n_flat05 = n_noisy = 0
+    for r in recs:
+        for key in ("_last_obs", "_last_original_obs"):
+            o = np.array(r[key]); dim = r["obs_dim"]
+            assert o.shape == (dim,) and np.isfinite(o).all()
+            if dim == 39:
+                quats = [_body_quat_from_obs(o[4 * b:4 * b + 4]) for b in range(3)]
+                assert max(abs(np.linalg.norm(o[4 * b:4 * b + 4]) - 1) for b in range(3)) < 1e-12
+                f = _fit_relative_positions(O, mu, quats, o[30:39], starts=6)
+                assert np.sqrt(np.mean(f.fun ** 2)) < 1e-12, (r["file"], key, f.fun)
+                n_uneven += 1
+                continue
+            caps = o[:18].reshape(6, 3)
+            tend = o[18:27] if dim == 27 else o[36:45]
+            lens = [np.linalg.norm(caps[2 * b] - caps[2 * b + 1]) for b in range(3)]
+            if max(abs(x - 1.376) for x in lens) > 1e-9:        # observation noise on the cap positions (sigma 0.05 m)
+                assert r["file"].endswith("models_forward/SAC_19800000.zip")
+                n_noisy += 1
+                continue
+            assert np.abs(caps.sum(0)).max() < 1e-12
+            if dim >= 45:
+                vel = o[18:36].reshape(6, 3)
+                for b in range(3):
+                    assert abs(np.dot(vel[2 * b] - vel[2 * b + 1], caps[2 * b] - caps[2 * b + 1])) < 1e-10
+            if dim == 48:
+                assert abs(np.arctan2(o[46], o[45]) - o[47]) < 1e-12
+            a = _fit_spins(O, mu, caps, tend)
+            if a < 1e-12:
+                n_uneven += 1
+                continue
+            b_ = _fit_spins(O, flat05, caps, tend)
+            assert b_ < 1e-12, (r["file"], key, a, b_)
+            assert "models_aiming" in r["file"]
+            assert _fit_spins(O, flat_now, caps, tend, starts=3) > 1e-3      # (not today's 0.0675 m offset)
+            n_flat05 += 1
+    assert (n_uneven, n_flat05, n_noisy) == (22 + 34, 12, 2), (n_uneven, n_flat05, n_noisy)
 
 
 def test_forward_policy_belongs_to_the_uneven_xml_robot(oracle, golden_dir):
