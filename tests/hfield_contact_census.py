@@ -18,7 +18,6 @@ from oracle import oracle as O  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-    sys.path.insert(0, os.path.join(ROOT, "tensegrity_rl_amd"))
     img = np.load(os.path.join(ROOT, "tests", "golden", "terrain_100.npy"))
     a = np.asarray(img, dtype=np.float64)
     a = (a - a.min()) / (a.max() - a.min())
