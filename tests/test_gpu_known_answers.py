@@ -323,8 +323,8 @@ def test_hip_observations_reproduce_the_mujoco_recorded_ones(oracle, golden_dir,
     flat05 = A._with_site_offset(O.default_model(), 0.05)
     free = dict(gain=0.0, bias=[0.0, 0.0, 0.0], ten_stiffness=[0.0] * 9, ten_damping=[0.0] * 9, gravity=0.0, frame_skip=1)
     jobs = {}   # (env id, table) -> list of (qpos, record observation)
-    for r in recs:
-        o = np.array(r["_last_obs"]); dim = r["obs_dim"]
+    for r, key in [(r, key) for r in recs for key in ("_last_original_obs", "_last_obs")]:   # (step t and step t + 1 of one rollout)
+        o = np.array(r[key]); dim = r["obs_dim"]
         if dim == 39:
             quats = [A._body_quat_from_obs(o[4 * b:4 * b + 4]) for b in range(3)]
             f = A._fit_relative_positions(O, mu, quats, o[30:39], starts=6)
@@ -344,7 +344,7 @@ def test_hip_observations_reproduce_the_mujoco_recorded_ones(oracle, golden_dir,
             a, q = A._fit_spins(O, flat05, caps, tend, want_qpos=True); table = "flat05"
         assert a < 1e-12
         jobs.setdefault(("tr_env-v0", table, 27), []).append((q, np.concatenate([o[:18], tend])))
-    assert sorted((k[1], len(v)) for k, v in jobs.items()) == [("flat05", 6), ("uneven", 11), ("uneven", 17)]
+    assert sorted((k[1], len(v)) for k, v in jobs.items()) == [("flat05", 12), ("uneven", 22), ("uneven", 34)]
     for (env_id, table, dim), items in jobs.items():
         n = len(items)
         kw = dict(xml_file="3prism_jonathan_steady_side_uneven_ground.xml", terrain=np.zeros((100, 100), dtype=np.float32), config_overrides=free) \
