@@ -9,7 +9,7 @@ left of the 36 / 33 recorded numbers of step t + 1.  A residual far below the re
 it finds (profiles/round4_mujoco_transition_fit.log) is agreement to a few per cent of the velocity change on the slow records -- the right
 ballpark, not a pin: the model version of the time is not the one of today (its action box, and for six checkpoints its site offset, differ).
 
-    python tests/mujoco_transition_fit.py [substring of the checkpoint path ...] > profiles/roundN_mujoco_transition_fit.log"""
+    python tests/mujoco_transition_fit.py [substring of the checkpoint path ...] [constant=value ...] > profiles/roundN_mujoco_transition_fit.log"""
 import ctypes as C
 import json
 import os
@@ -52,9 +52,25 @@ def statics_start(m, c, q, cap_points):
     return x[:6] / m.gain, x[[8, 11, 14]]
 
 
+OVERRIDES = {}   # model constants to try instead of today's: name=value on the command line (solref0, solref1, act_tau, friction0, ten_damping, ten_stiffness, ...)
+
+
+def model():
+    m = O.uneven_model(None)
+    for k, v in OVERRIDES.items():
+        if k in ("ten_damping", "ten_stiffness"):
+            for t in range(9):
+                getattr(m, k)[t] = v
+        elif k[-1].isdigit() and hasattr(m, k[:-1]):
+            getattr(m, k[:-1])[int(k[-1])] = v
+        else:
+            setattr(m, k, v)
+    return m
+
+
 def fit(rec):
     L = O.lib()
-    m = O.uneven_model(None); c = SN.Consts(m); h = m.timestep; H = m.bar_half
+    m = model(); c = SN.Consts(m); h = m.timestep; H = m.bar_half
     o0 = np.array(rec["_last_original_obs"]); o1 = np.array(rec["_last_obs"]); dim = rec["obs_dim"]
     d = O.new_data(m)
     if dim == 39:
@@ -143,7 +159,10 @@ def fit(rec):
 def main():
     O.build()
     recs = json.load(open(os.path.join(ROOT, "tests", "golden", "mujoco_last_obs.json")))["records"]
-    want = sys.argv[1:]
+    want = [a for a in sys.argv[1:] if "=" not in a]
+    OVERRIDES.update({a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[1:] if "=" in a})
+    if OVERRIDES:
+        print("# model constants overridden:", OVERRIDES)
     print("# fit of the unknowns of the one MuJoCo transition per checkpoint with the oracle (today's uneven-XML robot, flat floor at z = 0)")
     print("# file | obs dim | speed at t | recorded change over the step: pose, velocity | left after the fit: pose, velocity (fraction of the change) | contacts | lowest cap's penetration")
     for r in recs:
