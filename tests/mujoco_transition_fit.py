@@ -55,8 +55,10 @@ def statics_start(m, c, q, cap_points):
 OVERRIDES = {}   # model constants to try instead of today's: name=value on the command line (solref0, solref1, act_tau, friction0, ten_damping, ten_stiffness, ...)
 
 
-def model():
-    m = O.uneven_model(None)
+def model(flat05=False):
+    m = A._with_site_offset(O.default_model(), 0.05) if flat05 else O.uneven_model(None)
+    if flat05:
+        m.cap_radius = 0.05     # (sites sit on the cap's surface in every version of the XML)
     for k, v in OVERRIDES.items():
         if k in ("ten_damping", "ten_stiffness"):
             for t in range(9):
@@ -68,9 +70,9 @@ def model():
     return m
 
 
-def fit(rec):
+def fit(rec, flat05=False):
     L = O.lib()
-    m = model(); c = SN.Consts(m); h = m.timestep; H = m.bar_half
+    m = model(flat05); c = SN.Consts(m); h = m.timestep; H = m.bar_half
     o0 = np.array(rec["_last_original_obs"]); o1 = np.array(rec["_last_obs"]); dim = rec["obs_dim"]
     d = O.new_data(m)
     if dim == 39:
@@ -92,7 +94,7 @@ def fit(rec):
         caps1, vel1, t1 = o1[:18].reshape(6, 3), o1[18:36].reshape(6, 3), o1[36:45]
         a, ql0 = A._fit_spins(O, m, caps0, t0, want_qpos=True)
         if a > 1e-12:
-            return None                                      # (the flat-layout checkpoints: another model version altogether)
+            return None if flat05 else fit(rec, flat05=True)     # (six models_aiming checkpoints: the flat XML's layout, sites at 0.05 m)
         ql0 = ql0.copy(); ql0[2::7] -= 5.0
         axes = [(caps0[2 * b] - caps0[2 * b + 1]) / (2 * H) for b in range(3)]
         vlin = [(vel0[2 * b] + vel0[2 * b + 1]) / 2 for b in range(3)]
@@ -112,6 +114,9 @@ def fit(rec):
             capz.append(q0[7 * b + 2] + s * H * ez[2]); pts.append((b, s * H * ez - np.array([0, 0, m.cap_radius])))
     low = np.argsort(capz)[:3]
     act0, normal = statics_start(m, c, q0, [pts[k] for k in low])
+    if flat05:      # affine actuators: F = gain ctrl + b0 + b1 L (+ b2 Ldot): the statics force names ctrl; `act` is not a state of this model
+        Lq0 = SN.tendons(c, q0)[0][:6]
+        act0 = np.clip((act0 * m.gain - m.bias0 - m.bias1 * Lq0) / m.gain, -0.45, 0.15)
     zlow = min(capz)
 
     def predict(p):
