@@ -63,6 +63,9 @@ def model(flat05=False):
         if k in ("ten_damping", "ten_stiffness"):
             for t in range(9):
                 getattr(m, k)[t] = v
+        elif k in ("ten_damping_act", "ten_stiffness_act", "ten_damping_pas", "ten_stiffness_pas"):   # the six actuated / the three passive tendons
+            for t in (range(6) if k.endswith("_act") else range(6, 9)):
+                getattr(m, k[:-4])[t] = v
         elif k[-1].isdigit() and hasattr(m, k[:-1]):
             getattr(m, k[:-1])[int(k[-1])] = v
         else:
